@@ -1,0 +1,170 @@
+/*
+ * ugsm.h -- C-ABI of libugsm.so: the MI355X (gfx950) pyramidal dense stereo matcher
+ * that replaces ug_stereomatcher's MatchGPULib + MatchLib.cu behind the
+ * UG_matcher_gpu node / GetDisparitiesGPU.srv.
+ *
+ * Plain C, plain pointers and sizes; no torch, OpenCV or ROS types.  File:line
+ * citations are relative to /root/reference/src/gpu_matcher/ and name the reference
+ * interface each entry point replaces.  The reference's own C boundary
+ * (25 one-kernel `extern "C"` wrappers, MatchLib_common.h:35-74 and
+ * MatchGPULib.cpp:45-247) is deliberately NOT replicated: that granularity is what
+ * forces ~130 launches per iteration.  INTEGRATION.md shows the MatchGPULib shim and
+ * the node-side binding.
+ *
+ * Threading: calls on one ctx must be serialised by the caller (the reference node
+ * is a single-threaded ros::spin, UG_GPU_matcher.cpp:749-752).  Different slots of a
+ * ctx run concurrently on the device.  No entry point calls exit(); every failure is
+ * a status code (reference: checkCudaErrors -> exit(EXIT_FAILURE)).
+ */
+#ifndef UGSM_H
+#define UGSM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGSM_ABI_VERSION 1
+
+/* status codes */
+#define UGSM_OK                0
+#define UGSM_ERR_BAD_ARG       1  /* null pointer, non-positive size, bad slot/level */
+#define UGSM_ERR_SIZE_MISMATCH 2  /* left/right differ, or stride < 3*W (ref: unchecked, MatchGPULib.cpp:315-323) */
+#define UGSM_ERR_TOO_SMALL     3  /* a pyramid level would be < 1 px (ref: zero-size malloc, MatchGPULib.cpp:1247) */
+#define UGSM_ERR_NO_DEVICE     4  /* no HIP device / HIP runtime unusable */
+#define UGSM_ERR_DEVICE        5  /* a HIP call failed; see ugsm_last_error */
+#define UGSM_ERR_NOMEM         6
+#define UGSM_ERR_STATE         7  /* e.g. fine phase without coarse phase */
+
+#define UGSM_MAX_LEVELS 32
+
+typedef struct ugsm_ctx ugsm_ctx;
+
+/* Replaces the compile-time/argv configuration of the reference:
+ *   device        <- "-device=N" parsed by findCudaDevice, MatchGPULib.cpp:254
+ *   levels        <- MAX_LEVEL, MatchLib_common.h:13 (14)
+ *   fovea_levels  <- foveatelevel = argv[2] or 7, MatchGPULib.cpp:259-264
+ *   slots         <- pairs in flight (one HIP stream each); the reference has 1
+ *   kernel_path   <- 0: fused gfx950 kernels (default); 1: one-stage-per-kernel
+ *                    path kept for A/B parity checks (same results bit for bit) */
+typedef struct ugsm_config {
+    int device;
+    int levels;
+    int fovea_levels;
+    int slots;
+    int kernel_path;
+    int profile_events; /* 1: slot 0 records HIP events around every match-iteration kernel */
+    int reserved[6];
+} ugsm_config;
+
+void ugsm_default_config(ugsm_config *cfg);
+int ugsm_abi_version(void);
+const char *ugsm_status_string(int status);
+
+/* MatchGPULib::MatchGPULib(argc, argv), MatchGPULib.cpp:251-265.  Owns all device
+ * memory; reused across calls (the reference allocates/frees per level and resets
+ * the device per call, :400).  Buffers grow on demand to the largest size seen. */
+int ugsm_create(const ugsm_config *cfg, ugsm_ctx **out);
+void ugsm_destroy(ugsm_ctx *ctx);
+const char *ugsm_last_error(const ugsm_ctx *ctx);
+
+/* ---- geometry / schedule (pure host; usable without a GPU) ---------------------- */
+
+/* matching(): w[i+1] = (int)(w[i]/1.41421356), MatchGPULib.cpp:1224-1228 */
+int ugsm_level_dims(int W, int H, int levels, int *w, int *h);
+/* matchlevel(): mi = i>5 ? 22 : 2(i+1), MatchGPULib.cpp:1741 */
+int ugsm_level_iterations(int level);
+/* matchlevel(): realSmoothtime 10 for the two finest levels else 5, :2257-2261 */
+int ugsm_level_smooth_passes(int level);
+/* matchlevel(): clamp annealing, :1673 + :2299-2306; out[mi] */
+int ugsm_threshold_schedule(int mi, float *out);
+/* initStack()/getFoveaWidth()/getFoveaHeight(), MatchGPULib.cpp:406-426,268-274 */
+int ugsm_fovea_dims(int W, int H, int levels, int fovea_levels, int *fovW, int *fovH);
+/* Sum over levels of iterations x pixels; fovea_levels==0 => full-resolution mode */
+long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
+
+/* ---- the service path: host buffers in, host buffers out ------------------------ */
+
+/* MatchGPULib::match(L, R, 0), MatchGPULib.cpp:303-403, as used by
+ * GPU_matcher::disparitySrv (UG_GPU_matcher.cpp:645-658) and mainRoutine (:423-442).
+ * rgbL/rgbR: rgb8 rows of `stride` bytes (cv::Mat::step, :318).  dispH/dispV/dispC:
+ * caller-allocated H*W float32 planes (the 32FC1 payloads of dispH/dispV/dispC). */
+int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
+                    int stride, float *dispH, float *dispV, float *dispC);
+
+/* MatchGPULib::matchStack / matchStackPyramid, MatchGPULib.cpp:429-700, plus the
+ * node's stack packing (UG_GPU_matcher.cpp:293-320 disparity stacks, :203-226
+ * pyramid stacks).  stackH/V/C: (fovea_levels*fovH) x fovW float32, level 0 (finest)
+ * first.  pyrL/pyrR (may be NULL): (fovea_levels*3*fovH) x fovW, rows ordered
+ * [level][channel][row].  off_x/off_y: fovea-centre offset from the image centre in
+ * level-0 pixels; (0,0) is the reference's centred fovea (:1173-1176). */
+int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
+                        int stride, int off_x, int off_y, float *stackH, float *stackV,
+                        float *stackC, float *pyrL, float *pyrR);
+
+/* ---- throughput path: device buffers, asynchronous, one slot = one stream ------- */
+
+/* Same computation as ugsm_match_full on device-resident inputs/outputs.
+ * d_out: 3 contiguous H*W planes (dx, dy, conf).  Returns after enqueueing. */
+int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR,
+                     int W, int H, int stride, float *d_out);
+/* Same as ugsm_match_foveated on device buffers; d_stack: 3 x (F*fovH) x fovW. */
+int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR,
+                         int W, int H, int stride, int off_x, int off_y, float *d_stack,
+                         float *d_pyrL, float *d_pyrR);
+int ugsm_wait(ugsm_ctx *ctx, int slot);
+int ugsm_wait_all(ugsm_ctx *ctx);
+
+/* Fovea sharding over several GPUs (north-star; no reference counterpart: the
+ * reference has one centred fovea on one GPU).  coarse: pyramids + levels
+ * top..F-1 on the full frame; d_state receives level F-1's (dx,dy,conf),
+ * 3*fovH*fovW floats -- the 3 MB object broadcast over RCCL.  fine: levels
+ * F-2..0 for the window at (off_x, off_y) from a (possibly received) d_state;
+ * needs the pair's pyramids, so call ugsm_submit_pyramids (or coarse) first. */
+int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR,
+                         int W, int H, int stride);
+int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state);
+int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int off_x, int off_y,
+                           float *d_stack);
+
+/* ---- stage-level entry points (tests only; device pointers; synchronous) -------- */
+
+/* CreatePyramidFromImage, MatchGPULib.cpp:1033-1125: builds the pyramid of one rgb8
+ * image in `slot`'s left pyramid and copies level `level` (3 planes) to d_out3. */
+int ugsm_stage_pyramid(ugsm_ctx *ctx, const uint8_t *d_rgb, int W, int H, int stride, int level,
+                       float *d_out3);
+/* matchlevel, MatchGPULib.cpp:1662-2489: iterations m_from..m_to of a level with mi
+ * iterations and S smoothing passes.  d_dbg8 (may be NULL): 5 Q planes + dx',dy',kappa
+ * before smoothing, of the last iteration run (kernel_path 1 only). */
+int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, float *d_d3, int W,
+                       int H, int mi, int S, int is_top, int m_from, int m_to, float *d_dbg8);
+/* subsampleDisp / foveatedsubsampleDisp, MatchGPULib.cpp:1526-1655 */
+int ugsm_stage_seed(ugsm_ctx *ctx, const float *d_src3, int W, int H, float *d_dst3, int W2, int H2,
+                    int Wup, int Hup, int crop_x, int crop_y);
+/* S smoothing passes (+ box if do_box), MatchGPULib.cpp:2257-2412, in place */
+int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int do_box);
+
+/* ---- instrumentation ------------------------------------------------------------ */
+
+typedef struct ugsm_kernel_stat {
+    char name[48];
+    long long launches;
+    double total_ms;        /* sum of HIP-event durations (profile_events, slot 0) */
+    double pixel_launches;  /* sum over launches of pixels processed */
+} ugsm_kernel_stat;
+
+/* Fills up to `cap` entries; returns the number of kernel classes. */
+int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap);
+int ugsm_reset_kernel_stats(ugsm_ctx *ctx);
+
+/* Device-memory helpers so a C/C++ host (the ROS node) needs no HIP headers. */
+int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes);
+int ugsm_dev_free(ugsm_ctx *ctx, void *d_ptr);
+int ugsm_copy_to_device(ugsm_ctx *ctx, void *d_dst, const void *h_src, long long bytes);
+int ugsm_copy_to_host(ugsm_ctx *ctx, void *h_dst, const void *d_src, long long bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGSM_H */

@@ -1,0 +1,96 @@
+"""The C-ABI library without a GPU: it loads, exports every symbol include/ugsm.h declares, and
+its pure-host geometry agrees with the oracle.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from ug_stereomatcher_amd import _lib
+    return _lib
+
+
+def test_header_symbols_are_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ugsm.h")).read()
+    declared = sorted(set(re.findall(r"\b(ugsm_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 30
+    assert sorted(lib.EXPORTS) == declared, "ug_stereomatcher_amd/_lib.py EXPORTS out of date with include/ugsm.h"
+    so = C.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
+    assert lib.load().ugsm_abi_version() == 1
+
+
+def test_status_strings(lib):
+    for st in range(0, 8):
+        assert lib.status_string(st) != "unknown status"
+    assert lib.status_string(99) == "unknown status"
+
+
+def test_geometry_matches_oracle(lib, orc):
+    for (W, H, lv) in [(4928, 3264, 14), (1920, 1080, 14), (640, 480, 14), (640, 480, 3), (160, 120, 8), (97, 61, 5)]:
+        assert lib.level_dims(W, H, lv) == orc.level_dims(W, H, lv)
+    for i in range(20):
+        assert lib.level_iterations(i) == orc.iterations_for_level(i)
+        assert lib.level_smooth_passes(i) == orc.smooth_passes_for_level(i)
+    for mi in (2, 4, 6, 8, 10, 12, 22):
+        assert lib.threshold_schedule(mi).tobytes() == orc.threshold_schedule(mi).tobytes()
+    assert lib.fovea_dims(4928, 3264, 14, 7) == (615, 407)
+    assert lib.fovea_dims(1920, 1080, 14, 7) == (239, 134)
+
+
+def test_pixel_iterations_match_survey(lib):
+    # SURVEY.md Appendix B / BASELINE.md section 2
+    assert lib.pixel_iterations(4928, 3264, 14, 0) == 131429636
+    assert lib.pixel_iterations(4928, 3264, 14, 7) == 21414118
+    assert lib.pixel_iterations(1920, 1080, 14, 0) == 16897288
+    assert lib.pixel_iterations(1920, 1080, 14, 7) == 2726516
+    assert lib.pixel_iterations(640, 480, 14, 0) == 2480040
+    assert lib.pixel_iterations(640, 480, 3, 0) == 1684758
+
+
+def test_bad_arguments_are_status_codes_not_exits(lib):
+    so = lib.load()
+    w = (C.c_int * 32)()
+    h = (C.c_int * 32)()
+    assert so.ugsm_level_dims(0, 10, 3, w, h) == lib.UGSM_ERR_BAD_ARG
+    assert so.ugsm_level_dims(10, 10, 40, w, h) == lib.UGSM_ERR_BAD_ARG
+    assert so.ugsm_level_dims(64, 48, 14, w, h) == lib.UGSM_ERR_TOO_SMALL  # reference: zero-size mallocs
+    assert so.ugsm_level_dims(64, 48, 3, None, h) == lib.UGSM_ERR_BAD_ARG
+    assert so.ugsm_create(None, None) == lib.UGSM_ERR_BAD_ARG
+    cfg = lib.Config()
+    so.ugsm_default_config(C.byref(cfg))
+    assert (cfg.levels, cfg.fovea_levels, cfg.slots, cfg.device) == (14, 7, 1, 0)
+    cfg.levels = 0
+    hnd = C.c_void_p()
+    assert so.ugsm_create(C.byref(cfg), C.byref(hnd)) == lib.UGSM_ERR_BAD_ARG
+
+
+def test_no_device_fails_loudly(lib):
+    """On a box without a GPU the product must refuse, not fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(lib.UgsmError) as e:
+        lib.Context()
+    assert e.value.status == lib.UGSM_ERR_NO_DEVICE
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/."""
+    pkg = os.path.join(ROOT, "ug_stereomatcher_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "ugsm_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read()

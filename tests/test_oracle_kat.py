@@ -1,0 +1,206 @@
+"""Known-answer tests that pin the CPU oracle to the reference source.
+
+The reference has no tests or golden data; these are the analytic cases derivable from its
+source plus the one executable fragment (convolutionSeparable_gold.cpp -> blur_gold.npz).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, load_golden
+
+
+def test_gauss_taps_bit_patterns(orc):
+    # MatchGPULib.cpp:761-774; SURVEY.md A.1: LE hex 250eb93d ea9f773e 04d9ab3e
+    g = orc.gauss_taps()
+    assert g.tobytes().hex() == "250eb93dea9f773e04d9ab3eea9f773e250eb93d"
+    assert np.array_equal(orc.box_taps(), np.array([0, 0.3333, 0.3333, 0.3333, 0], np.float32))
+
+
+def test_level_dims_16mp(orc):
+    # SURVEY.md Appendix B
+    w, h = orc.level_dims(4928, 3264, 14)
+    assert w == [4928, 3484, 2463, 1741, 1231, 870, 615, 434, 306, 216, 152, 107, 75, 53]
+    assert h == [3264, 2307, 1631, 1153, 815, 576, 407, 287, 202, 142, 100, 70, 49, 34]
+    w, h = orc.level_dims(1920, 1080, 14)
+    assert w == [1920, 1357, 959, 678, 479, 338, 239, 168, 118, 83, 58, 41, 28, 19]
+    assert h == [1080, 763, 539, 381, 269, 190, 134, 94, 66, 46, 32, 22, 15, 10]
+    with pytest.raises(ValueError):
+        orc.level_dims(64, 48, 14)
+
+
+def test_iteration_and_smoothing_schedule(orc):
+    assert [orc.iterations_for_level(i) for i in range(14)] == [2, 4, 6, 8, 10, 12] + [22] * 8
+    assert [orc.smooth_passes_for_level(i) for i in range(14)] == [10, 10] + [5] * 12
+
+
+def test_threshold_schedule_table(orc):
+    # SURVEY.md A.5 step 5 known-answer table (MatchGPULib.cpp:2299-2306)
+    f = np.float32
+    table = {
+        2: [1, 1],
+        4: [1, 1, .1, .1],
+        6: [1, 1, .55, .55, .1, .1],
+        8: [1, 1, .7, .7, .4, .4, .1, .1],
+        10: [1, 1, .775, .775, .55, .55, .325, .325, .1, .1],
+        12: [1, 1, .82, .82, .64, .64, .46, .46, .28, .28, .1, .1],
+        22: [1] * 10 + [.55, .55, .46, .46, .37, .37, .28, .28, .19, .19, .1, .1],
+    }
+    for mi, exp in table.items():
+        got = orc.threshold_schedule(mi)
+        assert np.allclose(got, np.array(exp, f), rtol=0, atol=1e-6), (mi, got)
+    # exact: the value is f32(double expression)
+    assert orc.threshold_schedule(6)[2] == f((3 - 1 - 1) * ((1 - 0.1) / (3 - 1.0)) + 0.1)
+
+
+def test_poly_known_answers(orc):
+    # (l,c,r) = (0.5,0.9,0.7) -> b1=.1, c1=-.3, delta=1/6, c*=.908333, corr=.9725
+    d, k = orc.poly(0.9, 0.5, 0.7, 1.0)
+    assert abs(d - 1 / 6) < 1e-6
+    assert abs(k - 0.9725) < 1e-6
+    # c1 >= 0 -> (0, 0.4)
+    assert orc.poly(0.5, 0.5, 0.5, 1.0) == (np.float32(0), np.float32(0.4))
+    assert orc.poly(0.2, 0.5, 0.7, 1.0) == (np.float32(0), np.float32(0.4))
+    # NaN anywhere -> c1 < 0 is false -> (0, 0.4)   (MatchLib.cu:812,834-836)
+    for args in [(np.nan, .5, .7), (.9, np.nan, .7), (.9, .5, np.nan)]:
+        assert orc.poly(*args, 1.0) == (np.float32(0), np.float32(0.4))
+    # clamp to +-thr
+    d, _ = orc.poly(0.9, 0.1, 0.8, 0.1)
+    assert d == np.float32(0.1)
+    d, _ = orc.poly(0.9, 0.8, 0.1, 0.1)
+    assert d == np.float32(-0.1)
+    # c* > 1 -> corr = 1 and delta rescaled by (1-c)/(c*-c)
+    c, l, r = np.float32(0.99), np.float32(0.2), np.float32(0.9)
+    d, k = orc.poly(c, l, r, 1.0)
+    b1 = (r - l) / np.float32(2)
+    c1 = r - (c + b1)
+    dh = np.float32((np.float64(-b1) * 0.5) / np.float64(c1))
+    cstar = (c1 * dh + b1) * dh + c
+    assert cstar > 1 and k == np.float32(1.0)
+    assert d == np.float32(np.float64(dh) * ((1.0 - np.float64(c)) / np.float64(cstar - c)))
+
+
+def test_blur_matches_reference_gold(orc):
+    """Zero-padded row/column conv == the reference's convolutionRowCPU/ColumnCPU outputs
+    (fixture generated from oracle/_ref/libgold.so, i.e. from the reference's own code)."""
+    g = load_golden("blur_gold.npz")
+    taps = g["taps"]
+    assert_bit_equal(taps, orc.gauss_taps(), "taps")
+    for name in "abcd":
+        src = g[f"{name}_src"]
+        row = orc.conv_rows_zero(src, taps)
+        assert_bit_equal(row, g[f"{name}_row"], f"row {name}")
+        assert_bit_equal(orc.conv_cols_zero(row, taps), g[f"{name}_col"], f"col {name}")
+    # all-ones row -> [0.66782004, 0.90964097, 1, ...]
+    r = orc.conv_rows_zero(np.ones((1, 8), np.float32), taps)
+    assert_bit_equal(r, g["ones_row"], "ones")
+    assert r[0, 0] == np.float32(0.66782004) and r[0, 1] == np.float32(0.90964097)
+
+
+def test_blur_matches_live_reference_when_present(orc):
+    gold = orc.gold_lib()
+    if gold is None:
+        pytest.skip("oracle/_ref/libgold.so not built (no /root/reference here)")
+    f32p = C.POINTER(C.c_float)
+    rng = np.random.Generator(np.random.PCG64(11))
+    taps = orc.gauss_taps()
+    for H, W in [(17, 23), (2, 2), (40, 131)]:
+        src = rng.random((H, W), dtype=np.float32) * 1000
+        row = np.empty_like(src)
+        col = np.empty_like(src)
+        gold.convolutionRowCPU(row.ctypes.data_as(f32p), src.ctypes.data_as(f32p), taps.ctypes.data_as(f32p), W, H, 2)
+        gold.convolutionColumnCPU(col.ctypes.data_as(f32p), row.ctypes.data_as(f32p), taps.ctypes.data_as(f32p), W, H, 2)
+        assert_bit_equal(orc.conv(src, taps, "zero"), col, f"{W}x{H}")
+
+
+def test_clamp_conv_constant_field(orc):
+    v = np.full((9, 11), 7.0, np.float32)
+    out = orc.conv(v, orc.gauss_taps(), "clamp")
+    assert np.all(out == out[0, 0]) and abs(out[0, 0] - 7.0) < 1e-5
+    # box gain 0.9999 per pass -> 0.9998.. per iteration
+    d = np.full((3, 9, 11), 1.0, np.float32)
+    b = orc.box3(d)
+    assert abs(b[0, 4, 5] - 0.9999 ** 2) < 1e-6 and np.all(b == b[0, 0, 0])
+
+
+def test_smoothing_leaves_row0_col0(orc):
+    rng = np.random.Generator(np.random.PCG64(3))
+    d = rng.random((3, 13, 17), dtype=np.float32)
+    s = orc.smooth_pass(d)
+    assert np.array_equal(s[:, 0, :], d[:, 0, :]) and np.array_equal(s[:, :, 0], d[:, :, 0])
+    # interior value: weighted cross mean in the reference's order
+    y, x = 5, 7
+    w = d[2]
+    acc = np.float32(0)
+    den = np.float32(0)
+    for (yy, xx) in [(y, x), (y, x - 1), (y, x + 1), (y - 1, x), (y + 1, x)]:
+        acc = np.float32(d[0, yy, xx] * w[yy, xx]) + acc
+        den = den + w[yy, xx]
+    assert s[0, y, x] == np.float32(acc / den)
+    # right/bottom edges clamp
+    y, x = 12, 16
+    acc = den = np.float32(0)
+    for (yy, xx) in [(y, x), (y, x - 1), (y, x), (y - 1, x), (y, x)]:
+        acc = np.float32(d[1, yy, xx] * w[yy, xx]) + acc
+        den = den + w[yy, xx]
+    assert s[1, y, x] == np.float32(acc / den)
+
+
+def test_seed_index_map_and_scale(orc):
+    # MatchLib.cu:381-394: dst = f32(1.41421356 * src[floor((i+.5f)*0.70710677f)])
+    W, H, W2, H2 = 10, 7, 14, 9
+    src = np.arange(3 * H * W, dtype=np.float32).reshape(3, H, W)
+    dst = orc.seed(src, W2, H2)
+    sf = np.float32(1 / 1.41421356)
+    for (iy, ix) in [(0, 0), (3, 5), (8, 13), (8, 0)]:
+        sx = min(int(np.floor(np.float32(np.float32(ix) + np.float32(0.5)) * sf)), W - 1)
+        sy = min(int(np.floor(np.float32(np.float32(iy) + np.float32(0.5)) * sf)), H - 1)
+        for c in range(3):
+            assert dst[c, iy, ix] == np.float32(1.41421356 * np.float64(src[c, sy, sx]))
+
+
+def test_pyramid_structure(orc):
+    rng = np.random.Generator(np.random.PCG64(5))
+    p0 = (rng.random((3, 40, 60), dtype=np.float32) * 255).astype(np.float32)
+    pyr = orc.pyramid(p0, 4)
+    taps = orc.gauss_taps()
+    b0 = orc.conv(np.ascontiguousarray(p0[1]), taps, "zero")
+    # level 2 = blur(level 0)[2y+1, 2x+1]
+    assert_bit_equal(pyr[2][1], b0[1::2, 1::2][: pyr[2].shape[1], : pyr[2].shape[2]], "level2")
+    # level 1 = blur(level 0)[floor((i+.5f)*sqrt2f)]
+    sf = np.float32(1.41421356)
+    ys = np.floor((np.arange(pyr[1].shape[1], dtype=np.float32) + np.float32(0.5)) * sf).astype(int)
+    xs = np.floor((np.arange(pyr[1].shape[2], dtype=np.float32) + np.float32(0.5)) * sf).astype(int)
+    assert_bit_equal(pyr[1][1], b0[ys][:, xs], "level1")
+    b1 = orc.conv(np.ascontiguousarray(pyr[1][0]), taps, "zero")
+    assert_bit_equal(pyr[3][0], b1[1::2, 1::2][: pyr[3].shape[1], : pyr[3].shape[2]], "level3")
+
+
+def test_identical_images_zero_seed_do_not_move(orc):
+    """L == R and a zero seed: the centre correlation is 1 everywhere it is well defined, so the
+    interior parabola step is ~0: exactly -b1/(2 c1) with b1 = (Q_r - Q_l)/2 tiny."""
+    from ug_stereomatcher_amd import synth
+    L, _, _, _ = synth.make_pair(64, 48, 99)
+    pl = orc.rgb_to_planes(L)
+    d0 = np.zeros((3, 48, 64), np.float32)
+    d1, dbg = orc.iterate_level(pl, pl, d0, mi=4, S=5, is_top=True, m_from=1, m_to=1, want_dbg=True)
+    inner = (slice(4, -4), slice(4, -4))
+    assert np.all(dbg[4][inner] > 0.999)  # Q centre ~ 1
+    assert np.all(np.abs(dbg[5][inner]) < 0.05) and np.all(np.abs(dbg[6][inner]) < 0.05)
+    assert np.median(np.abs(dbg[5][inner])) < 1e-3
+
+
+def test_constant_shift_is_recovered(orc):
+    """R(x) = L(x-k): interior dx ~ k.  Statistical only: the nearest-neighbour warp makes the
+    iteration hover around the rounding boundary of floor(x+.5+dx), so each level settles within
+    about half a pixel of the truth (the algorithm's own noise floor)."""
+    from ug_stereomatcher_amd import synth
+    L, _, _, _ = synth.make_pair(200, 150, 42)
+    k = 3
+    R = np.roll(L, k, axis=1)
+    out = orc.match_full(L, R, levels=8)
+    inner = out[0][30:-30, 30:-30]
+    assert abs(np.median(inner) - k) < 0.5
+    assert abs(np.median(out[1][30:-30, 30:-30])) < 0.5
+    assert not np.isnan(out).any()

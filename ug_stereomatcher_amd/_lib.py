@@ -1,0 +1,222 @@
+"""ctypes binding of libugsm.so (include/ugsm.h) -- the only native entry into the product.
+
+There is no CPU fallback: if the HIP library is missing or no device is present every
+compute call raises (UgsmError).  The pure-host geometry calls work without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libugsm.so")
+
+UGSM_OK = 0
+UGSM_ERR_BAD_ARG = 1
+UGSM_ERR_SIZE_MISMATCH = 2
+UGSM_ERR_TOO_SMALL = 3
+UGSM_ERR_NO_DEVICE = 4
+UGSM_ERR_DEVICE = 5
+UGSM_ERR_NOMEM = 6
+UGSM_ERR_STATE = 7
+UGSM_MAX_LEVELS = 32
+
+# every symbol include/ugsm.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
+    "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
+    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_match_full",
+    "ugsm_match_foveated", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
+    "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_stage_pyramid",
+    "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_get_kernel_stats",
+    "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
+]
+
+
+class UgsmError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        super().__init__(f"ugsm status {status}: {what}")
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("levels", C.c_int), ("fovea_levels", C.c_int), ("slots", C.c_int),
+                ("kernel_path", C.c_int), ("profile_events", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_longlong), ("total_ms", C.c_double),
+                ("pixel_launches", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libugsm.so; raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UgsmError(UGSM_ERR_NO_DEVICE, f"{LIB_PATH} not built: run `make -C ug_stereomatcher_amd/csrc`")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    i = C.c_int
+    lib.ugsm_default_config.argtypes = [C.POINTER(Config)]
+    lib.ugsm_default_config.restype = None
+    lib.ugsm_abi_version.restype = i
+    lib.ugsm_status_string.argtypes = [i]
+    lib.ugsm_status_string.restype = C.c_char_p
+    lib.ugsm_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.ugsm_destroy.argtypes = [vp]
+    lib.ugsm_destroy.restype = None
+    lib.ugsm_last_error.argtypes = [vp]
+    lib.ugsm_last_error.restype = C.c_char_p
+    lib.ugsm_level_dims.argtypes = [i, i, i, ip, ip]
+    lib.ugsm_level_iterations.argtypes = [i]
+    lib.ugsm_level_smooth_passes.argtypes = [i]
+    lib.ugsm_threshold_schedule.argtypes = [i, fp]
+    lib.ugsm_fovea_dims.argtypes = [i, i, i, i, ip, ip]
+    lib.ugsm_pixel_iterations.argtypes = [i, i, i, i]
+    lib.ugsm_pixel_iterations.restype = C.c_longlong
+    lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
+    lib.ugsm_match_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
+    lib.ugsm_submit_full.argtypes = [vp, i, vp, vp, i, i, i, vp]
+    lib.ugsm_submit_foveated.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, vp, vp]
+    lib.ugsm_wait.argtypes = [vp, i]
+    lib.ugsm_wait_all.argtypes = [vp]
+    lib.ugsm_submit_pyramids.argtypes = [vp, i, vp, vp, i, i, i]
+    lib.ugsm_submit_fovea_coarse.argtypes = [vp, i, vp]
+    lib.ugsm_submit_fovea_fine.argtypes = [vp, i, vp, i, i, vp]
+    lib.ugsm_stage_pyramid.argtypes = [vp, vp, i, i, i, i, vp]
+    lib.ugsm_stage_iterate.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
+    lib.ugsm_stage_seed.argtypes = [vp, vp, i, i, vp, i, i, i, i, i, i]
+    lib.ugsm_stage_smooth.argtypes = [vp, vp, i, i, i, i]
+    lib.ugsm_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), i]
+    lib.ugsm_reset_kernel_stats.argtypes = [vp]
+    lib.ugsm_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]
+    lib.ugsm_dev_free.argtypes = [vp, vp]
+    lib.ugsm_copy_to_device.argtypes = [vp, vp, vp, C.c_longlong]
+    lib.ugsm_copy_to_host.argtypes = [vp, vp, vp, C.c_longlong]
+    _lib = lib
+    return lib
+
+
+def status_string(st: int) -> str:
+    return load().ugsm_status_string(st).decode()
+
+
+# ---- pure-host geometry (no GPU needed) -------------------------------------------------
+
+def level_dims(W: int, H: int, levels: int = 14):
+    w = (C.c_int * UGSM_MAX_LEVELS)()
+    h = (C.c_int * UGSM_MAX_LEVELS)()
+    st = load().ugsm_level_dims(W, H, levels, w, h)
+    if st:
+        raise UgsmError(st, status_string(st))
+    return list(w[:levels]), list(h[:levels])
+
+
+def level_iterations(level: int) -> int:
+    return load().ugsm_level_iterations(level)
+
+
+def level_smooth_passes(level: int) -> int:
+    return load().ugsm_level_smooth_passes(level)
+
+
+def threshold_schedule(mi: int) -> np.ndarray:
+    out = np.zeros(mi, np.float32)
+    st = load().ugsm_threshold_schedule(mi, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if st:
+        raise UgsmError(st, status_string(st))
+    return out
+
+
+def fovea_dims(W: int, H: int, levels: int = 14, fovea_levels: int = 7):
+    fw, fh = C.c_int(), C.c_int()
+    st = load().ugsm_fovea_dims(W, H, levels, fovea_levels, C.byref(fw), C.byref(fh))
+    if st:
+        raise UgsmError(st, status_string(st))
+    return fw.value, fh.value
+
+
+def pixel_iterations(W: int, H: int, levels: int = 14, fovea_levels: int = 0) -> int:
+    return int(load().ugsm_pixel_iterations(W, H, levels, fovea_levels))
+
+
+# ---- context -----------------------------------------------------------------------------
+
+class Context:
+    """Owns a ugsm_ctx*.  One per device; calls must be serialised by the caller."""
+
+    def __init__(self, device: int = 0, levels: int = 14, fovea_levels: int = 7, slots: int = 1,
+                 kernel_path: int = 0, profile_events: bool = False):
+        lib = load()
+        cfg = Config()
+        lib.ugsm_default_config(C.byref(cfg))
+        cfg.device, cfg.levels, cfg.fovea_levels, cfg.slots = device, levels, fovea_levels, slots
+        cfg.kernel_path, cfg.profile_events = kernel_path, int(profile_events)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        st = lib.ugsm_create(C.byref(cfg), C.byref(self._h))
+        if st:
+            self._h = None
+            raise UgsmError(st, status_string(st) + " (libugsm needs a HIP device; there is no CPU fallback)")
+        self.lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ugsm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def check(self, st: int):
+        if st:
+            raise UgsmError(st, f"{status_string(st)}: {self.lib.ugsm_last_error(self._h).decode()}")
+
+    @property
+    def handle(self):
+        return self._h
+
+    # device memory through the C-ABI (tests / C hosts); bench.py uses torch tensors instead
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self.check(self.lib.ugsm_dev_alloc(self._h, C.byref(p), nbytes))
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(self.lib.ugsm_dev_free(self._h, ptr))
+
+    def to_device(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(arr.nbytes)
+        self.check(self.lib.ugsm_copy_to_device(self._h, p, arr.ctypes.data, arr.nbytes))
+        return p
+
+    def to_host(self, ptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        self.check(self.lib.ugsm_copy_to_host(self._h, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def kernel_stats(self):
+        arr = (KernelStat * 16)()
+        n = self.lib.ugsm_get_kernel_stats(self._h, arr, 16)
+        return [dict(name=arr[k].name.decode(), launches=int(arr[k].launches), total_ms=float(arr[k].total_ms),
+                     pixel_launches=float(arr[k].pixel_launches)) for k in range(min(n, 16))]
+
+    def reset_kernel_stats(self):
+        self.check(self.lib.ugsm_reset_kernel_stats(self._h))

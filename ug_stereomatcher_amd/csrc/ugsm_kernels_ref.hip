@@ -1,0 +1,288 @@
+// ugsm_kernels_ref.hip -- kernel_path 1: one stage per kernel, global memory only.
+//
+// These kernels are the plainest possible gfx950 statement of each stage (one thread per
+// output pixel, every neighbourhood re-read through L1/L2).  They exist to (a) get a
+// first correct HIP path, (b) expose per-stage intermediates to the parity tests and
+// (c) A/B the fused kernels of ugsm_kernels_fused.hip, which must match them bit for
+// bit.  They are NOT the production path (kernel_path 0).
+//
+// Citations: /root/reference/src/gpu_matcher/<file>:<line>.
+#include "ugsm_device.hpp"
+#include "ugsm_launch.hpp"
+
+namespace ugsm {
+
+// --------------------------------------------------------------------------------------
+// MatchGPULib.cpp:332-338 : rgb8 interleaved -> 3 planar f32
+__global__ void k_rgb_planes(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ planes)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *p = rgb + (size_t)y * stride + 3 * x;
+    size_t n = (size_t)W * H, at = (size_t)y * W + x;
+    planes[at] = (float)p[0];
+    planes[n + at] = (float)p[1];
+    planes[2 * n + at] = (float)p[2];
+}
+
+// --------------------------------------------------------------------------------------
+// MatchGPULib.cpp:1071-1096 + MatchLib.cu:71-156,195-278,311-339.
+// dst[x,y] = blur(src)[floor((x+.5f)*sf), floor((y+.5f)*sf)], blur = zero-padded row conv
+// (rounded to f32) then zero-padded column conv.  The reference blurs the whole level and
+// then samples it; only the sampled sites are evaluated here.
+__global__ void k_blur_decimate(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3, int W2, int H2, float sf)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W2) return;
+    const float *src = src3 + (size_t)blockIdx.z * W * H;
+    int sx = tex_index(((float)ix + 0.5f) * sf, W);
+    int sy = tex_index(((float)iy + 0.5f) * sf, H);
+    float r[5];
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+        int yy = sy + j;
+        float v[5];
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {
+            int xx = sx + i;
+            v[i + 2] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(size_t)yy * W + xx] : 0.0f;
+        }
+        r[j + 2] = tap5(v[0], v[1], v[2], v[3], v[4]);
+    }
+    dst3[(size_t)blockIdx.z * W2 * H2 + (size_t)iy * W2 + ix] = tap5(r[0], r[1], r[2], r[3], r[4]);
+}
+
+// --------------------------------------------------------------------------------------
+// MatchLib.cu:372-401 (+ fovea crop MatchGPULib.cpp:1642-1644):
+// dst[x,y] = f32(SCALE * src[floor((x+cx+.5f)*sf), floor((y+cy+.5f)*sf)]), sf=(float)(1/SCALE)
+__global__ void k_seed(const float *__restrict__ src3, int Ws, int Hs, float *__restrict__ dst3, int Wd, int Hd, int cx, int cy)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= Wd) return;
+    const float sf = (float)(1 / UGSM_SCALE);
+    int sx = tex_index(((float)(ix + cx) + 0.5f) * sf, Ws);
+    int sy = tex_index(((float)(iy + cy) + 0.5f) * sf, Hs);
+    float v = src3[(size_t)blockIdx.z * Ws * Hs + (size_t)sy * Ws + sx];
+    dst3[(size_t)blockIdx.z * Wd * Hd + (size_t)iy * Wd + ix] = (float)(UGSM_SCALE * (double)v);
+}
+
+// --------------------------------------------------------------------------------------
+// MatchLib.cu:556-578 + 1461-1565: dst = colconv_clamp(rowconv_clamp(src^2))
+__global__ void k_sqblur_clamp(Img3 src, int W, int H, float *__restrict__ dst3)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    const float *s = src.p + (size_t)blockIdx.z * src.plane;
+    float r[5];
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+        int yy = clampi(iy + j, 0, H - 1);
+        float v[5];
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {
+            float t = s[(size_t)yy * src.pitch + clampi(ix + i, 0, W - 1)];
+            v[i + 2] = t * t;
+        }
+        r[j + 2] = tap5(v[0], v[1], v[2], v[3], v[4]);
+    }
+    dst3[(size_t)blockIdx.z * W * H + (size_t)iy * W + ix] = tap5(r[0], r[1], r[2], r[3], r[4]);
+}
+
+// --------------------------------------------------------------------------------------
+// warpAbyB, MatchLib.cu:499-520
+__global__ void k_warp(Img3 R, const float *__restrict__ d3, int W, int H, float *__restrict__ Rw3)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    size_t n = (size_t)W * H, at = (size_t)iy * W + ix;
+    int sx = tex_index(((float)ix + 0.5f) + d3[at], W);
+    int sy = tex_index(((float)iy + 0.5f) + d3[n + at], H);
+    size_t from = (size_t)sy * R.pitch + sx;
+#pragma unroll
+    for (int k = 0; k < 3; k++) Rw3[k * n + at] = R.p[k * R.plane + from];
+}
+
+// --------------------------------------------------------------------------------------
+// One iteration's cost + update for one pixel (MatchGPULib.cpp:1745-2250), naive form:
+//   P_s(x',y') = L(x',y') * R'(clamp(x'+sx), clamp(y'+sy))         CompareMove   MatchLib.cu:622-624
+//   N_s        = colconv_zero(rowconv_zero(P_s))                    smem convs    :71-278
+//   q_s,k      = clamp01(N_s^2 / (A * B(clamp(x+sx),clamp(y+sy))))  MoveCorrelation :681-687
+//   Q_s        = ((q_s,0 + q_s,1) + q_s,2) / 3.0f                   MatchGPULib.cpp:2033-2070
+//   parabola x (Q0,Q4,Q1), y (Q2,Q4,Q3); kappa = rho_y*rho_x; d += delta; conf blend.
+__global__ void k_cost_ref(Img3 L, const float *__restrict__ Rw3, const float *__restrict__ A3, const float *__restrict__ B3,
+                           const float *__restrict__ d3, float *__restrict__ nd3, int W, int H, float thr, int blend,
+                           float *__restrict__ dbg8)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    const size_t n = (size_t)W * H, at = (size_t)iy * W + ix;
+    const int mvx[5] = {-1, 1, 0, 0, 0};
+    const int mvy[5] = {0, 0, -1, 1, 0};
+    float Q[5];
+    for (int k = 0; k < 3; k++) {
+        const float *Lk = L.p + (size_t)k * L.plane;
+        const float *Rk = Rw3 + k * n;
+        const float a = A3[k * n + at];
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const int sx = mvx[s], sy = mvy[s];
+            float r[5];
+#pragma unroll
+            for (int j = -2; j <= 2; j++) {
+                int yy = iy + j;
+                float v[5];
+#pragma unroll
+                for (int i = -2; i <= 2; i++) {
+                    int xx = ix + i;
+                    float p = 0.0f;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        float lv = Lk[(size_t)yy * L.pitch + xx];
+                        float rv = Rk[(size_t)clampi(yy + sy, 0, H - 1) * W + clampi(xx + sx, 0, W - 1)];
+                        p = lv * rv;
+                    }
+                    v[i + 2] = p;
+                }
+                r[j + 2] = tap5(v[0], v[1], v[2], v[3], v[4]);
+            }
+            float N = tap5(r[0], r[1], r[2], r[3], r[4]);
+            float b = B3[k * n + (size_t)clampi(iy + sy, 0, H - 1) * W + clampi(ix + sx, 0, W - 1)];
+            float q = ncc2(N, a, b);
+            if (k == 0) Q[s] = q;
+            else if (k == 1) Q[s] = q + Q[s];
+            else Q[s] = (Q[s] + q) / 3.0f;
+        }
+    }
+    float ddx, ddy, cx, cy;
+    poly(Q[4], Q[0], Q[1], thr, ddx, cx);
+    poly(Q[4], Q[2], Q[3], thr, ddy, cy);
+    float kap = cy * cx;
+    float ndx = d3[at] + ddx;
+    float ndy = d3[n + at] + ddy;
+    if (blend) kap = blend_conf(d3[2 * n + at], kap);
+    nd3[at] = ndx;
+    nd3[n + at] = ndy;
+    nd3[2 * n + at] = kap;
+    if (dbg8) {
+#pragma unroll
+        for (int s = 0; s < 5; s++) dbg8[s * n + at] = Q[s];
+        dbg8[5 * n + at] = ndx;
+        dbg8[6 * n + at] = ndy;
+        dbg8[7 * n + at] = kap;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// smoothKernel, MatchLib.cu:1092-1145, for dx, dy and conf in one launch.  Row 0 and
+// column 0 pass through (ix>0 && iy>0 guard, :1106).  Weight = pre-pass conf for all three.
+__global__ void k_smooth_pass(const float *__restrict__ s3, float *__restrict__ o3, int W, int H)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    const size_t n = (size_t)W * H, at = (size_t)iy * W + ix;
+    if (ix > 0 && iy > 0) {
+        size_t aw = at - 1, ae = (size_t)iy * W + clampi(ix + 1, 0, W - 1);
+        size_t an = at - W, as = (size_t)clampi(iy + 1, 0, H - 1) * W + ix;
+        const float *cf = s3 + 2 * n;
+        float wc = cf[at], ww = cf[aw], we = cf[ae], wn = cf[an], ws = cf[as];
+        float sumCorr = 0.0f;
+        sumCorr = sumCorr + wc;
+        sumCorr = sumCorr + ww;
+        sumCorr = sumCorr + we;
+        sumCorr = sumCorr + wn;
+        sumCorr = sumCorr + ws;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float *s = s3 + p * n;
+            float sumDisp = 0.0f;
+            sumDisp = s[at] * wc + sumDisp;
+            sumDisp = s[aw] * ww + sumDisp;
+            sumDisp = s[ae] * we + sumDisp;
+            sumDisp = s[an] * wn + sumDisp;
+            sumDisp = s[as] * ws + sumDisp;
+            o3[p * n + at] = sumDisp / sumCorr;
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 3; p++) o3[p * n + at] = s3[p * n + at];
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// convolutionRows/ColumnsKernelTa on dx, dy, conf (MatchGPULib.cpp:2361-2412), clamp
+// addressing, taps {0,.3333,.3333,.3333,0}; row pass rounded to f32 before the column pass.
+__global__ void k_box(const float *__restrict__ s3, float *__restrict__ o3, int W, int H)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    const size_t n = (size_t)W * H;
+    const float *s = s3 + (size_t)blockIdx.z * n;
+    float r[5];
+#pragma unroll
+    for (int j = -2; j <= 2; j++) {
+        const float *row = s + (size_t)clampi(iy + j, 0, H - 1) * W;
+        r[j + 2] = box5(row[clampi(ix - 2, 0, W - 1)], row[clampi(ix - 1, 0, W - 1)], row[ix],
+                        row[clampi(ix + 1, 0, W - 1)], row[clampi(ix + 2, 0, W - 1)]);
+    }
+    o3[(size_t)blockIdx.z * n + (size_t)iy * W + ix] = box5(r[0], r[1], r[2], r[3], r[4]);
+}
+
+// fovea-stack / pyramid-stack packing: plain 2-D crop copy of 3 planes
+__global__ void k_copy_view(Img3 src, int W, int H, float *__restrict__ dst, size_t dst_plane, int dst_pitch)
+{
+    int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    int iy = blockIdx.y;
+    if (ix >= W) return;
+    dst[(size_t)blockIdx.z * dst_plane + (size_t)iy * dst_pitch + ix] = src.p[(size_t)blockIdx.z * src.plane + (size_t)iy * src.pitch + ix];
+}
+
+// ---- launchers -------------------------------------------------------------------------
+
+static inline dim3 grid2(int W, int H, int z = 1) { return dim3((W + 255) / 256, H, z); }
+
+void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes)
+{
+    hipLaunchKernelGGL(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
+}
+void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
+{
+    hipLaunchKernelGGL(k_blur_decimate, grid2(W2, H2, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);
+}
+void launch_seed(hipStream_t st, const float *src3, int Ws, int Hs, float *dst3, int Wd, int Hd, int cx, int cy)
+{
+    hipLaunchKernelGGL(k_seed, grid2(Wd, Hd, 3), dim3(256), 0, st, src3, Ws, Hs, dst3, Wd, Hd, cx, cy);
+}
+void launch_sqblur_clamp_ref(hipStream_t st, Img3 src, int W, int H, float *dst3)
+{
+    hipLaunchKernelGGL(k_sqblur_clamp, grid2(W, H, 3), dim3(256), 0, st, src, W, H, dst3);
+}
+void launch_warp_ref(hipStream_t st, Img3 R, const float *d3, int W, int H, float *Rw3)
+{
+    hipLaunchKernelGGL(k_warp, grid2(W, H), dim3(256), 0, st, R, d3, W, H, Rw3);
+}
+void launch_cost_ref(hipStream_t st, Img3 L, const float *Rw3, const float *A3, const float *B3, const float *d3, float *nd3,
+                     int W, int H, float thr, int blend, float *dbg8)
+{
+    hipLaunchKernelGGL(k_cost_ref, grid2(W, H), dim3(256), 0, st, L, Rw3, A3, B3, d3, nd3, W, H, thr, blend, dbg8);
+}
+void launch_smooth_pass_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
+{
+    hipLaunchKernelGGL(k_smooth_pass, grid2(W, H), dim3(256), 0, st, s3, o3, W, H);
+}
+void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
+{
+    hipLaunchKernelGGL(k_box, grid2(W, H, 3), dim3(256), 0, st, s3, o3, W, H);
+}
+void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch)
+{
+    hipLaunchKernelGGL(k_copy_view, grid2(W, H, 3), dim3(256), 0, st, src, W, H, dst, dst_plane, dst_pitch);
+}
+
+}  // namespace ugsm

@@ -1,0 +1,42 @@
+// ugsm_launch.hpp -- host-visible launchers of the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ugsm {
+
+// A 3-plane float image view: plane k starts at p + k*plane, rows are `pitch` floats
+// apart.  Pyramid levels are dense (pitch == width); fovea crops of the pyramid
+// (CreateFoveatedPyramid, MatchGPULib.cpp:1171-1185) are views into the full level,
+// not copies -- kernels clamp / zero-pad at the view's logical W x H.
+struct Img3 {
+    const float *p;
+    int pitch;
+    size_t plane;
+};
+
+// ---- kernel_path 1 (ugsm_kernels_ref.hip) -------------------------------------------
+void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes);
+void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
+void launch_seed(hipStream_t st, const float *src3, int Ws, int Hs, float *dst3, int Wd, int Hd, int cx, int cy);
+void launch_sqblur_clamp_ref(hipStream_t st, Img3 src, int W, int H, float *dst3);
+void launch_warp_ref(hipStream_t st, Img3 R, const float *d3, int W, int H, float *Rw3);
+void launch_cost_ref(hipStream_t st, Img3 L, const float *Rw3, const float *A3, const float *B3, const float *d3, float *nd3,
+                     int W, int H, float thr, int blend, float *dbg8);
+void launch_smooth_pass_ref(hipStream_t st, const float *s3, float *o3, int W, int H);
+void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H);
+void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch);
+
+// ---- kernel_path 0 (ugsm_kernels_fused.hip) -----------------------------------------
+// One iteration's warp + cost + parabola + update, LDS-tiled.
+void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H,
+                       float thr, int blend);
+// `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
+void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
+// zero-padded blur evaluated at the decimation sites, LDS-tiled
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
+void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
+
+}  // namespace ugsm

@@ -1,0 +1,837 @@
+// ugsm_runtime.cpp -- host runtime + C-ABI of libugsm.so.
+//
+// Replaces the host orchestration of /root/reference/src/gpu_matcher/MatchGPULib.cpp:
+// a persistent context owns every device buffer (the reference mallocs/frees ~23 buffers
+// per level, re-uploads the image planes every iteration and resets the device per call),
+// the pyramid and the disparity state never leave HBM, and each pair in flight has its own
+// HIP stream ("slot") so the launch-bound coarse levels of one pair overlap the
+// bandwidth/VALU-bound fine levels of another.
+#include "../../include/ugsm.h"
+#include "ugsm_launch.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ugsm;
+
+namespace {
+
+constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
+
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COUNT };
+const char *kClassName[2][KC_COUNT] = {
+    {"k_cost_fused", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc"}};
+
+struct EvRec {
+    int kclass;
+    double pixels;
+    hipEvent_t a, b;
+};
+
+struct Slot {
+    hipStream_t st = nullptr;
+    int W = 0, H = 0, levels = 0;
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    size_t off[UGSM_MAX_LEVELS];  // float offset of level i inside pyrL/pyrR
+    float *pyrL = nullptr, *pyrR = nullptr;
+    size_t pyr_cap = 0;  // floats
+    float *A = nullptr, *Rw = nullptr, *B = nullptr, *d0 = nullptr, *d1 = nullptr;
+    size_t lvl_cap = 0;  // floats per 3-plane level buffer
+    uint8_t *rgbL = nullptr, *rgbR = nullptr;
+    size_t rgb_cap = 0;
+    float *hout = nullptr;  // device staging for host-API outputs
+    size_t hout_cap = 0;
+    bool have_pyr = false;
+    bool have_coarse = false;
+    std::vector<EvRec> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace
+
+struct ugsm_ctx {
+    ugsm_config cfg;
+    std::vector<Slot> slots;
+    std::string err;
+    ugsm_kernel_stat stats[KC_COUNT];
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            char b__[512];                                                                            \
+            snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            (ctx)->err = b__;                                                                         \
+            return UGSM_ERR_DEVICE;                                                                   \
+        }                                                                                             \
+    } while (0)
+
+#define UCHK(call)                       \
+    do {                                 \
+        int r__ = (call);                \
+        if (r__ != UGSM_OK) return r__;  \
+    } while (0)
+
+int level_dims(int W, int H, int levels, int *w, int *h)
+{
+    if (W < 1 || H < 1 || levels < 1 || levels > UGSM_MAX_LEVELS) return UGSM_ERR_BAD_ARG;
+    w[0] = W;
+    h[0] = H;
+    for (int i = 0; i < levels - 1; i++) {  // MatchGPULib.cpp:1224-1228
+        w[i + 1] = (int)(w[i] / kScale);
+        h[i + 1] = (int)(h[i] / kScale);
+    }
+    for (int i = 0; i < levels; i++)
+        if (w[i] < 1 || h[i] < 1) return UGSM_ERR_TOO_SMALL;
+    return UGSM_OK;
+}
+
+int level_iterations(int i) { return (i > 5) ? 22 : ((i + 1) * 2); }  // MatchGPULib.cpp:1741
+int level_smooth(int i) { return (i < 2) ? 10 : 5; }                  // MatchGPULib.cpp:2257-2261
+
+void threshold_schedule(int mi, float *out)
+{
+    float threshold = 1.0f;  // MatchGPULib.cpp:1673
+    for (int m = 1; m <= mi; m++) {
+        out[m - 1] = threshold;
+        if (m % 2 == 0) {  // :2299-2306
+            if ((mi / 2 - m / 2) < 7)
+                threshold = (float)(((mi / 2 - m / 2) - 1) * ((1 - 0.1) / (mi / 2 - 1.0)) + 0.1);
+            else
+                threshold = 1.0f;
+        }
+    }
+}
+
+struct FoveaGeom {
+    int fw, fh, Wup, Hup;
+    int ox[UGSM_MAX_LEVELS], oy[UGSM_MAX_LEVELS];  // crop origin at level lev < F-1
+    int cx[UGSM_MAX_LEVELS], cy[UGSM_MAX_LEVELS];  // seed-crop origin for transition lev+1 -> lev
+};
+
+// Reference (off = 0): MatchGPULib.cpp:1143-1146,1173-1176 (pyramid crop) and :1612-1615 (seed crop).
+// The offset generalisation is this build's (DESIGN.md "Fovea windows").
+void fovea_geometry(const int *w, const int *h, int F, int off_x, int off_y, FoveaGeom &g)
+{
+    g.fw = w[F - 1];
+    g.fh = h[F - 1];
+    g.Wup = w[F - 2];
+    g.Hup = h[F - 2];
+    int ex[UGSM_MAX_LEVELS], ey[UGSM_MAX_LEVELS];
+    ex[F - 1] = ey[F - 1] = 0;
+    for (int lev = F - 2; lev >= 0; lev--) {
+        int ccx = w[lev] / 2 - g.fw / 2, ccy = h[lev] / 2 - g.fh / 2;
+        int ox = ccx + (int)lrint(off_x / pow(kScale, lev));
+        int oy = ccy + (int)lrint(off_y / pow(kScale, lev));
+        ox = std::min(std::max(ox, 0), w[lev] - g.fw);
+        oy = std::min(std::max(oy, 0), h[lev] - g.fh);
+        g.ox[lev] = ox;
+        g.oy[lev] = oy;
+        ex[lev] = ox - ccx;
+        ey[lev] = oy - ccy;
+    }
+    for (int lev = F - 2; lev >= 0; lev--) {
+        int lx = g.Wup / 2 - g.fw / 2 + ex[lev] - (int)lrint(kScale * ex[lev + 1]);
+        int ly = g.Hup / 2 - g.fh / 2 + ey[lev] - (int)lrint(kScale * ey[lev + 1]);
+        g.cx[lev] = std::min(std::max(lx, 0), g.Wup - g.fw);
+        g.cy[lev] = std::min(std::max(ly, 0), g.Hup - g.fh);
+    }
+}
+
+// ---- buffers ---------------------------------------------------------------------------
+
+template <class T>
+int grow(ugsm_ctx *ctx, T *&p, size_t &cap, size_t need)
+{
+    if (need <= cap) return UGSM_OK;
+    if (p) HIPCHK(ctx, hipFree(p));
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, need * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        p = nullptr;
+        return UGSM_ERR_NOMEM;
+    }
+    cap = need;
+    return UGSM_OK;
+}
+
+// (dx,dy,conf) ping-pong, A = G*L^2 and (kernel_path 1 only) R' and B: 3-plane buffers sized
+// for the largest level seen.
+int ensure_level_bufs(ugsm_ctx *ctx, Slot &s, size_t lvl)
+{
+    if (lvl <= s.lvl_cap) return UGSM_OK;
+    size_t c;
+    c = s.lvl_cap; UCHK(grow(ctx, s.A, c, lvl));
+    c = s.lvl_cap; UCHK(grow(ctx, s.d0, c, lvl));
+    c = s.lvl_cap; UCHK(grow(ctx, s.d1, c, lvl));
+    if (ctx->cfg.kernel_path == 1) {
+        c = s.lvl_cap; UCHK(grow(ctx, s.Rw, c, lvl));
+        c = s.lvl_cap; UCHK(grow(ctx, s.B, c, lvl));
+    }
+    s.lvl_cap = lvl;
+    return UGSM_OK;
+}
+
+int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H)
+{
+    const int levels = ctx->cfg.levels;
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    UCHK(level_dims(W, H, levels, w, h));
+    size_t tot = 0;
+    for (int i = 0; i < levels; i++) {
+        s.w[i] = w[i];
+        s.h[i] = h[i];
+        s.off[i] = tot;
+        tot += 3 * (size_t)w[i] * h[i];
+    }
+    s.W = W;
+    s.H = H;
+    s.levels = levels;
+    s.have_pyr = false;
+    s.have_coarse = false;
+    if (tot > s.pyr_cap) {
+        size_t cap = s.pyr_cap;
+        UCHK(grow(ctx, s.pyrL, cap, tot));
+        UCHK(grow(ctx, s.pyrR, s.pyr_cap, tot));
+    }
+    const size_t lvl = 3 * (size_t)W * H;
+    UCHK(ensure_level_bufs(ctx, s, lvl));
+    return UGSM_OK;
+}
+
+// ---- event bookkeeping -----------------------------------------------------------------
+
+struct Timer {
+    ugsm_ctx *ctx;
+    Slot *s;
+    bool on;
+    EvRec rec;
+    Timer(ugsm_ctx *c, Slot *sl, int slot_idx, int kclass, double pixels) : ctx(c), s(sl)
+    {
+        on = c->cfg.profile_events && slot_idx == 0;
+        if (!on) return;
+        rec.kclass = kclass;
+        rec.pixels = pixels;
+        for (hipEvent_t *e : {&rec.a, &rec.b}) {
+            if (!s->pool.empty()) {
+                *e = s->pool.back();
+                s->pool.pop_back();
+            } else if (hipEventCreate(e) != hipSuccess) {
+                on = false;
+                return;
+            }
+        }
+        (void)hipEventRecord(rec.a, s->st);
+    }
+    ~Timer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(rec.b, s->st);
+        s->pending.push_back(rec);
+    }
+};
+
+void harvest(ugsm_ctx *ctx, Slot &s)
+{
+    for (EvRec &r : s.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->stats[r.kclass].launches += 1;
+            ctx->stats[r.kclass].total_ms += ms;
+            ctx->stats[r.kclass].pixel_launches += r.pixels;
+        }
+        s.pool.push_back(r.a);
+        s.pool.push_back(r.b);
+    }
+    s.pending.clear();
+}
+
+// ---- stages ----------------------------------------------------------------------------
+
+int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int stride, float *pyr)
+{
+    const int levels = s.levels;
+    const bool ref = ctx->cfg.kernel_path == 1;
+    {
+        Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
+        launch_rgb_planes(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
+    }
+    // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
+    // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
+    for (int i = 0; i < levels; i++) {
+        if (i == 0 && levels > 1) {
+            Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
+            float sf = (float)kScale;
+            if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
+            else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
+        }
+        if (i + 2 < levels) {
+            Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
+            float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
+            if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
+            else launch_blur_decimate(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
+// S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
+// result and `b` is scratch.
+int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, int H, int S, bool do_box)
+{
+    const double px = (double)W * H;
+    if (ctx->cfg.kernel_path == 1) {
+        for (int j = 0; j < S; j++) {
+            Timer t(ctx, &s, si, KC_SMOOTH, px);
+            launch_smooth_pass_ref(s.st, a, b, W, H);
+            std::swap(a, b);
+        }
+        if (do_box) {
+            Timer t(ctx, &s, si, KC_BOX, px);
+            launch_box_ref(s.st, a, b, W, H);
+            std::swap(a, b);
+        }
+    } else {
+        int left = S;
+        do {
+            int p = std::min(left, 5);
+            left -= p;
+            if (p == 0 && !do_box) break;
+            Timer t(ctx, &s, si, KC_SMOOTH, px);
+            launch_smooth_fused(s.st, a, b, W, H, p, do_box && left == 0);
+            std::swap(a, b);
+        } while (left > 0);
+    }
+    return UGSM_OK;
+}
+
+// matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
+// on entry and on exit; other is scratch of the same size.
+int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int mi, int S, bool is_top, int m_from,
+              int m_to, float *&cur, float *&other, float *dbg8)
+{
+    const bool ref = ctx->cfg.kernel_path == 1;
+    const double px = (double)W * H;
+    std::vector<float> thr((size_t)std::max(mi, 1));
+    threshold_schedule(mi, thr.data());
+    {   // A = G_clamp * L^2 does not depend on the iteration: once per level.
+        Timer t(ctx, &s, si, KC_SQBLUR, px);
+        if (ref) launch_sqblur_clamp_ref(s.st, L, W, H, s.A);
+        else launch_sqblur_clamp(s.st, L, W, H, s.A);
+    }
+    for (int m = m_from; m <= m_to; m++) {
+        const int blend = !(is_top && m == 1);  // MatchGPULib.cpp:2223
+        if (ref) {
+            {
+                Timer t(ctx, &s, si, KC_WARP, px);
+                launch_warp_ref(s.st, R, cur, W, H, s.Rw);
+            }
+            {
+                Timer t(ctx, &s, si, KC_SQBLUR, px);
+                launch_sqblur_clamp_ref(s.st, Img3{s.Rw, W, (size_t)W * H}, W, H, s.B);
+            }
+            Timer t(ctx, &s, si, KC_COST, px);
+            launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
+        } else {
+            Timer t(ctx, &s, si, KC_COST, px);
+            launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
+        }
+        float *a = other, *b = cur;
+        UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true));
+        cur = a;
+        other = b;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
+Img3 level_view(const Slot &s, const float *pyr, int lev, int ox, int oy)
+{
+    return Img3{pyr + s.off[lev] + (size_t)oy * s.w[lev] + ox, s.w[lev], (size_t)s.w[lev] * s.h[lev]};
+}
+
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride)
+{
+    if (!d_rgbL || !d_rgbR) return UGSM_ERR_BAD_ARG;
+    if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
+    UCHK(prepare_slot(ctx, s, W, H));
+    UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
+    UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR));
+    s.have_pyr = true;
+    return UGSM_OK;
+}
+
+// matching() with foveatedmatching==0, MatchGPULib.cpp:1196-1318
+int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
+{
+    const int levels = s.levels;
+    float *cur = s.d0, *other = s.d1;
+    const int top = levels - 1;
+    HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
+    for (int i = top; i >= 0; i--) {
+        const int mi = level_iterations(i);
+        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr));
+        if (i > 0) {
+            Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
+            launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+            std::swap(cur, other);
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_out, cur, sizeof(float) * 3 * (size_t)s.W * s.H, hipMemcpyDeviceToDevice, s.st));
+    return UGSM_OK;
+}
+
+// matching() with foveatedmatching==1 (MatchGPULib.cpp:1230-1294), split at level F-1.
+int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
+{
+    const int levels = s.levels, F = ctx->cfg.fovea_levels;
+    if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
+    float *cur = s.d0, *other = s.d1;
+    const int top = levels - 1;
+    HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
+    for (int i = top; i >= F - 1; i--) {
+        const int mi = level_iterations(i);
+        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr));
+        if (i > F - 1) {
+            Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
+            launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+            std::swap(cur, other);
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_state, cur, sizeof(float) * 3 * (size_t)s.w[F - 1] * s.h[F - 1], hipMemcpyDeviceToDevice, s.st));
+    s.have_coarse = true;
+    return UGSM_OK;
+}
+
+int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int off_x, int off_y, float *d_stack,
+                       float *d_pyrL, float *d_pyrR)
+{
+    const int levels = s.levels, F = ctx->cfg.fovea_levels;
+    if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
+    FoveaGeom g;
+    fovea_geometry(s.w, s.h, F, off_x, off_y, g);
+    const size_t fn = (size_t)g.fw * g.fh;
+    float *cur = s.d0, *other = s.d1;
+    HIPCHK(ctx, hipMemcpyAsync(cur, d_state, sizeof(float) * 3 * fn, hipMemcpyDeviceToDevice, s.st));
+    // stack row block F-1 = the whole level F-1 (UG_GPU_matcher.cpp:293-303)
+    launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)(F - 1) * fn, (size_t)F * fn, g.fw);
+    for (int i = F - 2; i >= 0; i--) {
+        {   // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
+            Timer t(ctx, &s, si, KC_SEED, (double)fn);
+            launch_seed(s.st, cur, g.fw, g.fh, other, g.fw, g.fh, g.cx[i], g.cy[i]);
+            std::swap(cur, other);
+        }
+        const int mi = level_iterations(i);
+        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, g.ox[i], g.oy[i]), level_view(s, s.pyrR, i, g.ox[i], g.oy[i]),
+                       g.fw, g.fh, mi, level_smooth(i), false, 1, mi, cur, other, nullptr));
+        launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)i * fn, (size_t)F * fn, g.fw);
+    }
+    // pyramid stacks as the node publishes them (UG_GPU_matcher.cpp:203-213): [level][channel][row]
+    for (int k = 0; k < F; k++) {
+        int ox = (k < F - 1) ? g.ox[k] : 0, oy = (k < F - 1) ? g.oy[k] : 0;
+        if (d_pyrL) launch_copy_view(s.st, level_view(s, s.pyrL, k, ox, oy), g.fw, g.fh, d_pyrL + (size_t)k * 3 * fn, fn, g.fw);
+        if (d_pyrR) launch_copy_view(s.st, level_view(s, s.pyrR, k, ox, oy), g.fw, g.fh, d_pyrR + (size_t)k * 3 * fn, fn, g.fw);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
+int get_slot(ugsm_ctx *ctx, int slot, Slot **out)
+{
+    if (!ctx) return UGSM_ERR_BAD_ARG;
+    if (slot < 0 || slot >= (int)ctx->slots.size()) {
+        ctx->err = "slot out of range";
+        return UGSM_ERR_BAD_ARG;
+    }
+    *out = &ctx->slots[slot];
+    return UGSM_OK;
+}
+
+int stage_in(ugsm_ctx *ctx, Slot &s, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride)
+{
+    if (!rgbL || !rgbR || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
+    const size_t bytes = (size_t)stride * H;
+    if (bytes > s.rgb_cap) {
+        size_t c = s.rgb_cap;
+        UCHK(grow(ctx, s.rgbL, c, bytes));
+        UCHK(grow(ctx, s.rgbR, s.rgb_cap, bytes));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.rgbL, rgbL, bytes, hipMemcpyHostToDevice, s.st));
+    HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st));
+    return UGSM_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C-ABI
+// =========================================================================================
+extern "C" {
+
+void ugsm_default_config(ugsm_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->device = 0;
+    cfg->levels = 14;       // MAX_LEVEL, MatchLib_common.h:13
+    cfg->fovea_levels = 7;  // MatchGPULib.cpp:263
+    cfg->slots = 1;
+    cfg->kernel_path = 0;
+    cfg->profile_events = 0;
+}
+
+int ugsm_abi_version(void) { return UGSM_ABI_VERSION; }
+
+const char *ugsm_status_string(int st)
+{
+    switch (st) {
+    case UGSM_OK: return "ok";
+    case UGSM_ERR_BAD_ARG: return "bad argument";
+    case UGSM_ERR_SIZE_MISMATCH: return "size mismatch";
+    case UGSM_ERR_TOO_SMALL: return "image too small for the requested number of pyramid levels";
+    case UGSM_ERR_NO_DEVICE: return "no HIP device";
+    case UGSM_ERR_DEVICE: return "HIP runtime error";
+    case UGSM_ERR_NOMEM: return "out of device memory";
+    case UGSM_ERR_STATE: return "call sequence error";
+    default: return "unknown status";
+    }
+}
+
+int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
+{
+    if (!out) return UGSM_ERR_BAD_ARG;
+    *out = nullptr;
+    ugsm_config cfg;
+    if (cfg_in) cfg = *cfg_in;
+    else ugsm_default_config(&cfg);
+    if (const char *e = getenv("UGSM_KERNEL_PATH")) cfg.kernel_path = atoi(e);  // A/B switch for debugging
+    if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
+        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels)
+        return UGSM_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return UGSM_ERR_NO_DEVICE;
+    if (cfg.device < 0 || cfg.device >= ndev) return UGSM_ERR_BAD_ARG;
+    if (hipSetDevice(cfg.device) != hipSuccess) return UGSM_ERR_NO_DEVICE;
+    ugsm_ctx *ctx = new ugsm_ctx();
+    ctx->cfg = cfg;
+    ctx->slots.resize(cfg.slots);
+    for (int k = 0; k < KC_COUNT; k++) {
+        memset(&ctx->stats[k], 0, sizeof(ugsm_kernel_stat));
+        snprintf(ctx->stats[k].name, sizeof ctx->stats[k].name, "%s", kClassName[cfg.kernel_path][k]);
+    }
+    for (Slot &s : ctx->slots) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+            ugsm_destroy(ctx);
+            return UGSM_ERR_DEVICE;
+        }
+    }
+    *out = ctx;
+    return UGSM_OK;
+}
+
+void ugsm_destroy(ugsm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    for (Slot &s : ctx->slots) {
+        if (s.st) (void)hipStreamSynchronize(s.st);
+        harvest(ctx, s);
+        for (hipEvent_t e : s.pool) (void)hipEventDestroy(e);
+        for (void *p : {(void *)s.pyrL, (void *)s.pyrR, (void *)s.A, (void *)s.Rw, (void *)s.B, (void *)s.d0, (void *)s.d1,
+                        (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout})
+            if (p) (void)hipFree(p);
+        if (s.st) (void)hipStreamDestroy(s.st);
+    }
+    delete ctx;
+}
+
+const char *ugsm_last_error(const ugsm_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ugsm_level_dims(int W, int H, int levels, int *w, int *h)
+{
+    if (!w || !h) return UGSM_ERR_BAD_ARG;
+    return level_dims(W, H, levels, w, h);
+}
+int ugsm_level_iterations(int level) { return level < 0 ? 0 : level_iterations(level); }
+int ugsm_level_smooth_passes(int level) { return level < 0 ? 0 : level_smooth(level); }
+int ugsm_threshold_schedule(int mi, float *out)
+{
+    if (mi < 1 || !out) return UGSM_ERR_BAD_ARG;
+    threshold_schedule(mi, out);
+    return UGSM_OK;
+}
+int ugsm_fovea_dims(int W, int H, int levels, int F, int *fovW, int *fovH)
+{
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    if (!fovW || !fovH || F < 1 || F > levels) return UGSM_ERR_BAD_ARG;
+    UCHK(level_dims(W, H, levels, w, h));
+    *fovW = w[F - 1];  // MatchGPULib.cpp:419-420
+    *fovH = h[F - 1];
+    return UGSM_OK;
+}
+long long ugsm_pixel_iterations(int W, int H, int levels, int F)
+{
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    if (level_dims(W, H, levels, w, h) != UGSM_OK) return -1;
+    long long tot = 0;
+    for (int i = 0; i < levels; i++) {
+        long long px = (F > 0 && i < F - 1) ? (long long)w[F - 1] * h[F - 1] : (long long)w[i] * h[i];
+        tot += px * level_iterations(i);
+    }
+    return tot;
+}
+
+int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    return enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride);
+}
+
+int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, float *d_out)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_out) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride));
+    return enqueue_full(ctx, *s, slot, d_out);
+}
+
+int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_state) return UGSM_ERR_BAD_ARG;
+    if (!s->have_pyr) return UGSM_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    return enqueue_fovea_coarse(ctx, *s, slot, d_state);
+}
+
+int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int off_x, int off_y, float *d_stack)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_state || !d_stack) return UGSM_ERR_BAD_ARG;
+    if (!s->have_pyr) return UGSM_ERR_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    return enqueue_fovea_fine(ctx, *s, slot, d_state, off_x, off_y, d_stack, nullptr, nullptr);
+}
+
+int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride,
+                         int off_x, int off_y, float *d_stack, float *d_pyrL, float *d_pyrR)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_stack) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride));
+    const int F = ctx->cfg.fovea_levels;
+    if (F < 2) return UGSM_ERR_BAD_ARG;
+    // level F-1's state is parked in the (otherwise idle) A buffer's tail? No: use a dedicated spot
+    // at the end of d_stack's level F-1 block is not 3-plane contiguous, so stage through hout.
+    const size_t fn3 = 3 * (size_t)s->w[F - 1] * s->h[F - 1];
+    UCHK(grow(ctx, s->hout, s->hout_cap, std::max(fn3, s->hout_cap)));
+    UCHK(enqueue_fovea_coarse(ctx, *s, slot, s->hout));
+    return enqueue_fovea_fine(ctx, *s, slot, s->hout, off_x, off_y, d_stack, d_pyrL, d_pyrR);
+}
+
+int ugsm_wait(ugsm_ctx *ctx, int slot)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    HIPCHK(ctx, hipStreamSynchronize(s->st));
+    harvest(ctx, *s);
+    return UGSM_OK;
+}
+
+int ugsm_wait_all(ugsm_ctx *ctx)
+{
+    if (!ctx) return UGSM_ERR_BAD_ARG;
+    for (int i = 0; i < (int)ctx->slots.size(); i++) UCHK(ugsm_wait(ctx, i));
+    return UGSM_OK;
+}
+
+int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
+                    float *dispV, float *dispC)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!dispH || !dispV || !dispC) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
+    const size_t n = (size_t)W * H;
+    UCHK(grow(ctx, s->hout, s->hout_cap, 3 * n));
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
+    UCHK(enqueue_full(ctx, *s, 0, s->hout));
+    HIPCHK(ctx, hipMemcpyAsync(dispH, s->hout, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(dispV, s->hout + n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(dispC, s->hout + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
+int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
+                        int off_y, float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!stackH || !stackV || !stackC) return UGSM_ERR_BAD_ARG;
+    const int F = ctx->cfg.fovea_levels;
+    if (F < 2) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    int fw, fh;
+    UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
+    UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
+    const size_t fn = (size_t)fw * fh, stackn = (size_t)F * fn;
+    // layout of hout: [state 3*fn][stack 3*stackn][pyrL 3*stackn][pyrR 3*stackn]
+    const size_t need = 3 * fn + 3 * stackn + (pyrL ? 3 * stackn : 0) + (pyrR ? 3 * stackn : 0);
+    UCHK(grow(ctx, s->hout, s->hout_cap, need));
+    float *d_state = s->hout, *d_stack = d_state + 3 * fn;
+    float *d_pl = pyrL ? d_stack + 3 * stackn : nullptr;
+    float *d_pr = pyrR ? d_stack + 3 * stackn + (pyrL ? 3 * stackn : 0) : nullptr;
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
+    UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
+    UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, d_pl, d_pr));
+    HIPCHK(ctx, hipMemcpyAsync(stackH, d_stack, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(stackV, d_stack + stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(stackC, d_stack + 2 * stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    if (pyrL) HIPCHK(ctx, hipMemcpyAsync(pyrL, d_pl, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    if (pyrR) HIPCHK(ctx, hipMemcpyAsync(pyrR, d_pr, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
+// ---- stage-level ------------------------------------------------------------------------
+
+int ugsm_stage_pyramid(ugsm_ctx *ctx, const uint8_t *d_rgb, int W, int H, int stride, int level, float *d_out3)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_rgb || !d_out3 || level < 0 || level >= ctx->cfg.levels) return UGSM_ERR_BAD_ARG;
+    if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    UCHK(prepare_slot(ctx, *s, W, H));
+    UCHK(build_pyramid_one(ctx, *s, 0, d_rgb, stride, s->pyrL));
+    HIPCHK(ctx, hipMemcpyAsync(d_out3, s->pyrL + s->off[level], sizeof(float) * 3 * (size_t)s->w[level] * s->h[level],
+                               hipMemcpyDeviceToDevice, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
+int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, float *d_d3, int W, int H, int mi, int S,
+                       int is_top, int m_from, int m_to, float *d_dbg8)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_L3 || !d_R3 || !d_d3 || W < 1 || H < 1 || mi < 1 || m_from < 1 || m_to > mi || S < 0) return UGSM_ERR_BAD_ARG;
+    if (d_dbg8 && ctx->cfg.kernel_path != 1) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    // level buffers sized for this image; the pyramid buffers are not needed here
+    const size_t lvl = 3 * (size_t)W * H;
+    UCHK(ensure_level_bufs(ctx, *s, lvl));
+    float *cur = s->d0, *other = s->d1;
+    HIPCHK(ctx, hipMemcpyAsync(cur, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    const size_t n = (size_t)W * H;
+    UCHK(run_level(ctx, *s, 0, Img3{d_L3, W, n}, Img3{d_R3, W, n}, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
+    HIPCHK(ctx, hipMemcpyAsync(d_d3, cur, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
+int ugsm_stage_seed(ugsm_ctx *ctx, const float *d_src3, int W, int H, float *d_dst3, int W2, int H2, int Wup, int Hup,
+                    int crop_x, int crop_y)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_src3 || !d_dst3 || W < 1 || H < 1 || W2 < 1 || H2 < 1) return UGSM_ERR_BAD_ARG;
+    (void)Wup;
+    (void)Hup;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    launch_seed(s->st, d_src3, W, H, d_dst3, W2, H2, crop_x, crop_y);
+    HIPCHK(ctx, hipGetLastError());
+    return ugsm_wait(ctx, 0);
+}
+
+int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int do_box)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_d3 || W < 1 || H < 1 || passes < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t lvl = 3 * (size_t)W * H;
+    UCHK(ensure_level_bufs(ctx, *s, lvl));
+    float *a = s->d0, *b = s->d1;
+    HIPCHK(ctx, hipMemcpyAsync(a, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    UCHK(enqueue_smooth(ctx, *s, 0, a, b, W, H, passes, do_box != 0));
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(d_d3, a, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
+// ---- instrumentation / memory helpers ---------------------------------------------------
+
+int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap)
+{
+    if (!ctx) return 0;
+    int n = 0;
+    for (int k = 0; k < KC_COUNT && out && n < cap; k++) out[n++] = ctx->stats[k];
+    return KC_COUNT;
+}
+
+int ugsm_reset_kernel_stats(ugsm_ctx *ctx)
+{
+    if (!ctx) return UGSM_ERR_BAD_ARG;
+    for (int k = 0; k < KC_COUNT; k++) {
+        ctx->stats[k].launches = 0;
+        ctx->stats[k].total_ms = 0;
+        ctx->stats[k].pixel_launches = 0;
+    }
+    return UGSM_OK;
+}
+
+int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes)
+{
+    if (!ctx || !d_ptr || bytes < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    hipError_t e = hipMalloc(d_ptr, (size_t)std::max<long long>(bytes, 1));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        return UGSM_ERR_NOMEM;
+    }
+    return UGSM_OK;
+}
+int ugsm_dev_free(ugsm_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return UGSM_ERR_BAD_ARG;
+    if (d_ptr) HIPCHK(ctx, hipFree(d_ptr));
+    return UGSM_OK;
+}
+int ugsm_copy_to_device(ugsm_ctx *ctx, void *d_dst, const void *h_src, long long bytes)
+{
+    if (!ctx || !d_dst || !h_src || bytes < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipMemcpy(d_dst, h_src, (size_t)bytes, hipMemcpyHostToDevice));
+    return UGSM_OK;
+}
+int ugsm_copy_to_host(ugsm_ctx *ctx, void *h_dst, const void *d_src, long long bytes)
+{
+    if (!ctx || !h_dst || !d_src || bytes < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipMemcpy(h_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return UGSM_OK;
+}
+
+}  // extern "C"
