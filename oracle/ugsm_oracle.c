@@ -29,20 +29,34 @@
 
 #define ORC_SCALE 1.41421356 /* MatchLib_common.h:15 (double literal) */
 
+/* Thread policy.  The GPU box reports hundreds of logical CPUs but gives a job a share of
+ * ~16; an OpenMP team sized by omp_get_max_threads() there spins itself to a standstill.
+ * The team size is therefore explicit: UGSM_ORACLE_THREADS or 8 by default, and 1 for
+ * images too small to amortise a fork/join (results never depend on the team size). */
 static int g_threads = 0;
+static int cap_threads(void)
+{
+    if (g_threads > 0) return g_threads;
+    const char *e = getenv("UGSM_ORACLE_THREADS");
+    int n = e ? atoi(e) : 8;
+    return n > 0 ? n : 1;
+}
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
-    return g_threads > 0 ? g_threads : omp_get_max_threads();
+    return cap_threads();
 #else
     return 1;
 #endif
 }
-void orc_set_num_threads(int n)
+void orc_set_num_threads(int n) { g_threads = n; }
+static void pick_threads(size_t pixels)
 {
-    g_threads = n;
 #ifdef _OPENMP
-    if (n > 0) omp_set_num_threads(n);
+    omp_set_dynamic(0);
+    omp_set_num_threads(pixels < 40000 ? 1 : cap_threads());
+#else
+    (void)pixels;
 #endif
 }
 
@@ -115,6 +129,7 @@ void orc_threshold_schedule(int mi, float *out)
 /* MatchGPULib.cpp:332-338 */
 void orc_rgb_to_planes(const uint8_t *rgb, int W, int H, int stride, float *planes)
 {
+    pick_threads((size_t)W * H);
     for (int k = 0; k < 3; k++) {
         float *p = planes + (size_t)k * W * H;
 #pragma omp parallel for schedule(static)
@@ -144,6 +159,7 @@ static inline int tex_index(float coord, int n)
  * convolutionSeparable_gold.cpp:30-41 which skips out-of-range taps. */
 void orc_conv_rows_zero(float *dst, const float *src, int W, int H, const float t[5])
 {
+    pick_threads((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {
         const float *s = src + (size_t)y * W;
@@ -162,6 +178,7 @@ void orc_conv_rows_zero(float *dst, const float *src, int W, int H, const float 
 /* MatchLib.cu:250-259 (+U3) == convolutionSeparable_gold.cpp:59-72 */
 void orc_conv_cols_zero(float *dst, const float *src, int W, int H, const float t[5])
 {
+    pick_threads((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {
         float *o = dst + (size_t)y * W;
@@ -179,6 +196,7 @@ void orc_conv_cols_zero(float *dst, const float *src, int W, int H, const float 
 /* MatchLib.cu:1478-1491 / 1610-1623: sum += tex(x+k, y) * taps[R-k], clamp addressing */
 void orc_conv_rows_clamp(float *dst, const float *src, int W, int H, const float t[5])
 {
+    pick_threads((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {
         const float *s = src + (size_t)y * W;
@@ -194,6 +212,7 @@ void orc_conv_rows_clamp(float *dst, const float *src, int W, int H, const float
 /* MatchLib.cu:1545-1558 / 1677-1690 */
 void orc_conv_cols_clamp(float *dst, const float *src, int W, int H, const float t[5])
 {
+    pick_threads((size_t)W * H);
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < H; y++) {
         float *o = dst + (size_t)y * W;
@@ -210,6 +229,7 @@ void orc_conv_cols_clamp(float *dst, const float *src, int W, int H, const float
 /* MatchLib.cu:320-332: x=(float)ix+0.5f; tex2D(src, x*sf, y*sf) */
 void orc_subsample(float *dst, int W2, int H2, const float *src, int W, int H, float sf)
 {
+    pick_threads((size_t)W2 * H2);
 #pragma omp parallel for schedule(static)
     for (int iy = 0; iy < H2; iy++) {
         float y = (float)iy + 0.5f;
@@ -300,6 +320,7 @@ void orc_poly(float c, float l, float r, float thr, float *delta, float *corr)
  * (MatchGPULib.cpp:1222), SCALE*src in double then stored to float. 3 planes. */
 void orc_seed(float *dst, int W2, int H2, const float *src, int W, int H)
 {
+    pick_threads((size_t)W2 * H2);
     const float sf = 1 / ORC_SCALE;
     for (int c = 0; c < 3; c++) {
         const float *s = src + (size_t)c * W * H;
@@ -322,6 +343,7 @@ void orc_seed(float *dst, int W2, int H2, const float *src, int W, int H)
  * (:1628-1636), then copy rows u..u+fovH-1, cols l..l+fovW-1 (:1642-1644). */
 void orc_seed_fovea(float *dst, int fovW, int fovH, const float *src, int Wup, int Hup, int l, int u)
 {
+    pick_threads((size_t)fovW * fovH);
     const float sf = 1 / ORC_SCALE;
     for (int c = 0; c < 3; c++) {
         const float *s = src + (size_t)c * fovW * fovH;
@@ -349,6 +371,7 @@ void orc_seed_fovea(float *dst, int fovW, int fovH, const float *src, int Wup, i
  * All three planes use the PRE-pass confidence as weight (:2264-2266). */
 void orc_smooth_pass(float *dst3, const float *src3, int W, int H)
 {
+    pick_threads((size_t)W * H);
     size_t n = (size_t)W * H;
     const float *conf = src3 + 2 * n;
     for (int p = 0; p < 3; p++) {
@@ -407,6 +430,7 @@ static inline float clamp01(float v)
 void orc_iterate_level(const float *L, const float *R, float *d, int W, int H, int mi, int S, int is_top,
                        int m_from, int m_to, float *dbg)
 {
+    pick_threads((size_t)W * H);
     const size_t n = (size_t)W * H;
     float g[5];
     orc_gauss_taps(g);

@@ -157,7 +157,8 @@ class Context:
         lib = load()
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))
-        cfg.device, cfg.levels, cfg.fovea_levels, cfg.slots = device, levels, fovea_levels, slots
+        # full-mode users never name fovea_levels; keep the default legal for short pyramids
+        cfg.device, cfg.levels, cfg.fovea_levels, cfg.slots = device, levels, min(fovea_levels, levels), slots
         cfg.kernel_path, cfg.profile_events = kernel_path, int(profile_events)
         self.cfg = cfg
         self._h = C.c_void_p()
