@@ -22,7 +22,8 @@ BASE_SEED = 20250310
 
 
 def _value_noise(rng: np.random.Generator, W: int, H: int, cell: int) -> np.ndarray:
-    """Bilinearly interpolated random lattice with `cell`-pixel spacing, float32 in [0,1)."""
+    """Bilinearly (smoothstep) interpolated random lattice with `cell`-pixel spacing, float32 in [0,1).
+    Separable: interpolate the lattice rows along x first (small), then along y."""
     gw = W // cell + 2
     gh = H // cell + 2
     lat = rng.random((gh, gw), dtype=np.float32)
@@ -35,9 +36,11 @@ def _value_noise(rng: np.random.Generator, W: int, H: int, cell: int) -> np.ndar
     # smoothstep keeps lattice lines from showing up as gradient discontinuities
     fx = fx * fx * (3 - 2 * fx)
     fy = fy * fy * (3 - 2 * fy)
-    top = lat[y0][:, x0] * (1 - fx) + lat[y0][:, x0 + 1] * fx
-    bot = lat[y0 + 1][:, x0] * (1 - fx) + lat[y0 + 1][:, x0 + 1] * fx
-    return top * (1 - fy[:, None]) + bot * fy[:, None]
+    rows = lat[:, x0] * (1 - fx) + lat[:, x0 + 1] * fx  # (gh, W)
+    out = np.take(rows, y0, axis=0)
+    out *= (1 - fy)[:, None]
+    out += np.take(rows, y0 + 1, axis=0) * fy[:, None]
+    return out
 
 
 def _texture(rng: np.random.Generator, W: int, H: int) -> np.ndarray:
@@ -61,24 +64,41 @@ def _texture(rng: np.random.Generator, W: int, H: int) -> np.ndarray:
 def truth_field(W: int, H: int, a: float = 0.01, b: float = 0.002, dy_amp: float = 0.75):
     x = np.arange(W, dtype=np.float64)[None, :]
     y = np.arange(H, dtype=np.float64)[:, None]
-    dx = a * W * (0.5 + 0.5 * np.sin(2 * np.pi * x / W) * np.cos(2 * np.pi * y / H)) + b * x
-    dy = dy_amp * np.sin(2 * np.pi * y / H) + 0.0 * x
-    return dx.astype(np.float32), dy.astype(np.float32)
+    sx = np.sin(2 * np.pi * x / W)  # separable: evaluate the trig on the axes only
+    cy = np.cos(2 * np.pi * y / H)
+    dx = a * W * (0.5 + 0.5 * (sx * cy)) + b * x
+    dy = np.broadcast_to(dy_amp * np.sin(2 * np.pi * y / H), (H, W))
+    return dx.astype(np.float32), np.ascontiguousarray(dy, dtype=np.float32)
 
 
-def _bilinear(img: np.ndarray, sx: np.ndarray, sy: np.ndarray) -> np.ndarray:
+def _bilinear(img: np.ndarray, sx: np.ndarray, sy: np.ndarray, block: int = 64) -> np.ndarray:
+    """Bilinear resample of img at (sx, sy); processed in row blocks so the gathers stay in cache."""
+    out = np.empty(np.broadcast_shapes(sx.shape, sy.shape), np.float32)
+    for y in range(0, out.shape[0], block):
+        ys = sy[y:y + block] if sy.shape[0] > 1 else sy
+        out[y:y + block] = _bilinear_rows(img, sx[y:y + block] if sx.shape[0] > 1 else sx, ys)
+    return out
+
+
+def _bilinear_rows(img: np.ndarray, sx: np.ndarray, sy: np.ndarray) -> np.ndarray:
     H, W = img.shape
     sx = np.clip(sx, 0, W - 1)
     sy = np.clip(sy, 0, H - 1)
-    x0 = np.floor(sx).astype(np.int64)
-    y0 = np.floor(sy).astype(np.int64)
-    x1 = np.minimum(x0 + 1, W - 1)
-    y1 = np.minimum(y0 + 1, H - 1)
+    x0 = np.floor(sx).astype(np.int32)
+    y0 = np.floor(sy).astype(np.int32)
     fx = (sx - x0).astype(np.float32)
     fy = (sy - y0).astype(np.float32)
-    top = img[y0, x0] * (1 - fx) + img[y0, x1] * fx
-    bot = img[y1, x0] * (1 - fx) + img[y1, x1] * fx
-    return top * (1 - fy) + bot * fy
+    x1 = np.minimum(x0 + 1, W - 1)
+    y1 = np.minimum(y0 + 1, H - 1)
+    flat = img.ravel()
+    r0 = y0.astype(np.int64) * W
+    r1 = y1.astype(np.int64) * W
+    top = np.take(flat, r0 + x0)
+    top += (np.take(flat, r0 + x1) - top) * fx
+    bot = np.take(flat, r1 + x0)
+    bot += (np.take(flat, r1 + x1) - bot) * fx
+    top += (bot - top) * fy
+    return top
 
 
 def make_pair(W: int, H: int, seed: int = BASE_SEED, a: float = 0.01, b: float = 0.002,
@@ -89,7 +109,8 @@ def make_pair(W: int, H: int, seed: int = BASE_SEED, a: float = 0.01, b: float =
     ys = np.arange(H, dtype=np.float32)[:, None] - dy
     left = np.empty((H, W, 3), dtype=np.uint8)
     right = np.empty((H, W, 3), dtype=np.uint8)
-    for ch in range(3):
+
+    def channel(ch: int):
         rng = np.random.Generator(np.random.PCG64(seed * 3 + ch))
         tex = _texture(rng, W, H)
         lq = np.clip(np.rint(1.0 + 254.0 * tex), 1, 255)
@@ -97,4 +118,12 @@ def make_pair(W: int, H: int, seed: int = BASE_SEED, a: float = 0.01, b: float =
         # resample the quantised left so that a perfect matcher would see identical greys
         rr = _bilinear(lq.astype(np.float32), xs, ys)
         right[:, :, ch] = np.clip(np.rint(rr), 1, 255).astype(np.uint8)
+
+    if W * H >= 1 << 20:  # channels are independent streams: run them on three threads
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(3) as ex:
+            list(ex.map(channel, range(3)))
+    else:
+        for ch in range(3):
+            channel(ch)
     return left, right, dx, dy
