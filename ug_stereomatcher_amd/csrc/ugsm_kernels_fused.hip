@@ -25,13 +25,12 @@ namespace ugsm {
 // (qx = tid&7, row = tid>>3) -> quad column qx, tile row `row`.
 //
 // LDS images (float, tile-relative column c stored at [c + OX]):
-//   sIdx  [34][38]  source offset of the warped fetch for every pixel of tile+halo3 (all channels)
 //   sR    [34][48]  R' = warped right plane, tile+halo3, edge-replicated (texture clamp)   OX=8
 //   sL    [32][40]  left plane, tile+halo2, ZERO outside the image (smem-conv zero padding) OX=4
 //   sRow  [5][32][32] row-pass of the five product images, rows tile+halo2
 //   sBrow [34][40]  row-pass of R'^2, rows tile+halo3, cols tile+halo4                       OX=4
 //   sB    [30][40]  B = G_clamp*(R'^2), tile+halo1 (only in-image entries are ever read)     OX=4
-// = 47.5 KB -> 3 workgroups (12 waves) per CU.
+// = 42.4 KB -> 3 workgroups (12 waves) per CU.
 //
 // Per channel: P1 fill sL,sR | barrier | P2 row passes | barrier | P2.5 B column pass | barrier |
 // P3 column pass of the 5 products + correlation, accumulated over channels in registers.
@@ -40,7 +39,7 @@ constexpr int SR_W = TX + 16, SR_H = TY + 6, SR_OX = 8;
 constexpr int SL_W = TX + 8, SL_H = TY + 4, SL_OX = 4;
 constexpr int ROW_W = TX, ROW_H = TY + 4;
 constexpr int SB_W = TX + 8, SBROW_H = TY + 6, SB_H = TY + 2, SB_OX = 4;
-constexpr int IDX_W = TX + 6, IDX_H = TY + 6;
+constexpr int IDX_W = TX + 6, IDX_H = TY + 6;  // tile + halo 3: the pixels whose warped fetch the tile needs
 
 struct f4 {
     float v[4];
@@ -74,21 +73,57 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
     __shared__ __attribute__((aligned(16))) float sRow[5 * ROW_H * ROW_W];
     __shared__ __attribute__((aligned(16))) float sBrow[SBROW_H * SB_W];
     __shared__ __attribute__((aligned(16))) float sB[SB_H * SB_W];
-    __shared__ int sIdx[IDX_H * IDX_W];
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const size_t n = (size_t)W * H;
     const int qx = tid & (QX - 1), trow = tid >> 3;  // 8 quad columns x 32 rows
 
-    // ---- P0: warped source offsets for tile+halo3 (warpAbyB, MatchLib.cu:510-515) -------------
-    for (int it = tid; it < IDX_H * IDX_W; it += 256) {
-        const int r = it / IDX_W, c = it - r * IDX_W;
-        const int gx = clampi(x0 + c - 3, 0, W - 1), gy = clampi(y0 + r - 3, 0, H - 1);
-        const size_t at = (size_t)gy * W + gx;
-        const int sx = tex_index(((float)gx + 0.5f) + d3[at], W);
-        const int sy = tex_index(((float)gy + 0.5f) + d3[n + at], H);
-        sIdx[it] = sy * R.pitch + sx;
+    // ---- P0: every global read of the tile is issued up front and parked in registers, so the
+    // three channel rounds below touch LDS only (one exposed memory latency per workgroup instead
+    // of one per channel).  A thread stages the same halo items for all three channels.
+    constexpr int NR = (IDX_H * IDX_W + 255) / 256;        // R' items per thread (tile+halo3)
+    constexpr int NL = (SL_H * (TX + 4) + 255) / 256;      // L items per thread (tile+halo2)
+    float rv[3][NR], lv[3][NL], av[3][4], dv[3][4];
+    int ridx[NR];
+#pragma unroll
+    for (int u = 0; u < NR; u++) {  // warped source offsets (warpAbyB, MatchLib.cu:510-515)
+        const int it = tid + u * 256;
+        ridx[u] = -1;
+        if (it < IDX_H * IDX_W) {
+            const int r = it / IDX_W, c = it - r * IDX_W;
+            const int gx = clampi(x0 + c - 3, 0, W - 1), gy = clampi(y0 + r - 3, 0, H - 1);
+            const size_t at = (size_t)gy * W + gx;
+            const int sx = tex_index(((float)gx + 0.5f) + d3[at], W);
+            const int sy = tex_index(((float)gy + 0.5f) + d3[n + at], H);
+            ridx[u] = sy * R.pitch + sx;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+        const int it = tid + u * 256;
+        const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
+        const int gx = x0 + c - 2, gy = y0 + r - 2;
+        const bool in = it < SL_H * (TX + 4) && gx >= 0 && gx < W && gy >= 0 && gy < H;
+#pragma unroll
+        for (int k = 0; k < 3; k++) lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < NR; u++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
+    {
+        const int gy = y0 + trow, gx0 = x0 + qx * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = trow < TY && gy < H && gx0 + i < W;
+            const size_t at = in ? (size_t)gy * W + gx0 + i : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                av[k][i] = in ? A3[k * n + at] : 1.0f;
+                dv[k][i] = in ? d3[k * n + at] : 0.0f;
+            }
+        }
     }
 
     float Q[5][4];
@@ -97,21 +132,27 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
 #pragma unroll
         for (int i = 0; i < 4; i++) Q[s][i] = 0.0f;
 
+#pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float *Lk = L.p + (size_t)k * L.plane;
-        const float *Rk = R.p + (size_t)k * R.plane;
-        __syncthreads();  // sIdx ready (k==0); previous channel's P3 finished with sRow/sB
-        // ---- P1: stage L (zero outside) and R' (gather, edge replicated) ------------------
-        for (int it = tid; it < IDX_H * IDX_W; it += 256) {
-            const int r = it / IDX_W, c = it - r * IDX_W;
-            sR[r * SR_W + (c - 3 + SR_OX)] = Rk[sIdx[it]];
+        // No barrier needed here: P1 rewrites sL/sR, whose last readers (P2 of the previous channel) are
+        // two barriers back; sRow/sB (still being read by slower threads' P3) are rewritten only after
+        // the barrier that ends P1.
+        // ---- P1: stage L (zero outside) and R' (gather, edge replicated) into LDS ------------
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int it = tid + u * 256;
+            if (it < IDX_H * IDX_W) {
+                const int r = it / IDX_W, c = it - r * IDX_W;
+                sR[r * SR_W + (c - 3 + SR_OX)] = rv[k][u];
+            }
         }
-        for (int it = tid; it < SL_H * (TX + 4); it += 256) {
-            const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
-            const int gx = x0 + c - 2, gy = y0 + r - 2;
-            float v = 0.0f;
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = Lk[(size_t)gy * L.pitch + gx];
-            sL[r * SL_W + (c - 2 + SL_OX)] = v;
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int it = tid + u * 256;
+            if (it < SL_H * (TX + 4)) {
+                const int r = it / (TX + 4), c = it - r * (TX + 4);
+                sL[r * SL_W + (c - 2 + SL_OX)] = lv[k][u];
+            }
         }
         __syncthreads();
         // ---- P2a: row pass of the five products (CompareMove + convolutionRowsKernel) -----
@@ -129,12 +170,12 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             float p[5][8];  // products at columns cx-2 .. cx+5
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float lv = l[j + 2];
-                p[0][j] = lv * rc[j + 1];  // shift (-1, 0)
-                p[1][j] = lv * rc[j + 3];  // shift (+1, 0)
-                p[2][j] = lv * ru[j + 2];  // shift (0, -1)
-                p[3][j] = lv * rd[j + 2];  // shift (0, +1)
-                p[4][j] = lv * rc[j + 2];  // shift (0, 0)
+                const float lvj = l[j + 2];
+                p[0][j] = lvj * rc[j + 1];  // shift (-1, 0)
+                p[1][j] = lvj * rc[j + 3];  // shift (+1, 0)
+                p[2][j] = lvj * ru[j + 2];  // shift (0, -1)
+                p[3][j] = lvj * rd[j + 2];  // shift (0, +1)
+                p[4][j] = lvj * rc[j + 2];  // shift (0, 0)
             }
 #pragma unroll
             for (int s = 0; s < 5; s++) {
@@ -164,7 +205,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         for (int it = tid; it < SB_H * (SB_W / 4); it += 256) {
             const int r = it / (SB_W / 4), q = it - r * (SB_W / 4);  // r: tile row + 1
             float a[4], b[4], c[4], d[4], e[4], o[4];
-            const float *pb = &sBrow[r * SB_W + q * 4];  // sBrow row index = tile row + 3; rows (r-1)-2+3 = r .. r+4
+            const float *pb = &sBrow[r * SB_W + q * 4];  // sBrow row index = tile row + 3; rows r .. r+4
             ld4(pb, a); ld4(pb + SB_W, b); ld4(pb + 2 * SB_W, c); ld4(pb + 3 * SB_W, d); ld4(pb + 4 * SB_W, e);
 #pragma unroll
             for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
@@ -183,9 +224,6 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                 ld4(pb - SB_W + 4, bu);
                 ld4(pb + SB_W + 4, bd);
                 const bool top = (gy == 0), bot = (gy == H - 1);
-                float a4[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) a4[i] = (gx0 + i < W) ? A3[k * n + (size_t)gy * W + gx0 + i] : 1.0f;
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
                     float r0[4], r1[4], r2[4], r3[4], r4[4];
@@ -201,7 +239,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                         else if (s == 2) b = top ? bc[i + 4] : bu[i];
                         else if (s == 3) b = bot ? bc[i + 4] : bd[i];
                         else b = bc[i + 4];
-                        const float q = ncc2(N, a4[i], b);
+                        const float q = ncc2(N, av[k][i], b);
                         if (k == 0) Q[s][i] = q;
                         else if (k == 1) Q[s][i] = q + Q[s][i];
                         else Q[s][i] = (Q[s][i] + q) / 3.0f;
@@ -224,9 +262,9 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                     poly(Q[4][i], Q[0][i], Q[1][i], thr, ddx, cx_);
                     poly(Q[4][i], Q[2][i], Q[3][i], thr, ddy, cy_);
                     float kap = cy_ * cx_;
-                    const float ndx = d3[at] + ddx;
-                    const float ndy = d3[n + at] + ddy;
-                    if (blend) kap = blend_conf(d3[2 * n + at], kap);
+                    const float ndx = dv[0][i] + ddx;
+                    const float ndy = dv[1][i] + ddy;
+                    if (blend) kap = blend_conf(dv[2][i], kap);
                     nd3[at] = ndx;
                     nd3[n + at] = ndy;
                     nd3[2 * n + at] = kap;
@@ -241,144 +279,201 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
 // box filter (convolutionRows/ColumnsKernelTa, :1593-1697) in one launch.
 // =========================================================================================
 //
-// Tile STX x STY outputs, halo h = P (+2 when the box follows: its outer taps have weight 0 but
-// are still multiplied, exactly as in the reference).  The three fields live in LDS for the whole
-// tile+halo; each pass computes into registers, barrier, writes back, barrier.  A pass leaves
-// pixels of global row 0 / column 0 untouched (ix>0 && iy>0 guard) and clamps x+1 / y+1 at the
-// image edge.  Values outside the image are never needed: every tap is either inside the image or
-// clamped onto it.
+// Tile STX x STY outputs.  The three fields (dx, dy, conf) of tile + halo live in LDS for the whole
+// launch: region columns [tileX0-8, tileX0+STX+8), rows [tileY0-7, tileY0+STY+7) -- halo 7 = 5 passes
+// + 2 for the box (its outer taps have weight 0 but are still multiplied, as in the reference); the
+// column origin is a multiple of 4 so that a thread's "quad" (4 consecutive x) is one ds_read_b128.
+// Thread (q, rg) owns quad column q and rows rg, rg+RG, ...; a pass computes into registers,
+// barrier, writes back, barrier.  A pass leaves global row 0 / column 0 untouched (ix>0 && iy>0
+// guard) and clamps x+1 / y+1 at the image edge.  Out-of-image LDS cells hold the clamped pixel;
+// they are refreshed once before the box so that its clamp addressing needs no index logic.
 template <int STX, int STY, int NT>
 __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box)
 {
-    constexpr int HMAX = 7;
-    constexpr int LW = STX + 2 * HMAX + 2;  // +2 keeps the row stride off a multiple of 32 banks
-    constexpr int LH = STY + 2 * HMAX;
+    constexpr int HX = 8, HY = 7;
+    constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
+    constexpr int LW = RWID + 4;             // LDS row stride: +4 keeps rows 16-B aligned and off a 32-bank multiple
+    constexpr int LH = STY + 2 * HY;
+    constexpr int QW = RWID / 4;             // quad columns
+    constexpr int RG = NT / QW;              // row groups
+    constexpr int MAXR = (LH + RG - 1) / RG; // rows per thread per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *f0 = smem, *f1 = smem + LH * LW, *f2 = smem + 2 * LH * LW;
 
     const int tid = threadIdx.x;
-    const int h = P + (do_box ? 2 : 0);
-    const int x0 = blockIdx.x * STX - h, y0 = blockIdx.y * STY - h;  // global coords of LDS (0,0)
-    const int rw = STX + 2 * h, rh = STY + 2 * h;                  // region held in LDS
+    const int tx0 = blockIdx.x * STX, ty0 = blockIdx.y * STY;
+    const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
+    const int h = P + (do_box ? 2 : 0);      // halo actually needed
 
-    // load region; positions outside the image hold the clamped pixel (never used un-clamped)
-    for (int it = tid; it < rw * rh; it += NT) {
-        const int r = it / rw, c = it - r * rw;
-        const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
-        const size_t at = (size_t)gy * W + gx;
-        f0[r * LW + c] = s3[at];
-        f1[r * LW + c] = s3[n + at];
-        f2[r * LW + c] = s3[2 * n + at];
+    // ---- load tile + needed halo (clamped onto the image) -----------------------------------
+    {
+        const int r_lo = HY - h, r_hi = LH - (HY - h);
+        for (int it = tid; it < LH * RWID; it += NT) {
+            const int r = it / RWID, c = it - r * RWID;
+            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+                const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
+                const size_t at = (size_t)gy * W + gx;
+                f0[r * LW + c] = s3[at];
+                f1[r * LW + c] = s3[n + at];
+                f2[r * LW + c] = s3[2 * n + at];
+            }
+        }
     }
     __syncthreads();
 
-    constexpr int MAXPX = ((STX + 2 * HMAX) * (STY + 2 * HMAX) + NT - 1) / NT;
+    const int q = tid % QW, rg = tid / QW;
+    const int c0 = q * 4, gx0 = x0 + c0;
+    const bool lane_on = rg < RG;
+
     for (int p = 1; p <= P; p++) {
-        // after pass p the valid region is the loaded region shrunk by p on every side
-        const int lo = p, wv = rw - 2 * p, hv = rh - 2 * p;
-        float n0[MAXPX], n1[MAXPX], n2[MAXPX];
+        // pass p is needed (and valid) on the region shrunk to halo h-p
+        const int r_lo = HY - (h - p), r_hi = LH - (HY - (h - p));
+        const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p)));
+        float nv[MAXR][3][4];
 #pragma unroll
-        for (int u = 0; u < MAXPX; u++) {
-            const int it = tid + u * NT;
-            if (it < wv * hv) {
-                const int r = lo + it / wv, c = lo + it % wv;
-                const int gx = x0 + c, gy = y0 + r;
-                const int at = r * LW + c;
-                float v0 = f0[at], v1 = f1[at], v2 = f2[at];
-                if (gx > 0 && gy > 0 && gx < W && gy < H) {
-                    const int ae = (gx + 1 <= W - 1) ? at + 1 : at;
-                    const int as = (gy + 1 <= H - 1) ? at + LW : at;
-                    const int aw = at - 1, an = at - LW;
-                    const float wc = f2[at], ww = f2[aw], we = f2[ae], wn = f2[an], ws = f2[as];
+        for (int u = 0; u < MAXR; u++) {
+            const int r = r_lo + rg + u * RG;
+            if (col_on && r < r_hi) {
+                const int gy = y0 + r;
+                const int at = r * LW + c0;
+                float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
+                ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
+                ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
+                ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
+                wl[0] = f0[at - 1]; wl[1] = f1[at - 1]; wl[2] = f2[at - 1];
+                er[0] = f0[at + 4]; er[1] = f1[at + 4]; er[2] = f2[at + 4];
+                const bool row_ok = gy > 0 && gy < H;
+                const bool south_in = gy + 1 <= H - 1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int gx = gx0 + i;
+                    const bool act = row_ok && gx > 0 && gx < W;
+                    const bool east_in = gx + 1 <= W - 1;
+                    float vw[3], ve[3], vs[3];
+#pragma unroll
+                    for (int f = 0; f < 3; f++) {
+                        vw[f] = (i == 0) ? wl[f] : c4[f][i > 0 ? i - 1 : 0];
+                        const float e_raw = (i == 3) ? er[f] : c4[f][i < 3 ? i + 1 : 3];
+                        ve[f] = east_in ? e_raw : c4[f][i];
+                        vs[f] = south_in ? s4[f][i] : c4[f][i];
+                    }
+                    const float wc = c4[2][i], ww = vw[2], we = ve[2], wn = n4[2][i], ws = vs[2];
                     float sumCorr = 0.0f;
                     sumCorr = sumCorr + wc;
                     sumCorr = sumCorr + ww;
                     sumCorr = sumCorr + we;
                     sumCorr = sumCorr + wn;
                     sumCorr = sumCorr + ws;
-                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-                    a0 = f0[at] * wc + a0; a1 = f1[at] * wc + a1; a2 = wc * wc + a2;
-                    a0 = f0[aw] * ww + a0; a1 = f1[aw] * ww + a1; a2 = ww * ww + a2;
-                    a0 = f0[ae] * we + a0; a1 = f1[ae] * we + a1; a2 = we * we + a2;
-                    a0 = f0[an] * wn + a0; a1 = f1[an] * wn + a1; a2 = wn * wn + a2;
-                    a0 = f0[as] * ws + a0; a1 = f1[as] * ws + a1; a2 = ws * ws + a2;
-                    v0 = a0 / sumCorr;
-                    v1 = a1 / sumCorr;
-                    v2 = a2 / sumCorr;
+#pragma unroll
+                    for (int f = 0; f < 3; f++) {
+                        float a = 0.0f;
+                        a = c4[f][i] * wc + a;
+                        a = vw[f] * ww + a;
+                        a = ve[f] * we + a;
+                        a = n4[f][i] * wn + a;
+                        a = vs[f] * ws + a;
+                        nv[u][f][i] = act ? a / sumCorr : c4[f][i];
+                    }
                 }
-                n0[u] = v0; n1[u] = v1; n2[u] = v2;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < MAXPX; u++) {
-            const int it = tid + u * NT;
-            if (it < wv * hv) {
-                const int at = (lo + it / wv) * LW + lo + it % wv;
-                f0[at] = n0[u]; f1[at] = n1[u]; f2[at] = n2[u];
+        for (int u = 0; u < MAXR; u++) {
+            const int r = r_lo + rg + u * RG;
+            if (col_on && r < r_hi) {
+                const int at = r * LW + c0;
+                st4(f0 + at, nv[u][0]); st4(f1 + at, nv[u][1]); st4(f2 + at, nv[u][2]);
             }
         }
         __syncthreads();
     }
 
     if (do_box) {
-        // rows (Ta) on the tile + 2 rows above/below, rounded to f32, then columns (Ta)
-        const int lo = P;  // valid region after the passes starts at P; box row pass needs +-2 columns
-        float *t0 = f0, *t1 = f1, *t2 = f2;
-        constexpr int BMAX = (STX * (STY + 4) + NT - 1) / NT;
-        float b0[BMAX], b1[BMAX], b2[BMAX];
+        // refresh the clamped replicas of out-of-image cells within tile+-2 (only edge tiles have any)
+        if (tx0 - 2 < 0 || ty0 - 2 < 0 || tx0 + STX + 2 > W || ty0 + STY + 2 > H) {
+            for (int it = tid; it < (STY + 4) * (STX + 4); it += NT) {
+                const int r = HY - 2 + it / (STX + 4), c = HX - 2 + it % (STX + 4);
+                const int gx = x0 + c, gy = y0 + r;
+                if (gx < 0 || gx >= W || gy < 0 || gy >= H) {
+                    const int src = (clampi(gy, 0, H - 1) - y0) * LW + clampi(gx, 0, W - 1) - x0;
+                    f0[r * LW + c] = f0[src]; f1[r * LW + c] = f1[src]; f2[r * LW + c] = f2[src];
+                }
+            }
+            __syncthreads();
+        }
+        // rows (Ta): tile columns, rows tile-2 .. tile+STY+1, rounded to f32, written back in place
+        constexpr int BQ = STX / 4, BRG = NT / BQ, BMAXR = (STY + 4 + BRG - 1) / BRG;
+        const int bq = tid % BQ, brg = tid / BQ;
+        const int bc0 = HX + bq * 4;
+        float bv[BMAXR][3][4];
 #pragma unroll
-        for (int u = 0; u < BMAX; u++) {
-            const int it = tid + u * NT;
-            if (it < STX * (STY + 4)) {
-                const int r = lo + it / STX, c = lo + 2 + it % STX;  // rows tile-2 .. tile+STY+1, tile columns
-                const int gx = x0 + c, gy = clampi(y0 + r, 0, H - 1);
-                const int rr = gy - y0;  // clamp rows onto the image (texture clamp)
-                if (gx < W) {
-                    int cm2 = clampi(gx - 2, 0, W - 1) - x0, cm1 = clampi(gx - 1, 0, W - 1) - x0;
-                    int cp1 = clampi(gx + 1, 0, W - 1) - x0, cp2 = clampi(gx + 2, 0, W - 1) - x0;
-                    const float *q0 = t0 + rr * LW, *q1 = t1 + rr * LW, *q2 = t2 + rr * LW;
-                    b0[u] = box5(q0[cm2], q0[cm1], q0[c], q0[cp1], q0[cp2]);
-                    b1[u] = box5(q1[cm2], q1[cm1], q1[c], q1[cp1], q1[cp2]);
-                    b2[u] = box5(q2[cm2], q2[cm1], q2[c], q2[cp1], q2[cp2]);
+        for (int u = 0; u < BMAXR; u++) {
+            const int r = HY - 2 + brg + u * BRG;
+            if (brg < BRG && r < HY + STY + 2) {
+                const int at = r * LW + bc0;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const float *src = (f == 0 ? f0 : (f == 1 ? f1 : f2)) + at;
+                    float v[12];
+                    ld4(src - 4, v); ld4(src, v + 4); ld4(src + 4, v + 8);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bv[u][f][i] = box5(v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
                 }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < BMAX; u++) {
-            const int it = tid + u * NT;
-            if (it < STX * (STY + 4)) {
-                const int r = lo + it / STX, c = lo + 2 + it % STX;
-                if (x0 + c < W) {
-                    t0[r * LW + c] = b0[u]; t1[r * LW + c] = b1[u]; t2[r * LW + c] = b2[u];
-                }
+        for (int u = 0; u < BMAXR; u++) {
+            const int r = HY - 2 + brg + u * BRG;
+            if (brg < BRG && r < HY + STY + 2) {
+                const int at = r * LW + bc0;
+                st4(f0 + at, bv[u][0]); st4(f1 + at, bv[u][1]); st4(f2 + at, bv[u][2]);
             }
         }
         __syncthreads();
-        for (int it = tid; it < STX * STY; it += NT) {
-            const int r = h + it / STX, c = h + it % STX;
-            const int gx = x0 + c, gy = y0 + r;
-            if (gx < W && gy < H) {
-                // row-pass image rows gy-2..gy+2 clamped: a clamped row's row-pass equals the edge row's
-                const int rm2 = clampi(gy - 2, 0, H - 1) - y0, rm1 = clampi(gy - 1, 0, H - 1) - y0;
-                const int rp1 = clampi(gy + 1, 0, H - 1) - y0, rp2 = clampi(gy + 2, 0, H - 1) - y0;
-                const size_t at = (size_t)gy * W + gx;
-                o3[at] = box5(t0[rm2 * LW + c], t0[rm1 * LW + c], t0[r * LW + c], t0[rp1 * LW + c], t0[rp2 * LW + c]);
-                o3[n + at] = box5(t1[rm2 * LW + c], t1[rm1 * LW + c], t1[r * LW + c], t1[rp1 * LW + c], t1[rp2 * LW + c]);
-                o3[2 * n + at] = box5(t2[rm2 * LW + c], t2[rm1 * LW + c], t2[r * LW + c], t2[rp1 * LW + c], t2[rp2 * LW + c]);
+        // columns (Ta) -> global
+        constexpr int CMAXR = (STY + BRG - 1) / BRG;
+#pragma unroll
+        for (int u = 0; u < CMAXR; u++) {
+            const int r = HY + brg + u * BRG;
+            const int gy = y0 + r;
+            if (brg < BRG && r < HY + STY && gy < H) {
+                const int at = r * LW + bc0;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    const float *src = (f == 0 ? f0 : (f == 1 ? f1 : f2)) + at;
+                    float a[4], b[4], c[4], d[4], e[4];
+                    ld4(src - 2 * LW, a); ld4(src - LW, b); ld4(src, c); ld4(src + LW, d); ld4(src + 2 * LW, e);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int gx = x0 + bc0 + i;
+                        if (gx < W) o3[f * n + (size_t)gy * W + gx] = box5(a[i], b[i], c[i], d[i], e[i]);
+                    }
+                }
             }
         }
     } else {
-        for (int it = tid; it < STX * STY; it += NT) {
-            const int r = h + it / STX, c = h + it % STX;
-            const int gx = x0 + c, gy = y0 + r;
-            if (gx < W && gy < H) {
-                const size_t at = (size_t)gy * W + gx;
-                o3[at] = f0[r * LW + c];
-                o3[n + at] = f1[r * LW + c];
-                o3[2 * n + at] = f2[r * LW + c];
+        constexpr int BQ = STX / 4, BRG = NT / BQ, CMAXR = (STY + BRG - 1) / BRG;
+        const int bq = tid % BQ, brg = tid / BQ;
+        const int bc0 = HX + bq * 4;
+#pragma unroll
+        for (int u = 0; u < CMAXR; u++) {
+            const int r = HY + brg + u * BRG;
+            const int gy = y0 + r;
+            if (brg < BRG && r < HY + STY && gy < H) {
+                const int at = r * LW + bc0;
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    float v[4];
+                    ld4((f == 0 ? f0 : (f == 1 ? f1 : f2)) + at, v);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int gx = x0 + bc0 + i;
+                        if (gx < W) o3[f * n + (size_t)gy * W + gx] = v[i];
+                    }
+                }
             }
         }
     }
@@ -395,7 +490,7 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 template <int STX, int STY, int NT>
 static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
-    constexpr int LW = STX + 16, LH = STY + 14;
+    constexpr int LW = STX + 20, LH = STY + 14;
     constexpr size_t bytes = 3 * (size_t)LH * LW * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -408,9 +503,12 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
-    // big levels: 128x64 tiles (halo redundancy ~1.2x); small levels: 64x32 so the chip still fills
-    if ((size_t)W * H >= (size_t)1 << 20) launch_smooth_t<128, 64, 1024>(st, s3, o3, W, H, passes, do_box);
-    else launch_smooth_t<64, 32, 256>(st, s3, o3, W, H, passes, do_box);
+    // big levels: 128x64 tiles (halo redundancy ~1.3x, one 16-wave workgroup per CU);
+    // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
+    const size_t px = (size_t)W * H;
+    if (px >= ((size_t)1 << 20)) launch_smooth_t<128, 64, 1024>(st, s3, o3, W, H, passes, do_box);
+    else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, 256>(st, s3, o3, W, H, passes, do_box);
+    else launch_smooth_t<32, 16, 256>(st, s3, o3, W, H, passes, do_box);
 }
 
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
