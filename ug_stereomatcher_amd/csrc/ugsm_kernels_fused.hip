@@ -22,23 +22,28 @@ namespace ugsm {
 //
 // Tile TX x TY = 32 x 28 output pixels per 256-thread workgroup (4 waves).  A thread owns a
 // "quad" (4 consecutive x) so that every LDS access is a 16-byte ds_read/write_b128; thread
-// (qx = tid&7, row = tid>>3) -> quad column qx, tile row `row`.
+// (row = tid&31, qx = tid>>5) -> tile row `row`, quad column qx.
 //
 // LDS images (float, tile-relative column c stored at [c + OX]):
-//   sR    [34][48]  R' = warped right plane, tile+halo3, edge-replicated (texture clamp)   OX=8
-//   sL    [32][40]  left plane, tile+halo2, ZERO outside the image (smem-conv zero padding) OX=4
-//   sRow  [5][32][32] row-pass of the five product images, rows tile+halo2
-//   sBrow [34][40]  row-pass of R'^2, rows tile+halo3, cols tile+halo4                       OX=4
-//   sB    [30][40]  B = G_clamp*(R'^2), tile+halo1 (only in-image entries are ever read)     OX=4
-// = 42.4 KB -> 3 workgroups (12 waves) per CU.
+//   sR    [34][52]  R' = warped right plane, tile+halo3, edge-replicated (texture clamp)   OX=8
+//   sL    [32][44]  left plane, tile+halo2, ZERO outside the image (smem-conv zero padding) OX=4
+//   sRow  [5][32][36] row-pass of the five product images, rows tile+halo2
+//   sBrow [34][44]  row-pass of R'^2, rows tile+halo3, cols tile+halo4                       OX=4
+//   sB    [30][44]  B = G_clamp*(R'^2), tile+halo1 (only in-image entries are ever read)     OX=4
+// = 47.0 KB -> 3 workgroups (12 waves) per CU.
 //
 // Per channel: P1 fill sL,sR | barrier | P2 row passes | barrier | P2.5 B column pass | barrier |
 // P3 column pass of the 5 products + correlation, accumulated over channels in registers.
+// Row strides are an ODD number of quads (52, 44, 36 floats) and a wave's lanes walk DOWN the rows
+// (row = tid & 31, quad column = tid >> 5): the 16-lane groups of ds_read_b128 then hit 16 distinct
+// 4-bank slots (odd multiplier mod 16 is a bijection) -- conflict-free; with lanes walking along a
+// row the same reads cost 2-3x (rows of 40/48 floats alias in the 64 banks).  Measured:
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 47 % -> see profiles/.
 constexpr int TX = 32, TY = 28, QX = TX / 4;
-constexpr int SR_W = TX + 16, SR_H = TY + 6, SR_OX = 8;
-constexpr int SL_W = TX + 8, SL_H = TY + 4, SL_OX = 4;
-constexpr int ROW_W = TX, ROW_H = TY + 4;
-constexpr int SB_W = TX + 8, SBROW_H = TY + 6, SB_H = TY + 2, SB_OX = 4;
+constexpr int SR_W = TX + 20, SR_H = TY + 6, SR_OX = 8;
+constexpr int SL_W = TX + 12, SL_H = TY + 4, SL_OX = 4;
+constexpr int ROW_W = TX + 4, ROW_H = TY + 4;
+constexpr int SB_W = TX + 12, SB_Q = (TX + 8) / 4, SBROW_H = TY + 6, SB_H = TY + 2, SB_OX = 4;
 constexpr int IDX_W = TX + 6, IDX_H = TY + 6;  // tile + halo 3: the pixels whose warped fetch the tile needs
 
 struct f4 {
@@ -65,6 +70,9 @@ __device__ __forceinline__ float tap5p(float a, float b, float c, float d, float
     return sum;
 }
 
+// ABL: development-only ablation mask (tools/kbench.hip times variants with phases removed to see
+// where the time goes); the product instantiates ABL = 0 only.
+template <int ABL>
 __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                     float *__restrict__ nd3, int W, int H, float thr, int blend)
 {
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
     const size_t n = (size_t)W * H;
-    const int qx = tid & (QX - 1), trow = tid >> 3;  // 8 quad columns x 32 rows
+    const int trow = tid & 31, qx = tid >> 5;  // 32 rows x 8 quad columns, lanes walk down the rows
 
     // ---- P0: every global read of the tile is issued up front and parked in registers, so the
     // three channel rounds below touch LDS only (one exposed memory latency per workgroup instead
@@ -94,9 +102,13 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             const int r = it / IDX_W, c = it - r * IDX_W;
             const int gx = clampi(x0 + c - 3, 0, W - 1), gy = clampi(y0 + r - 3, 0, H - 1);
             const size_t at = (size_t)gy * W + gx;
-            const int sx = tex_index(((float)gx + 0.5f) + d3[at], W);
-            const int sy = tex_index(((float)gy + 0.5f) + d3[n + at], H);
-            ridx[u] = sy * R.pitch + sx;
+            if constexpr (ABL & 1) {
+                ridx[u] = (int)at;
+            } else {
+                const int sx = tex_index(((float)gx + 0.5f) + d3[at], W);
+                const int sy = tex_index(((float)gy + 0.5f) + d3[n + at], H);
+                ridx[u] = sy * R.pitch + sx;
+            }
         }
     }
 #pragma unroll
@@ -106,12 +118,19 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         const int gx = x0 + c - 2, gy = y0 + r - 2;
         const bool in = it < SL_H * (TX + 4) && gx >= 0 && gx < W && gy >= 0 && gy < H;
 #pragma unroll
-        for (int k = 0; k < 3; k++) lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
+        for (int k = 0; k < 3; k++) {
+            if constexpr (ABL & 1) lv[k][u] = in ? (float)(gx + k) : 0.0f;
+            else lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
+        }
     }
 #pragma unroll
-    for (int u = 0; u < NR; u++)
+    for (int u = 0; u < NR; u++) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
+        for (int k = 0; k < 3; k++) {
+            if constexpr (ABL & 1) rv[k][u] = (float)(ridx[u] & 255) + k;
+            else rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
+        }
+    }
     {
         const int gy = y0 + trow, gx0 = x0 + qx * 4;
 #pragma unroll
@@ -120,8 +139,13 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             const size_t at = in ? (size_t)gy * W + gx0 + i : 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                av[k][i] = in ? A3[k * n + at] : 1.0f;
-                dv[k][i] = in ? d3[k * n + at] : 0.0f;
+                if constexpr (ABL & 1) {
+                    av[k][i] = 1.0e4f + i;
+                    dv[k][i] = 0.5f;
+                } else {
+                    av[k][i] = in ? A3[k * n + at] : 1.0f;
+                    dv[k][i] = in ? d3[k * n + at] : 0.0f;
+                }
             }
         }
     }
@@ -156,6 +180,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         }
         __syncthreads();
         // ---- P2a: row pass of the five products (CompareMove + convolutionRowsKernel) -----
+        if constexpr (!(ABL & 2)) {
         {
             const int r = trow;  // 0..31 <-> tile row r-2
             const int cx = qx * 4;
@@ -186,8 +211,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             }
         }
         // ---- P2b: row pass of R'^2 (Square + convolutionRowsKernelT), cols -4..TX+3 -------
-        for (int it = tid; it < SBROW_H * (SB_W / 4); it += 256) {
-            const int r = it / (SB_W / 4), q = it - r * (SB_W / 4);
+        for (int it = tid; it < SBROW_H * SB_Q; it += 256) {
+            const int q = it / SBROW_H, r = it - q * SBROW_H;  // lanes walk down the rows
             const int cx = q * 4 - 4;
             float v[12];
             const float *pr = &sR[r * SR_W + cx - 4 + SR_OX];
@@ -200,10 +225,12 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             for (int i = 0; i < 4; i++) o[i] = tap5p(sq[i], sq[i + 1], sq[i + 2], sq[i + 3], sq[i + 4]);
             st4(&sBrow[r * SB_W + cx + SB_OX], o);
         }
+        }
         __syncthreads();
         // ---- P2.5: column pass of R'^2 -> B on tile+halo1 (convolutionColumnsKernelT) -----
-        for (int it = tid; it < SB_H * (SB_W / 4); it += 256) {
-            const int r = it / (SB_W / 4), q = it - r * (SB_W / 4);  // r: tile row + 1
+        if constexpr (!(ABL & 4)) {
+        for (int it = tid; it < SB_H * SB_Q; it += 256) {
+            const int q = it / SB_H, r = it - q * SB_H;  // r: tile row + 1; lanes walk down the rows
             float a[4], b[4], c[4], d[4], e[4], o[4];
             const float *pb = &sBrow[r * SB_W + q * 4];  // sBrow row index = tile row + 3; rows r .. r+4
             ld4(pb, a); ld4(pb + SB_W, b); ld4(pb + 2 * SB_W, c); ld4(pb + 3 * SB_W, d); ld4(pb + 4 * SB_W, e);
@@ -211,8 +238,12 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
             st4(&sB[r * SB_W + q * 4], o);
         }
+        }
         __syncthreads();
         // ---- P3: column pass of the products, correlation, channel accumulate ---------------
+        if constexpr ((ABL & 8)) {
+        Q[k][0] += sRow[tid] + sB[tid];
+        } else {
         if (trow < TY) {
             const int cx = qx * 4;
             const int gy = y0 + trow, gx0 = x0 + cx;
@@ -239,13 +270,16 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                         else if (s == 2) b = top ? bc[i + 4] : bu[i];
                         else if (s == 3) b = bot ? bc[i + 4] : bd[i];
                         else b = bc[i + 4];
-                        const float q = ncc2(N, av[k][i], b);
+                        float q;
+                        if constexpr (ABL & 16) q = N * av[k][i] * b;
+                        else q = ncc2(N, av[k][i], b);
                         if (k == 0) Q[s][i] = q;
                         else if (k == 1) Q[s][i] = q + Q[s][i];
                         else Q[s][i] = (Q[s][i] + q) / 3.0f;
                     }
                 }
             }
+        }
         }
     }
 
@@ -259,12 +293,18 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                 if (gx < W) {
                     const size_t at = (size_t)gy * W + gx;
                     float ddx, ddy, cx_, cy_;
+        if constexpr ((ABL & 32)) {
+                    ddx = Q[0][i] + Q[1][i] + Q[4][i]; ddy = Q[2][i] + Q[3][i]; cx_ = thr; cy_ = ddx;
+        } else {
                     poly(Q[4][i], Q[0][i], Q[1][i], thr, ddx, cx_);
                     poly(Q[4][i], Q[2][i], Q[3][i], thr, ddy, cy_);
+        }
                     float kap = cy_ * cx_;
                     const float ndx = dv[0][i] + ddx;
                     const float ndy = dv[1][i] + ddy;
+        if constexpr (!(ABL & 32)) {
                     if (blend) kap = blend_conf(dv[2][i], kap);
+        }
                     nd3[at] = ndx;
                     nd3[n + at] = ndy;
                     nd3[2 * n + at] = kap;
@@ -341,8 +381,12 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
                 ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
                 ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
                 ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
-                wl[0] = f0[at - 1]; wl[1] = f1[at - 1]; wl[2] = f2[at - 1];
-                er[0] = f0[at + 4]; er[1] = f1[at + 4]; er[2] = f2[at + 4];
+                {   // west / east neighbours of the quad: whole-quad reads (a lane-strided ds_read_b32
+                    // here is a 4-way bank conflict: 65 % of LDS cycles in the first version)
+                    float t[4];
+                    ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
+                    ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
+                }
                 const bool row_ok = gy > 0 && gy < H;
                 const bool south_in = gy + 1 <= H - 1;
 #pragma unroll
@@ -484,7 +528,7 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
 void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend)
 {
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
-    hipLaunchKernelGGL(k_cost_fused, grid, dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend);
+    hipLaunchKernelGGL(k_cost_fused<0>, grid, dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend);
 }
 
 template <int STX, int STY, int NT>
