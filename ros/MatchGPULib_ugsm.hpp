@@ -1,0 +1,124 @@
+// MatchGPULib_ugsm.hpp -- source-compatible C++ shim of the reference's MatchGPULib class
+// (/root/reference/src/gpu_matcher/MatchGPULib.h:6-47) over the C-ABI of include/ugsm.h.
+//
+// The node's call sites (UG_GPU_matcher.cpp:160-181,423,530-535,645) compile unchanged against
+// this header: same constructor, same method names, same return layouts (malloc'd float** /
+// float***, freed by the caller exactly as the node already does, :414-418,487-489,636-640,689-691).
+// The image argument is templated on "something with ->image.{rows,cols,step,data}", i.e.
+// cv_bridge::CvImagePtr in the node; the header itself needs neither OpenCV nor ROS.
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+#include "ugsm.h"
+
+class MatchGPULib {
+public:
+    bool foveatedmatching;
+    int foveatelevel;
+    int fovH;
+    int fovW;
+
+    // MatchGPULib.cpp:251-265: "-device=N" anywhere in argv, argv[2] = number of fovea levels (7)
+    MatchGPULib(int argc, char **argv) : foveatedmatching(false), foveatelevel(7), fovH(0), fovW(0), ctx_(nullptr)
+    {
+        ugsm_config cfg;
+        ugsm_default_config(&cfg);
+        for (int i = 1; i < argc; i++)
+            if (argv[i] && std::strncmp(argv[i], "-device=", 8) == 0) cfg.device = std::atoi(argv[i] + 8);
+        if (argc > 2) foveatelevel = std::atoi(argv[2]);
+        cfg.fovea_levels = foveatelevel;
+        const int st = ugsm_create(&cfg, &ctx_);
+        if (st != UGSM_OK) throw std::runtime_error(std::string("ugsm_create: ") + ugsm_status_string(st));
+    }
+    ~MatchGPULib() { ugsm_destroy(ctx_); }
+    MatchGPULib(const MatchGPULib &) = delete;
+    MatchGPULib &operator=(const MatchGPULib &) = delete;
+
+    int getFoveaWidth() { return fovW; }
+    int getFoveaHeight() { return fovH; }
+    int getFoveateLevel() { return foveatelevel; }
+    void setFoveaWidth(int rows) { fovW = rows; }
+    void setFoveaHeight(int cols) { fovH = cols; }
+    void setFoveated(int fov) { foveatedmatching = fov; }
+
+    // MatchGPULib.cpp:406-426
+    template <class ImgPtr>
+    int initStack(ImgPtr L, ImgPtr /*R*/)
+    {
+        return ugsm_fovea_dims(L->image.cols, L->image.rows, 14, foveatelevel, &fovW, &fovH) == UGSM_OK ? 0 : -1;
+    }
+
+    // MatchGPULib.cpp:303-403 (fov == 0).  Returns finDisp[3][rows*cols]; nullptr on failure
+    // (the reference exit()s instead).
+    template <class ImgPtr>
+    float **match(ImgPtr L, ImgPtr R, int fov)
+    {
+        foveatedmatching = fov;
+        if (fov == 1) return nullptr;  // hierarchicalDisparity: unreachable from the node, out of scope
+        const int W = L->image.cols, H = L->image.rows;
+        if (R->image.cols != W || R->image.rows != H) return nullptr;
+        float **fin = alloc_planes(3, (size_t)W * H);
+        const int st = ugsm_match_full(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, fin[0], fin[1], fin[2]);
+        if (st != UGSM_OK) return fail(fin, 3, st);
+        return fin;
+    }
+
+    // MatchGPULib.cpp:429-531.  Returns disparity[level][3][fovH*fovW] for level < foveatelevel.
+    template <class ImgPtr>
+    float ***matchStack(ImgPtr L, ImgPtr R) { return stack(L, R, nullptr, nullptr); }
+
+    // MatchGPULib.cpp:534-700.  leftFov/rightFov: caller-allocated [14][3][fovH*fovW] as in
+    // UG_GPU_matcher.cpp:169-179; levels < foveatelevel are filled.
+    template <class ImgPtr>
+    float ***matchStackPyramid(ImgPtr L, ImgPtr R, float ***leftFov, float ***rightFov) { return stack(L, R, leftFov, rightFov); }
+
+private:
+    ugsm_ctx *ctx_;
+
+    static float **alloc_planes(int n, size_t px)
+    {
+        float **p = (float **)std::malloc(n * sizeof(float *));
+        for (int i = 0; i < n; i++) p[i] = (float *)std::malloc(px * sizeof(float));
+        return p;
+    }
+    float **fail(float **p, int n, int st)
+    {
+        std::fprintf(stderr, "ugsm: %s: %s\n", ugsm_status_string(st), ugsm_last_error(ctx_));
+        for (int i = 0; i < n; i++) std::free(p[i]);
+        std::free(p);
+        return nullptr;
+    }
+    template <class ImgPtr>
+    float ***stack(ImgPtr L, ImgPtr R, float ***leftFov, float ***rightFov)
+    {
+        const int W = L->image.cols, H = L->image.rows, F = foveatelevel;
+        if (R->image.cols != W || R->image.rows != H) return nullptr;
+        if (ugsm_fovea_dims(W, H, 14, F, &fovW, &fovH) != UGSM_OK) return nullptr;
+        const size_t fn = (size_t)fovW * fovH, sn = fn * F;
+        float *sh = (float *)std::malloc(3 * sn * sizeof(float));
+        float *pl = leftFov ? (float *)std::malloc(3 * sn * sizeof(float)) : nullptr;
+        float *pr = rightFov ? (float *)std::malloc(3 * sn * sizeof(float)) : nullptr;
+        const int st = ugsm_match_foveated(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, 0, 0, sh, sh + sn,
+                                           sh + 2 * sn, pl, pr);
+        float ***disp = nullptr;
+        if (st == UGSM_OK) {
+            disp = (float ***)std::malloc(F * sizeof(float **));
+            for (int k = 0; k < F; k++) {
+                disp[k] = alloc_planes(3, fn);
+                for (int c = 0; c < 3; c++) std::memcpy(disp[k][c], sh + c * sn + k * fn, fn * sizeof(float));
+                for (int c = 0; c < 3 && pl; c++) std::memcpy(leftFov[k][c], pl + ((size_t)k * 3 + c) * fn, fn * sizeof(float));
+                for (int c = 0; c < 3 && pr; c++) std::memcpy(rightFov[k][c], pr + ((size_t)k * 3 + c) * fn, fn * sizeof(float));
+            }
+        } else {
+            std::fprintf(stderr, "ugsm: %s: %s\n", ugsm_status_string(st), ugsm_last_error(ctx_));
+        }
+        std::free(sh);
+        std::free(pl);
+        std::free(pr);
+        return disp;
+    }
+};

@@ -1,0 +1,164 @@
+// UG_GPU_matcher_ugsm.cpp -- the UG_matcher_gpu node on top of libugsm (catkin build only; not
+// compiled in the GPU image, which has no ROS).  Same node / topic / service / parameter names and
+// message layouts as /root/reference/src/gpu_matcher/UG_GPU_matcher.cpp (:48-61,:742); the body of
+// each callback is: convert to rgb8 -> one call into the MatchGPULib shim -> wrap the returned
+// planes in 32FC1 images.  Written from the reference's interface, not from its source text: one
+// persistent matcher object instead of one per callback, cv::Mat headers over the returned planes
+// instead of per-pixel at<float>() loops, the service path fills the whole fovea stack (U6).
+#include <cv_bridge/cv_bridge.h>
+#include <image_transport/image_transport.h>
+#include <image_transport/subscriber_filter.h>
+#include <message_filters/sync_policies/approximate_time.h>
+#include <message_filters/synchronizer.h>
+#include <ros/ros.h>
+#include <sensor_msgs/image_encodings.h>
+#include <stereo_msgs/DisparityImage.h>
+#include <ug_stereomatcher/GetDisparitiesGPU.h>
+#include <ug_stereomatcher/foveatedstack.h>
+
+#include <memory>
+
+#include "MatchGPULib_ugsm.hpp"
+
+namespace enc = sensor_msgs::image_encodings;
+using ug_stereomatcher::foveatedstack;
+
+class GPU_matcher {
+public:
+    GPU_matcher(int argc, char **argv)
+        : it_(nh_), imL_sub_(it_, "input_left_image", 1), imR_sub_(it_, "input_right_image", 1),
+          sync_(Policy(1), imL_sub_, imR_sub_), mgpu_(new MatchGPULib(argc, argv))
+    {
+        for (const char *t : {"output_stackH", "output_stackV", "output_stackC", "output_stackL_pyramid", "output_stackR_pyramid"})
+            stack_pub_[t] = nh_.advertise<foveatedstack>(t, 1);
+        for (const char *t : {"output_disparityH", "output_disparityV", "output_disparityC"})
+            disp_pub_[t] = nh_.advertise<stereo_msgs::DisparityImage>(t, 1);
+        srv_ = nh_.advertiseService("get_disparities_srv", &GPU_matcher::disparitySrv, this);
+        sync_.registerCallback(boost::bind(&GPU_matcher::mainRoutine, this, _1, _2));
+    }
+
+private:
+    typedef message_filters::sync_policies::ApproximateTime<sensor_msgs::Image, sensor_msgs::Image> Policy;
+    ros::NodeHandle nh_;
+    image_transport::ImageTransport it_;
+    image_transport::SubscriberFilter imL_sub_, imR_sub_;
+    message_filters::Synchronizer<Policy> sync_;
+    ros::ServiceServer srv_;
+    std::map<std::string, ros::Publisher> stack_pub_, disp_pub_;
+    std::unique_ptr<MatchGPULib> mgpu_;
+
+    int foveated()
+    {  // re-read on every call, default 0 with a warning (reference :96-102)
+        int f = 0;
+        if (!nh_.getParam("foveated", f)) ROS_WARN("foveated option has not been set. Matcher is on non-foveated mode!");
+        return f;
+    }
+    static sensor_msgs::Image plane_msg(float *p, int rows, int cols, const std_msgs::Header &h)
+    {
+        cv_bridge::CvImage out(h, enc::TYPE_32FC1, cv::Mat(rows, cols, CV_32FC1, p));
+        return *out.toImageMsg();
+    }
+    // (levels*fovH) x fovW, finest level first
+    foveatedstack stack_msg(float ***st, int plane, const std_msgs::Header &h, int imW, int imH, bool dims)
+    {
+        const int F = mgpu_->getFoveateLevel(), fw = mgpu_->getFoveaWidth(), fh = mgpu_->getFoveaHeight();
+        cv::Mat m(F * fh, fw, CV_32FC1);
+        for (int k = 0; k < F; k++) std::memcpy(m.ptr<float>(k * fh), st[k][plane], sizeof(float) * fw * fh);
+        foveatedstack s;
+        s.header = h;
+        s.image_stack = *cv_bridge::CvImage(h, enc::TYPE_32FC1, m).toImageMsg();
+        if (dims) { s.im_width = imW; s.im_height = imH; s.roi_width = fw; s.roi_height = fh; s.num_levels = F; }
+        return s;
+    }
+    static void free_stack(float ***st, int F)
+    {
+        for (int k = 0; k < F; k++) { for (int i = 0; i < 3; i++) free(st[k][i]); free(st[k]); }
+        free(st);
+    }
+
+    bool disparitySrv(ug_stereomatcher::GetDisparitiesGPU::Request &req, ug_stereomatcher::GetDisparitiesGPU::Response &rsp)
+    {
+        cv_bridge::CvImagePtr L, R;
+        try { L = cv_bridge::toCvCopy(req.imL, enc::RGB8); R = cv_bridge::toCvCopy(req.imR, enc::RGB8); }
+        catch (cv_bridge::Exception &) { ROS_ERROR("Could not convert from '%s' to 'rgb8'.", req.imL.encoding.c_str()); return false; }
+        const int fov = foveated();
+        mgpu_->setFoveated(fov);
+        if (fov == 1) {
+            float ***st = mgpu_->matchStack(L, R);
+            if (!st) return false;
+            rsp.fdispH = stack_msg(st, 0, L->header, 0, 0, false);
+            rsp.fdispV = stack_msg(st, 1, R->header, 0, 0, false);
+            rsp.fdispC = stack_msg(st, 2, L->header, 0, 0, false);
+            free_stack(st, mgpu_->getFoveateLevel());
+        } else {
+            float **fin = mgpu_->match(L, R, fov);
+            if (!fin) return false;
+            rsp.dispH.image = plane_msg(fin[0], L->image.rows, L->image.cols, L->header); rsp.dispH.header = L->header;
+            rsp.dispV.image = plane_msg(fin[1], L->image.rows, L->image.cols, R->header); rsp.dispV.header = R->header;
+            rsp.dispC.image = plane_msg(fin[2], L->image.rows, L->image.cols, L->header); rsp.dispC.header = L->header;
+            for (int i = 0; i < 3; i++) free(fin[i]);
+            free(fin);
+        }
+        return true;
+    }
+
+    void mainRoutine(const sensor_msgs::ImageConstPtr &imL, const sensor_msgs::ImageConstPtr &imR)
+    {
+        cv_bridge::CvImagePtr L, R;
+        try { L = cv_bridge::toCvCopy(imL, enc::RGB8); R = cv_bridge::toCvCopy(imR, enc::RGB8); }
+        catch (cv_bridge::Exception &) { ROS_ERROR("Could not convert from '%s' to 'rgb8'.", imL->encoding.c_str()); return; }
+        const int fov = foveated();
+        mgpu_->setFoveated(fov);
+        const ros::WallTime t0 = ros::WallTime::now();
+        if (fov == 1) {
+            mgpu_->initStack(L, R);
+            const int F = mgpu_->getFoveateLevel(), fw = mgpu_->getFoveaWidth(), fh = mgpu_->getFoveaHeight();
+            // caller-allocated [14][3][fovW*fovH] as the reference node does
+            float ***lf = (float ***)malloc(14 * sizeof(float **)), ***rf = (float ***)malloc(14 * sizeof(float **));
+            for (int k = 0; k < 14; k++) {
+                lf[k] = (float **)malloc(3 * sizeof(float *)); rf[k] = (float **)malloc(3 * sizeof(float *));
+                for (int c = 0; c < 3; c++) { lf[k][c] = (float *)malloc(sizeof(float) * fw * fh); rf[k][c] = (float *)malloc(sizeof(float) * fw * fh); }
+            }
+            float ***st = mgpu_->matchStackPyramid(L, R, lf, rf);
+            ROS_INFO("Foveated Disparity took %f Seconds", (ros::WallTime::now() - t0).toSec());
+            if (st) {
+                auto pyr = [&](float ***p, const std_msgs::Header &h) {  // (F*3*fovH) x fovW, rows [level][channel][row]
+                    cv::Mat m(F * 3 * fh, fw, CV_32FC1);
+                    for (int k = 0; k < F; k++) for (int c = 0; c < 3; c++) std::memcpy(m.ptr<float>((k * 3 + c) * fh), p[k][c], sizeof(float) * fw * fh);
+                    foveatedstack s; s.header = h; s.image_stack = *cv_bridge::CvImage(h, enc::TYPE_32FC1, m).toImageMsg();
+                    s.im_width = L->image.cols; s.im_height = L->image.rows; s.roi_width = fw; s.roi_height = fh; s.num_levels = F;
+                    return s;
+                };
+                stack_pub_["output_stackL_pyramid"].publish(pyr(lf, L->header));
+                stack_pub_["output_stackR_pyramid"].publish(pyr(rf, R->header));
+                stack_pub_["output_stackH"].publish(stack_msg(st, 0, L->header, L->image.cols, L->image.rows, true));
+                stack_pub_["output_stackV"].publish(stack_msg(st, 1, R->header, L->image.cols, L->image.rows, true));
+                stack_pub_["output_stackC"].publish(stack_msg(st, 2, L->header, L->image.cols, L->image.rows, true));
+                free_stack(st, F);
+            }
+            for (int k = 0; k < 14; k++) { for (int c = 0; c < 3; c++) { free(lf[k][c]); free(rf[k][c]); } free(lf[k]); free(rf[k]); }
+            free(lf); free(rf);
+        } else {
+            float **fin = mgpu_->match(L, R, fov);
+            ROS_INFO("Non Foveated Disparity took %f Seconds", (ros::WallTime::now() - t0).toSec());
+            if (!fin) return;
+            const char *topics[3] = {"output_disparityH", "output_disparityV", "output_disparityC"};
+            for (int i = 0; i < 3; i++) {
+                stereo_msgs::DisparityImage d;
+                d.header = (i == 1) ? R->header : L->header;
+                d.image = plane_msg(fin[i], L->image.rows, L->image.cols, d.header);
+                disp_pub_[topics[i]].publish(d);
+                free(fin[i]);
+            }
+            free(fin);
+        }
+    }
+};
+
+int main(int argc, char **argv)
+{
+    ros::init(argc, argv, "RH_GPU_matcher");
+    GPU_matcher matcher(argc, argv);
+    while (ros::ok()) ros::spin();
+    return 0;
+}

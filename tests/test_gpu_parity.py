@@ -376,3 +376,21 @@ def test_16mp_determinism_and_sanity(lib):
             c.free(p)
     finally:
         c.close()
+
+
+def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
+    """ros/MatchGPULib_ugsm.hpp (the class the ROS node includes) against the built library,
+    without OpenCV/ROS: ros/shim_selftest.cpp supplies a struct with cv::Mat's field names."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "shim_selftest")
+    libdir = os.path.join(ROOT, "ug_stereomatcher_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ros"),
+                           os.path.join(ROOT, "ros", "shim_selftest.cpp"), "-L" + libdir, "-lugsm", "-Wl,-rpath," + libdir,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fovea 160x120 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout

@@ -555,10 +555,108 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
     else launch_smooth_t<32, 16, 256>(st, s3, o3, W, H, passes, do_box);
 }
 
+// =========================================================================================
+// K-pyr: level i+1 / i+2 of the pyramid = zero-padded 5x5 separable blur of the parent sampled at
+// floor((x+.5f)*sf) (MatchGPULib.cpp:1071-1096).  The reference blurs the whole parent level and
+// then samples it; here the row pass is evaluated only in the sampled columns and the column pass
+// only in the sampled rows.  One workgroup = 64x16 outputs of one plane; the parent region it needs
+// (<= 133 x 37 for sf <= 2) is staged in LDS.
+// =========================================================================================
+constexpr int PTX = 64, PTY = 16, PRW = 2 * PTX + 8, PRH = 2 * PTY + 6;
+
+__global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3,
+                                                             int W2, int H2, float sf)
+{
+    __shared__ float sS[PRH * PRW];
+    __shared__ float sT[PRH * PTX];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * PTX, oy0 = blockIdx.y * PTY;
+    const float *src = src3 + (size_t)blockIdx.z * W * H;
+    // parent region covered by this tile of outputs (sampling sites are monotone in ix / iy)
+    const int ox1 = min(ox0 + PTX, W2) - 1, oy1 = min(oy0 + PTY, H2) - 1;
+    const int rx0 = tex_index(((float)ox0 + 0.5f) * sf, W) - 2, ry0 = tex_index(((float)oy0 + 0.5f) * sf, H) - 2;
+    const int rw = tex_index(((float)ox1 + 0.5f) * sf, W) + 2 - rx0 + 1, rh = tex_index(((float)oy1 + 0.5f) * sf, H) + 2 - ry0 + 1;
+    for (int it = tid; it < rh * PRW; it += 256) {
+        const int r = it / PRW, c = it - r * PRW;
+        if (c < rw) {
+            const int gx = rx0 + c, gy = ry0 + r;
+            sS[it] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.0f;  // zero padding (U2/U3)
+        }
+    }
+    __syncthreads();
+    // row pass at the sampled columns, every region row
+    const int lx = tid & (PTX - 1);
+    const int ix = ox0 + lx;
+    const int cx = tex_index(((float)ix + 0.5f) * sf, W) - rx0;  // region column of the sampling site
+    if (ix < W2) {
+        for (int r = tid / PTX; r < rh; r += 256 / PTX) {
+            const float *p = &sS[r * PRW + cx];
+            sT[r * PTX + lx] = tap5(p[-2], p[-1], p[0], p[1], p[2]);
+        }
+    }
+    __syncthreads();
+    // column pass at the sampled rows
+    if (ix < W2) {
+        for (int ly = tid / PTX; ly < PTY; ly += 256 / PTX) {
+            const int iy = oy0 + ly;
+            if (iy < H2) {
+                const int cy = tex_index(((float)iy + 0.5f) * sf, H) - ry0;
+                const float *p = &sT[cy * PTX + lx];
+                dst3[(size_t)blockIdx.z * W2 * H2 + (size_t)iy * W2 + ix] =
+                    tap5(p[-2 * PTX], p[-PTX], p[0], p[PTX], p[2 * PTX]);
+            }
+        }
+    }
+}
+
+// A = colconv_clamp(rowconv_clamp(L^2)) (Square + convolutionRows/ColumnsKernelT, MatchLib.cu:556-578,
+// 1461-1565), once per level: it does not depend on the iteration.  64x16 tile, region +2 clamped.
+__global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3)
+{
+    constexpr int RW = PTX + 4, RH = PTY + 4;
+    __shared__ float sS[RH * RW];
+    __shared__ float sT[RH * PTX];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * PTX, y0 = blockIdx.y * PTY;
+    const float *s = src.p + (size_t)blockIdx.z * src.plane;
+    for (int it = tid; it < RH * RW; it += 256) {
+        const int r = it / RW, c = it - r * RW;
+        const float v = s[(size_t)clampi(y0 + r - 2, 0, H - 1) * src.pitch + clampi(x0 + c - 2, 0, W - 1)];
+        sS[it] = v * v;
+    }
+    __syncthreads();
+    const int lx = tid & (PTX - 1);
+    for (int r = tid / PTX; r < RH; r += 256 / PTX) {
+        const float *p = &sS[r * RW + lx];
+        sT[r * PTX + lx] = tap5(p[0], p[1], p[2], p[3], p[4]);
+    }
+    __syncthreads();
+    const int gx = x0 + lx;
+    if (gx < W) {
+        for (int ly = tid / PTX; ly < PTY; ly += 256 / PTX) {
+            const int gy = y0 + ly;
+            if (gy < H) {
+                const float *p = &sT[ly * PTX + lx];
+                dst3[(size_t)blockIdx.z * W * H + (size_t)gy * W + gx] = tap5(p[0], p[PTX], p[2 * PTX], p[3 * PTX], p[4 * PTX]);
+            }
+        }
+    }
+}
+
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
 {
-    launch_blur_decimate_ref(st, src3, W, H, dst3, W2, H2, sf);
+    if (sf > 2.0f || sf < 1.0f) {  // region bound assumes 1 <= sf <= 2 (the reference uses sqrt2 and 2)
+        launch_blur_decimate_ref(st, src3, W, H, dst3, W2, H2, sf);
+        return;
+    }
+    dim3 grid((W2 + PTX - 1) / PTX, (H2 + PTY - 1) / PTY, 3);
+    hipLaunchKernelGGL(k_blur_decimate_tiled, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);
 }
-void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3) { launch_sqblur_clamp_ref(st, src, W, H, dst3); }
+
+void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3)
+{
+    dim3 grid((W + PTX - 1) / PTX, (H + PTY - 1) / PTY, 3);
+    hipLaunchKernelGGL(k_sqblur_tiled, grid, dim3(256), 0, st, src, W, H, dst3);
+}
 
 }  // namespace ugsm
