@@ -393,4 +393,4 @@ def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
                            "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "fovea 160x120 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout
+    assert "fovea 159x119 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout

@@ -4,6 +4,7 @@
 // Times k_cost_fused and k_smooth_fused on one level-sized random problem with HIP events.
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -17,7 +18,7 @@ int main(int argc, char **argv)
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (size_t i = 0; i < 3 * n; i++) { hL[i] = 1 + 254 * rnd(); hR[i] = 1 + 254 * rnd(); }
-    for (size_t i = 0; i < n; i++) { hd[i] = 8 * rnd() - 4; hd[n + i] = 2 * rnd() - 1; hd[2 * n + i] = 0.3f + 0.7f * rnd(); }
+    for (size_t i = 0; i < n; i++) { int x = i % W, y = i / W; hd[i] = 30.0f * sinf(x * 0.002f) * cosf(y * 0.003f) + 0.3f * (rnd() - 0.5f); hd[n + i] = 0.75f * sinf(y * 0.002f) + 0.3f * (rnd() - 0.5f); hd[2 * n + i] = 0.3f + 0.7f * rnd(); }
     float *L, *R, *A, *d, *o;
     CK(hipMalloc(&L, 12 * n)); CK(hipMalloc(&R, 12 * n)); CK(hipMalloc(&A, 12 * n)); CK(hipMalloc(&d, 12 * n)); CK(hipMalloc(&o, 12 * n));
     CK(hipMemcpy(L, hL.data(), 12 * n, hipMemcpyHostToDevice)); CK(hipMemcpy(R, hR.data(), 12 * n, hipMemcpyHostToDevice));
@@ -36,8 +37,9 @@ int main(int argc, char **argv)
     };
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
 #define COST(ABL) timeit("k_cost_fused<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_fused<ABL>, grid, dim3(256), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1); })
+#define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, grid, dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1); })
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
-        COST(0); COST(1); COST(2); COST(4); COST(8); COST(16); COST(32); COST(3); COST(63);
+        COST(0); COST(1); COST(64); COST(128); SPLIT(0);
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });
     timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 1); });

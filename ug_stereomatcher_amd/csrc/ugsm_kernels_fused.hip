@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
     __shared__ __attribute__((aligned(16))) float sRow[5 * ROW_H * ROW_W];
     __shared__ __attribute__((aligned(16))) float sBrow[SBROW_H * SB_W];
     __shared__ __attribute__((aligned(16))) float sB[SB_H * SB_W];
+    __shared__ __attribute__((aligned(16))) float sA[TY * ROW_W];  // A = G_clamp*(L^2) of the tile, current channel
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
     // of one per channel).  A thread stages the same halo items for all three channels.
     constexpr int NR = (IDX_H * IDX_W + 255) / 256;        // R' items per thread (tile+halo3)
     constexpr int NL = (SL_H * (TX + 4) + 255) / 256;      // L items per thread (tile+halo2)
-    float rv[3][NR], lv[3][NL], av[3][4], dv[3][4];
+    float rv[3][NR], lv[3][NL];
     int ridx[NR];
 #pragma unroll
     for (int u = 0; u < NR; u++) {  // warped source offsets (warpAbyB, MatchLib.cu:510-515)
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             const int r = it / IDX_W, c = it - r * IDX_W;
             const int gx = clampi(x0 + c - 3, 0, W - 1), gy = clampi(y0 + r - 3, 0, H - 1);
             const size_t at = (size_t)gy * W + gx;
-            if constexpr (ABL & 1) {
-                ridx[u] = (int)at;
+            if constexpr (ABL & (1 | 64)) {
+                ridx[u] = gy * R.pitch + gx;
             } else {
                 const int sx = tex_index(((float)gx + 0.5f) + d3[at], W);
                 const int sy = tex_index(((float)gy + 0.5f) + d3[n + at], H);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         const bool in = it < SL_H * (TX + 4) && gx >= 0 && gx < W && gy >= 0 && gy < H;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            if constexpr (ABL & 1) lv[k][u] = in ? (float)(gx + k) : 0.0f;
+            if constexpr (ABL & (1 | 128)) lv[k][u] = in ? (float)(gx + k) : 0.0f;
             else lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
         }
     }
@@ -131,22 +132,22 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             else rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
         }
     }
-    {
-        const int gy = y0 + trow, gx0 = x0 + qx * 4;
+    // A of the tile: read with lanes along the rows (coalesced 128-B segments) and handed to the
+    // row-walking compute threads through LDS.  Reading it -- or (dx,dy,conf), or writing the result --
+    // directly in the compute mapping costs one cache line per LANE: 32 lines per wave instruction,
+    // which made the texture-address unit the bottleneck (ablation: -106 us of 636 at 16 MP).
+    constexpr int NA = (TX * TY + 255) / 256;
+    float aq[3][NA];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool in = trow < TY && gy < H && gx0 + i < W;
-            const size_t at = in ? (size_t)gy * W + gx0 + i : 0;
+    for (int u = 0; u < NA; u++) {
+        const int it = tid + u * 256;
+        const int r = it / TX, c = it - r * TX;
+        const bool in = it < TX * TY && x0 + c < W && y0 + r < H;
+        const size_t at = in ? (size_t)(y0 + r) * W + x0 + c : 0;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if constexpr (ABL & 1) {
-                    av[k][i] = 1.0e4f + i;
-                    dv[k][i] = 0.5f;
-                } else {
-                    av[k][i] = in ? A3[k * n + at] : 1.0f;
-                    dv[k][i] = in ? d3[k * n + at] : 0.0f;
-                }
-            }
+        for (int k = 0; k < 3; k++) {
+            if constexpr (ABL & (1 | 128)) aq[k][u] = 1.0e4f + c;
+            else aq[k][u] = in ? A3[k * n + at] : 1.0f;
         }
     }
 
@@ -179,6 +180,12 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             }
         }
         __syncthreads();
+        // sA is rewritten only now: its readers (P3 of the previous channel) are all behind the barrier above
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int it = tid + u * 256;
+            if (it < TX * TY) sA[(it / TX) * ROW_W + (it % TX)] = aq[k][u];
+        }
         // ---- P2a: row pass of the five products (CompareMove + convolutionRowsKernel) -----
         if constexpr (!(ABL & 2)) {
         {
@@ -255,6 +262,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                 ld4(pb - SB_W + 4, bu);
                 ld4(pb + SB_W + 4, bd);
                 const bool top = (gy == 0), bot = (gy == H - 1);
+                float a4[4];
+                ld4(&sA[trow * ROW_W + cx], a4);
 #pragma unroll
                 for (int s = 0; s < 5; s++) {
                     float r0[4], r1[4], r2[4], r3[4], r4[4];
@@ -271,8 +280,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                         else if (s == 3) b = bot ? bc[i + 4] : bd[i];
                         else b = bc[i + 4];
                         float q;
-                        if constexpr (ABL & 16) q = N * av[k][i] * b;
-                        else q = ncc2(N, av[k][i], b);
+                        if constexpr (ABL & 16) q = N * a4[i] * b;
+                        else q = ncc2(N, a4[i], b);
                         if (k == 0) Q[s][i] = q;
                         else if (k == 1) Q[s][i] = q + Q[s][i];
                         else Q[s][i] = (Q[s][i] + q) / 3.0f;
@@ -283,33 +292,300 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         }
     }
 
-    // ---- epilogue: parabola x/y, correlation product, update, confidence blend --------------
+    // ---- epilogue: parabola x/y and correlation product in the compute mapping, then the update,
+    // confidence blend and all global I/O with lanes along the rows (coalesced), through LDS ------
+    __syncthreads();  // every P3 is done with sRow: planes 0..2 become the hand-over buffers
     if (trow < TY) {
-        const int gy = y0 + trow, gx0 = x0 + qx * 4;
-        if (gy < H) {
+        float ex[4], ey[4], ek[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int gx = gx0 + i;
-                if (gx < W) {
-                    const size_t at = (size_t)gy * W + gx;
-                    float ddx, ddy, cx_, cy_;
-        if constexpr ((ABL & 32)) {
-                    ddx = Q[0][i] + Q[1][i] + Q[4][i]; ddy = Q[2][i] + Q[3][i]; cx_ = thr; cy_ = ddx;
-        } else {
-                    poly(Q[4][i], Q[0][i], Q[1][i], thr, ddx, cx_);
-                    poly(Q[4][i], Q[2][i], Q[3][i], thr, ddy, cy_);
+        for (int i = 0; i < 4; i++) {
+            float cx_, cy_;
+            if constexpr (ABL & 32) {
+                ex[i] = Q[0][i] + Q[1][i] + Q[4][i]; ey[i] = Q[2][i] + Q[3][i]; cx_ = thr; cy_ = ex[i];
+            } else {
+                poly(Q[4][i], Q[0][i], Q[1][i], thr, ex[i], cx_);
+                poly(Q[4][i], Q[2][i], Q[3][i], thr, ey[i], cy_);
+            }
+            ek[i] = cy_ * cx_;
         }
-                    float kap = cy_ * cx_;
-                    const float ndx = dv[0][i] + ddx;
-                    const float ndy = dv[1][i] + ddy;
-        if constexpr (!(ABL & 32)) {
-                    if (blend) kap = blend_conf(dv[2][i], kap);
+        st4(&sRow[(0 * ROW_H + trow) * ROW_W + qx * 4], ex);
+        st4(&sRow[(1 * ROW_H + trow) * ROW_W + qx * 4], ey);
+        st4(&sRow[(2 * ROW_H + trow) * ROW_W + qx * 4], ek);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NA; u++) {
+        const int it = tid + u * 256;
+        const int r = it / TX, c = it - r * TX;
+        const int gx = x0 + c, gy = y0 + r;
+        if (it < TX * TY && gx < W && gy < H) {
+            const size_t at = (size_t)gy * W + gx;
+            const float ddx = sRow[(0 * ROW_H + r) * ROW_W + c], ddy = sRow[(1 * ROW_H + r) * ROW_W + c];
+            float kap = sRow[(2 * ROW_H + r) * ROW_W + c];
+            float odx = 0.5f, ody = 0.5f, ocf = 0.5f;
+            if constexpr (!(ABL & (1 | 128))) { odx = d3[at]; ody = d3[n + at]; ocf = d3[2 * n + at]; }
+            if constexpr (!(ABL & 32)) {
+                if (blend) kap = blend_conf(ocf, kap);
+            }
+            nd3[at] = odx + ddx;
+            nd3[n + at] = ody + ddy;
+            nd3[2 * n + at] = kap;
         }
-                    nd3[at] = ndx;
-                    nd3[n + at] = ndy;
-                    nd3[2 * n + at] = kap;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// k_cost_split: the same tile and LDS images as k_cost_fused, but TWO threads per quad (512-thread
+// workgroup).  The kernel is latency-bound, not issue-bound (profiles/: 3 waves/SIMD reach ~40 % of
+// the VALU issue rate, and going to 2 waves/SIMD costs 30 %), and the LDS footprint per tile -- not
+// registers -- caps the wave count; so the waves per LDS byte are doubled by splitting each quad's
+// work by correlation shift:  role 0 (threads 0..255)  = shifts (-1,0), (+1,0), (0,0)  + parabola x
+//                             role 1 (threads 256..511) = shifts (0,-1), (0,+1), the R'^2 passes + parabola y.
+// The roles are wave-uniform (no divergence).  They meet once per tile: role 0 hands Q(0,0) to role 1,
+// role 1 hands rho_y back (two 3.5 KB LDS exchanges in the dead sRow planes).
+template <int ABL>
+__global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+                                                    float *__restrict__ nd3, int W, int H, float thr, int blend)
+{
+    __shared__ __attribute__((aligned(16))) float sR[SR_H * SR_W];
+    __shared__ __attribute__((aligned(16))) float sL[SL_H * SL_W];
+    __shared__ __attribute__((aligned(16))) float sRow[5 * ROW_H * ROW_W];
+    __shared__ __attribute__((aligned(16))) float sBrow[SBROW_H * SB_W];
+    __shared__ __attribute__((aligned(16))) float sB[SB_H * SB_W];
+
+    const int tid = threadIdx.x;
+    const int role = tid >> 8, t = tid & 255;
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+    const size_t n = (size_t)W * H;
+    const int trow = t & 31, qx = t >> 5;  // 32 rows x 8 quad columns, lanes walk down the rows
+    const int cx = qx * 4;
+    const int gy = y0 + trow, gx0 = x0 + cx;
+    const bool live = trow < TY && gy < H && gx0 < W;
+
+    // ---- P0: all global reads of the tile up front (see k_cost_fused) ---------------------------
+    constexpr int NR = (IDX_H * IDX_W + 511) / 512;
+    constexpr int NL = (SL_H * (TX + 4) + 511) / 512;
+    float rv[3][NR], lv[3][NL], av[3][4], dq[4], cq[4];  // dq: dx (role 0) or dy (role 1); cq: conf (role 0)
+    int ridx[NR];
+#pragma unroll
+    for (int u = 0; u < NR; u++) {  // warped source offsets (warpAbyB, MatchLib.cu:510-515)
+        const int it = tid + u * 512;
+        ridx[u] = -1;
+        if (it < IDX_H * IDX_W) {
+            const int r = it / IDX_W, c = it - r * IDX_W;
+            const int gxh = clampi(x0 + c - 3, 0, W - 1), gyh = clampi(y0 + r - 3, 0, H - 1);
+            const size_t at = (size_t)gyh * W + gxh;
+            const int sx = tex_index(((float)gxh + 0.5f) + d3[at], W);
+            const int sy = tex_index(((float)gyh + 0.5f) + d3[n + at], H);
+            ridx[u] = sy * R.pitch + sx;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+        const int it = tid + u * 512;
+        const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
+        const int gxl = x0 + c - 2, gyl = y0 + r - 2;
+        const bool in = it < SL_H * (TX + 4) && gxl >= 0 && gxl < W && gyl >= 0 && gyl < H;
+#pragma unroll
+        for (int k = 0; k < 3; k++) lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gyl * L.pitch + gxl] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < NR; u++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool in = live && gx0 + i < W;
+        const size_t at = in ? (size_t)gy * W + gx0 + i : 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) av[k][i] = in ? A3[k * n + at] : 1.0f;
+        dq[i] = in ? d3[(size_t)role * n + at] : 0.0f;
+        cq[i] = (in && role == 0) ? d3[2 * n + at] : 0.0f;
+    }
+
+    float Q[3][4];  // role 0: shifts 0,1,4; role 1: shifts 2,3 (Q[2] unused)
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) Q[s][i] = 0.0f;
+
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        // ---- P1: registers -> LDS (sR edge-replicated, sL zero outside the image) -------------
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int it = tid + u * 512;
+            if (it < IDX_H * IDX_W) {
+                const int r = it / IDX_W, c = it - r * IDX_W;
+                sR[r * SR_W + (c - 3 + SR_OX)] = rv[k][u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int it = tid + u * 512;
+            if (it < SL_H * (TX + 4)) {
+                const int r = it / (TX + 4), c = it - r * (TX + 4);
+                sL[r * SL_W + (c - 2 + SL_OX)] = lv[k][u];
+            }
+        }
+        __syncthreads();
+        // ---- P2: row passes -----------------------------------------------------------------------
+        {
+            const int r = trow;  // 0..31 <-> tile row r-2
+            float l[12];
+            const float *pl = &sL[r * SL_W + cx - 4 + SL_OX];
+            ld4(pl, l); ld4(pl + 4, l + 4); ld4(pl + 8, l + 8);
+            const float *pr = &sR[(r + 1) * SR_W + cx - 4 + SR_OX];  // sR row index = tile row + 3
+            if (role == 0) {
+                float rc[12];
+                ld4(pr, rc); ld4(pr + 4, rc + 4); ld4(pr + 8, rc + 8);
+                // arrays hold tile columns cx-4 .. cx+7; products at columns cx-2 .. cx+5
+                float p0[8], p1[8], p4[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float lvj = l[j + 2];
+                    p0[j] = lvj * rc[j + 1];  // shift (-1, 0)
+                    p1[j] = lvj * rc[j + 3];  // shift (+1, 0)
+                    p4[j] = lvj * rc[j + 2];  // shift (0, 0)
+                }
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(p0[i], p0[i + 1], p0[i + 2], p0[i + 3], p0[i + 4]);
+                st4(&sRow[(0 * ROW_H + r) * ROW_W + cx], o);
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(p1[i], p1[i + 1], p1[i + 2], p1[i + 3], p1[i + 4]);
+                st4(&sRow[(1 * ROW_H + r) * ROW_W + cx], o);
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(p4[i], p4[i + 1], p4[i + 2], p4[i + 3], p4[i + 4]);
+                st4(&sRow[(4 * ROW_H + r) * ROW_W + cx], o);
+            } else {
+                float ru[12], rd[12];
+                ld4(pr - SR_W, ru); ld4(pr - SR_W + 4, ru + 4); ld4(pr - SR_W + 8, ru + 8);
+                ld4(pr + SR_W, rd); ld4(pr + SR_W + 4, rd + 4); ld4(pr + SR_W + 8, rd + 8);
+                float p2[8], p3[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float lvj = l[j + 2];
+                    p2[j] = lvj * ru[j + 2];  // shift (0, -1)
+                    p3[j] = lvj * rd[j + 2];  // shift (0, +1)
+                }
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(p2[i], p2[i + 1], p2[i + 2], p2[i + 3], p2[i + 4]);
+                st4(&sRow[(2 * ROW_H + r) * ROW_W + cx], o);
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(p3[i], p3[i + 1], p3[i + 2], p3[i + 3], p3[i + 4]);
+                st4(&sRow[(3 * ROW_H + r) * ROW_W + cx], o);
+                // row pass of R'^2 (Square + convolutionRowsKernelT), cols -4..TX+3
+                for (int it = t; it < SBROW_H * SB_Q; it += 256) {
+                    const int q = it / SBROW_H, rr = it - q * SBROW_H;
+                    const int cb = q * 4 - 4;
+                    float v[12];
+                    const float *pq = &sR[rr * SR_W + cb - 4 + SR_OX];
+                    ld4(pq, v); ld4(pq + 4, v + 4); ld4(pq + 8, v + 8);
+                    float sq[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) sq[j] = v[j + 2] * v[j + 2];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[i] = tap5p(sq[i], sq[i + 1], sq[i + 2], sq[i + 3], sq[i + 4]);
+                    st4(&sBrow[rr * SB_W + cb + SB_OX], o);
                 }
             }
+        }
+        __syncthreads();
+        // ---- P2.5: column pass of R'^2 -> B on tile+halo1 (role 1) ------------------------------
+        if (role == 1) {
+            for (int it = t; it < SB_H * SB_Q; it += 256) {
+                const int q = it / SB_H, r = it - q * SB_H;  // r: tile row + 1
+                float a[4], b[4], c[4], d[4], e[4], o[4];
+                const float *pb = &sBrow[r * SB_W + q * 4];
+                ld4(pb, a); ld4(pb + SB_W, b); ld4(pb + 2 * SB_W, c); ld4(pb + 3 * SB_W, d); ld4(pb + 4 * SB_W, e);
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
+                st4(&sB[r * SB_W + q * 4], o);
+            }
+        }
+        __syncthreads();
+        // ---- P3: column pass of the products, correlation, channel accumulate ---------------
+        if (live) {
+            const float *pb = &sB[(trow + 1) * SB_W + cx - 4 + SB_OX];
+            auto colpass = [&](int s, float *N) {
+                float r0[4], r1[4], r2[4], r3[4], r4[4];
+                const float *ps = &sRow[(s * ROW_H + trow) * ROW_W + cx];  // rows trow .. trow+4 <-> tile rows trow-2..trow+2
+                ld4(ps, r0); ld4(ps + ROW_W, r1); ld4(ps + 2 * ROW_W, r2); ld4(ps + 3 * ROW_W, r3); ld4(ps + 4 * ROW_W, r4);
+#pragma unroll
+                for (int i = 0; i < 4; i++) N[i] = tap5p(r0[i], r1[i], r2[i], r3[i], r4[i]);
+            };
+            auto accum = [&](int slot, const float *N, const float *b) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float q = ncc2(N[i], av[k][i], b[i]);
+                    if (k == 0) Q[slot][i] = q;
+                    else if (k == 1) Q[slot][i] = q + Q[slot][i];
+                    else Q[slot][i] = (Q[slot][i] + q) / 3.0f;
+                }
+            };
+            float N[4], b[4];
+            if (role == 0) {
+                float bc[12];
+                ld4(pb, bc); ld4(pb + 4, bc + 4); ld4(pb + 8, bc + 8);  // columns cx-4 .. cx+7, pixel i at [i+4]
+                colpass(0, N);
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[i] = (gx0 + i == 0) ? bc[i + 4] : bc[i + 3];
+                accum(0, N, b);
+                colpass(1, N);
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[i] = (gx0 + i >= W - 1) ? bc[i + 4] : bc[i + 5];
+                accum(1, N, b);
+                colpass(4, N);
+                accum(2, N, bc + 4);
+            } else {
+                float bm[4], bu[4], bd[4];
+                ld4(pb + 4, bm); ld4(pb - SB_W + 4, bu); ld4(pb + SB_W + 4, bd);
+                const bool top = (gy == 0), bot = (gy == H - 1);
+                colpass(2, N);
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[i] = top ? bm[i] : bu[i];
+                accum(0, N, b);
+                colpass(3, N);
+#pragma unroll
+                for (int i = 0; i < 4; i++) b[i] = bot ? bm[i] : bd[i];
+                accum(1, N, b);
+            }
+        }
+    }
+
+    // ---- epilogue: parabola x (role 0) / y (role 1), correlation product, update, blend --------
+    __syncthreads();  // every P3 is done with sRow: planes 0 and 1 become the exchange buffers
+    float *xq = &sRow[(0 * ROW_H + trow) * ROW_W + cx], *yq = &sRow[(1 * ROW_H + trow) * ROW_W + cx];
+    if (role == 0 && live) st4(xq, Q[2]);  // Q(0,0) for the y parabola
+    __syncthreads();
+    float rho[4];
+    if (live) {
+        float c4[4];
+        if (role == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) c4[i] = Q[2][i];
+        } else {
+            ld4(xq, c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float dd;
+            poly(c4[i], Q[0][i], Q[1][i], thr, dd, rho[i]);  // x: (l,r) = shifts (-1,0),(+1,0); y: (0,-1),(0,+1)
+            if (gx0 + i < W) nd3[(size_t)role * n + (size_t)gy * W + gx0 + i] = dq[i] + dd;
+        }
+        if (role == 1) st4(yq, rho);
+    }
+    __syncthreads();
+    if (role == 0 && live) {
+        float cy[4];
+        ld4(yq, cy);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float kap = cy[i] * rho[i];
+            if (blend) kap = blend_conf(cq[i], kap);
+            if (gx0 + i < W) nd3[2 * n + (size_t)gy * W + gx0 + i] = kap;
         }
     }
 }
