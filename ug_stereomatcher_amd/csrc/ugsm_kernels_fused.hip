@@ -39,7 +39,7 @@ namespace ugsm {
 // 4-bank slots (odd multiplier mod 16 is a bijection) -- conflict-free; with lanes walking along a
 // row the same reads cost 2-3x (rows of 40/48 floats alias in the 64 banks).  Measured:
 // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 47 % -> see profiles/.
-constexpr int TX = 32, TY = 28, QX = TX / 4;
+constexpr int TX = 32, TY = 28;
 constexpr int SR_W = TX + 20, SR_H = TY + 6, SR_OX = 8;
 constexpr int SL_W = TX + 12, SL_H = TY + 4, SL_OX = 4;
 constexpr int ROW_W = TX + 4, ROW_H = TY + 4;
@@ -112,32 +112,41 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             }
         }
     }
+    // Issue order is CHANNEL-major: vmcnt retires in order, so the wait in front of channel 0's P1
+    // covers only channel 0's loads and the other two channels land while channel 0 is computed.
+    constexpr int NA = (TX * TY + 255) / 256;
+    float aq[3][NA], od[3][NA];
 #pragma unroll
-    for (int u = 0; u < NL; u++) {
-        const int it = tid + u * 256;
-        const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
-        const int gx = x0 + c - 2, gy = y0 + r - 2;
-        const bool in = it < SL_H * (TX + 4) && gx >= 0 && gx < W && gy >= 0 && gy < H;
+    for (int k = 0; k < 3; k++) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if constexpr (ABL & (1 | 128)) lv[k][u] = in ? (float)(gx + k) : 0.0f;
-            else lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NR; u++) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int u = 0; u < NR; u++) {
             if constexpr (ABL & 1) rv[k][u] = (float)(ridx[u] & 255) + k;
             else rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
         }
+#pragma unroll
+        for (int u = 0; u < NL; u++) {
+            const int it = tid + u * 256;
+            const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
+            const int gx = x0 + c - 2, gy = y0 + r - 2;
+            const bool in = it < SL_H * (TX + 4) && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            if constexpr (ABL & (1 | 128)) lv[k][u] = in ? (float)(gx + k) : 0.0f;
+            else lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gy * L.pitch + gx] : 0.0f;
+        }
+        // A of the tile: read with lanes along the rows (coalesced 128-B segments) and handed to the
+        // row-walking compute threads through LDS.  Reading it -- or (dx,dy,conf), or writing the result --
+        // directly in the compute mapping costs one cache line per LANE: 32 lines per wave instruction,
+        // which made the texture-address unit the bottleneck (ablation: -106 us of 636 at 16 MP).
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int it = tid + u * 256;
+            const int r = it / TX, c = it - r * TX;
+            const bool in = it < TX * TY && x0 + c < W && y0 + r < H;
+            const size_t at = in ? (size_t)(y0 + r) * W + x0 + c : 0;
+            if constexpr (ABL & (1 | 128)) aq[k][u] = 1.0e4f + c;
+            else aq[k][u] = in ? A3[k * n + at] : 1.0f;
+        }
     }
-    // A of the tile: read with lanes along the rows (coalesced 128-B segments) and handed to the
-    // row-walking compute threads through LDS.  Reading it -- or (dx,dy,conf), or writing the result --
-    // directly in the compute mapping costs one cache line per LANE: 32 lines per wave instruction,
-    // which made the texture-address unit the bottleneck (ablation: -106 us of 636 at 16 MP).
-    constexpr int NA = (TX * TY + 255) / 256;
-    float aq[3][NA];
+    // the tile's own (dx, dy, conf) for the update/blend at the very end: issued now, used last
 #pragma unroll
     for (int u = 0; u < NA; u++) {
         const int it = tid + u * 256;
@@ -146,8 +155,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
         const size_t at = in ? (size_t)(y0 + r) * W + x0 + c : 0;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            if constexpr (ABL & (1 | 128)) aq[k][u] = 1.0e4f + c;
-            else aq[k][u] = in ? A3[k * n + at] : 1.0f;
+            if constexpr (ABL & (1 | 128)) od[k][u] = 0.5f;
+            else od[k][u] = in ? d3[k * n + at] : 0.0f;
         }
     }
 
@@ -322,13 +331,11 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             const size_t at = (size_t)gy * W + gx;
             const float ddx = sRow[(0 * ROW_H + r) * ROW_W + c], ddy = sRow[(1 * ROW_H + r) * ROW_W + c];
             float kap = sRow[(2 * ROW_H + r) * ROW_W + c];
-            float odx = 0.5f, ody = 0.5f, ocf = 0.5f;
-            if constexpr (!(ABL & (1 | 128))) { odx = d3[at]; ody = d3[n + at]; ocf = d3[2 * n + at]; }
             if constexpr (!(ABL & 32)) {
-                if (blend) kap = blend_conf(ocf, kap);
+                if (blend) kap = blend_conf(od[2][u], kap);
             }
-            nd3[at] = odx + ddx;
-            nd3[n + at] = ody + ddy;
+            nd3[at] = od[0][u] + ddx;
+            nd3[n + at] = od[1][u] + ddy;
             nd3[2 * n + at] = kap;
         }
     }
