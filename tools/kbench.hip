@@ -36,25 +36,22 @@ int main(int argc, char **argv)
         printf("%-28s %4dx%-4d  %8.1f us/launch  %7.1f Gpx/s\n", name, W, H, 1e3 * ms / reps, n / (ms / reps) / 1e6);
     };
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
-#define COST(ABL) timeit("k_cost_fused<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_fused<ABL>, grid, dim3(256), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1); })
+    const int ctx = (W + TX - 1) / TX, cnt = ctx * ((H + TY - 1) / TY);
+#define COST(ABL) timeit("k_cost_fused<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_fused<ABL>, dim3(cnt), dim3(256), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
 #define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, grid, dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1); })
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
-        COST(0);
+        COST(0); COST(1);
     }
     {
         auto run = [&](auto kern, int stx, int sty, int nt, const char *nm) {
             const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 20) * sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            dim3 g((W + stx - 1) / stx, (H + sty - 1) / sty);
-            timeit(nm, [&]() { hipLaunchKernelGGL(kern, g, dim3(nt), bytes, st, d, o, W, H, 5, 1); });
+            const int stxn = (W + stx - 1) / stx, stn = stxn * ((H + sty - 1) / sty);
+            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, 5, 1, stxn, stn); });
         };
         for (int round = 0; round < 2; round++) {
             run(k_smooth_fused<128, 64, 1024>, 128, 64, 1024, "smooth<128,64,1024> p5+box");
             run(k_smooth_fused<64, 64, 512>, 64, 64, 512, "smooth<64,64,512> p5+box");
-            run(k_smooth_fused<64, 64, 1024>, 64, 64, 1024, "smooth<64,64,1024> p5+box");
-            run(k_smooth_fused<64, 32, 256>, 64, 32, 256, "smooth<64,32,256> p5+box");
-            run(k_smooth_fused<64, 32, 512>, 64, 32, 512, "smooth<64,32,512> p5+box");
-            run(k_smooth_fused<128, 32, 512>, 128, 32, 512, "smooth<128,32,512> p5+box");
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });
