@@ -145,6 +145,12 @@ int ugsm_stage_seed(ugsm_ctx *ctx, const float *d_src3, int W, int H, float *d_d
 /* S smoothing passes (+ box if do_box), MatchGPULib.cpp:2257-2412, in place */
 int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int do_box);
 
+/* The fused kernels' exact arithmetic shortcuts (f32 first quotient of PolyDisparity, x/3 by two
+ * FMAs) evaluated on caller-supplied operands: delta/corr = PolyDisparity(c,l,r,thr)
+ * (MatchLib.cu:805-836), third = c/3.0f for c >= 0.  Lets tests force the rare fallback branches. */
+int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r,
+                          const float *d_thr, float *d_delta, float *d_corr, float *d_third, int n);
+
 /* ---- instrumentation ------------------------------------------------------------ */
 
 typedef struct ugsm_kernel_stat {

@@ -394,3 +394,59 @@ def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fovea 159x119 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout
+
+
+def test_exact_shortcuts_of_the_fused_kernels(lib, orc):
+    """The fused kernels replace three literal forms by cheaper ones that are provably the same number:
+    x/3.0f -> two FMAs (exhaustively verified on the host for every non-negative float), the dead '<0'
+    clamp arm, and PolyDisparity's first quotient in binary32 with an f64 fallback for operands near
+    underflow.  Real images never reach the fallback, so force it here (and the special values)."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 1 << 18
+    c = rng.random(n, dtype=np.float32)
+    l = rng.random(n, dtype=np.float32)
+    r = rng.random(n, dtype=np.float32)
+    thr = rng.choice(np.array([1.0, 0.55, 0.1, 0.325], np.float32), n)
+    # crafted tail: tiny / subnormal differences, exact ties, zeros, NaN, values that overshoot 1
+    tiny = np.float32(2.0) ** np.arange(-149, -90, dtype=np.float32)
+    k = len(tiny)
+    c[:k] = 0.5; l[:k] = 0.25; r[:k] = 0.25 + tiny                 # |b1| below 2^-100 -> f64 fallback
+    c[k:2 * k] = tiny; l[k:2 * k] = 0; r[k:2 * k] = tiny / 2       # |c1| tiny
+    c[2 * k:2 * k + 6] = [np.nan, 0.0, 1.0, 0.999, 0.0, 1.0]
+    l[2 * k:2 * k + 6] = [0.5, 0.0, 1.0, 0.2, np.nan, 0.9]
+    r[2 * k:2 * k + 6] = [0.7, 0.0, 1.0, 0.95, 0.3, 0.9]
+    exp_d = np.empty(n, np.float32)
+    exp_k = np.empty(n, np.float32)
+    for i in range(n if n <= 4096 else 4096):
+        exp_d[i], exp_k[i] = orc.poly(c[i], l[i], r[i], thr[i])
+    # vectorised literal PolyDisparity for the bulk (same float/double steps as the oracle's C code)
+    with np.errstate(all="ignore"):
+        b1 = ((r - l) / np.float32(2)).astype(np.float32)
+        c1 = (r - (c + b1)).astype(np.float32)
+        dh = ((-b1).astype(np.float64) * 0.5 / c1.astype(np.float64)).astype(np.float32)
+        dh = np.minimum(thr.astype(np.float64), np.maximum(dh.astype(np.float64), -thr.astype(np.float64))).astype(np.float32)
+        cstar = ((c1 * dh + b1).astype(np.float32) * dh).astype(np.float32) + c
+        d = (cstar - c).astype(np.float32)
+        resc = (dh.astype(np.float64) * ((1.0 - c.astype(np.float64)) / d.astype(np.float64))).astype(np.float32)
+        over = cstar.astype(np.float64) > 1.0
+        dd = np.where(over & (d.astype(np.float64) > 1e-10), resc, dh)
+        kk = np.where(over, np.float32(1.0), (0.3 * cstar.astype(np.float64) + 0.7).astype(np.float32))
+        neg = c1 < 0
+        ref_d = np.where(neg, dd, np.float32(0)).astype(np.float32)
+        ref_k = np.where(neg, kk, np.float32(0.4)).astype(np.float32)
+    assert_bit_equal(ref_d[:4096], exp_d[:4096], "numpy restatement vs oracle (delta)")
+    assert_bit_equal(ref_k[:4096], exp_k[:4096], "numpy restatement vs oracle (corr)")
+    ctx = lib.Context(levels=3)
+    try:
+        ptrs = [ctx.to_device(a) for a in (c, l, r, thr)]
+        outs = [ctx.alloc(4 * n) for _ in range(3)]
+        ctx.check(ctx.lib.ugsm_stage_poly_probe(ctx.handle, *ptrs, *outs, n))
+        got_d, got_k, got_t = (ctx.to_host(p, (n,)) for p in outs)
+        for p in ptrs + outs:
+            ctx.free(p)
+    finally:
+        ctx.close()
+    assert_bit_equal(got_d, ref_d, "poly_fast delta")
+    assert_bit_equal(got_k, ref_k, "poly_fast corr")
+    pos = ~np.isnan(c)
+    assert_bit_equal(got_t[pos], (c[pos] / np.float32(3.0)).astype(np.float32), "x/3 by two FMAs")

@@ -84,6 +84,56 @@ __device__ __forceinline__ float tap5p(float a, float b, float c, float d, float
     return sum;
 }
 
+// ---- exact shortcuts used by the fused kernels only (the one-stage-per-kernel path and the CPU
+// oracle keep the literal forms; the parity tests compare the two) ------------------------------
+//
+// x / 3.0f for x >= 0 (finite or NaN): q = RN(x*c), r = x - 3q exactly (fma), q' = RN(q + r*c) with
+// c = RN(1/3).  Checked exhaustively against the IEEE quotient for all 2^31-2^23 non-negative
+// finite floats, subnormals included; 3 instructions instead of 11.
+__device__ __forceinline__ float div3_nonneg(float x)
+{
+    const float c = 0x1.555556p-2f;
+    const float q = x * c;
+    const float r = __builtin_fmaf(-3.0f, q, x);
+    return __builtin_fmaf(r, c, q);
+}
+// MoveCorrelation (MatchLib.cu:681-687): N*N >= +0 and A*B >= +0 (or NaN), so the quotient is never
+// negative and the "< 0" arm of the clamp is dead; NaN (0/0) still passes through untouched.
+__device__ __forceinline__ float ncc2_nn(float n, float a, float b)
+{
+    float v = (n * n) / (a * b);
+    if (v > 1.0f) v = 1.0f;
+    return v;
+}
+// PolyDisparity (MatchLib.cu:805-836) with the first quotient in binary32 when that is provably the
+// same number: (-b1*0.5) is exact in f32 unless it underflows, and rounding a binary64 quotient of two
+// binary32 numbers to binary32 equals the correctly rounded binary32 quotient (53 >= 2*24+2, double
+// rounding is innocuous for division).  Operands outside [2^-100, ...) take the literal f64 route.
+__device__ __forceinline__ void poly_fast(float c, float l, float r, float thr, float &delta, float &corr)
+{
+    float b1 = (r - l) / 2.0f;
+    float c1 = r - (c + b1);
+    if (c1 < 0.0f) {
+        float dh;
+        if ((fabsf(b1) >= 0x1p-100f || b1 == 0.0f) && c1 <= -0x1p-100f) dh = (-b1 * 0.5f) / c1;
+        else dh = (float)(((double)(-b1) * 0.5) / (double)c1);
+        dh = fminf(thr, fmaxf(dh, -thr));
+        float cstar = (c1 * dh + b1) * dh + c;
+        if (cstar > 1.0f) {
+            float d = cstar - c;
+            if ((double)d > 1e-10) dh = (float)((double)dh * ((1.0 - (double)c) / (double)d));
+            delta = dh;
+            corr = 1.0f;
+        } else {
+            delta = dh;
+            corr = (float)(0.3 * (double)cstar + 0.7);
+        }
+    } else {
+        delta = 0.0f;
+        corr = 0.4f;
+    }
+}
+
 // ABL: development-only ablation mask (tools/kbench.hip times variants with phases removed to see
 // where the time goes); the product instantiates ABL = 0 only.
 template <int ABL>
@@ -306,10 +356,10 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
                         else b = bc[i + 4];
                         float q;
                         if constexpr (ABL & 16) q = N * a4[i] * b;
-                        else q = ncc2(N, a4[i], b);
+                        else q = ncc2_nn(N, a4[i], b);
                         if (k == 0) Q[s][i] = q;
                         else if (k == 1) Q[s][i] = q + Q[s][i];
-                        else Q[s][i] = (Q[s][i] + q) / 3.0f;
+                        else Q[s][i] = div3_nonneg(Q[s][i] + q);
                     }
                 }
             }
@@ -328,8 +378,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
             if constexpr (ABL & 32) {
                 ex[i] = Q[0][i] + Q[1][i] + Q[4][i]; ey[i] = Q[2][i] + Q[3][i]; cx_ = thr; cy_ = ex[i];
             } else {
-                poly(Q[4][i], Q[0][i], Q[1][i], thr, ex[i], cx_);
-                poly(Q[4][i], Q[2][i], Q[3][i], thr, ey[i], cy_);
+                poly_fast(Q[4][i], Q[0][i], Q[1][i], thr, ex[i], cx_);
+                poly_fast(Q[4][i], Q[2][i], Q[3][i], thr, ey[i], cy_);
             }
             ek[i] = cy_ * cx_;
         }
@@ -823,6 +873,22 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
             }
         }
     }
+}
+
+// test hook (tests only): poly_fast on arbitrary operands, so that its rarely taken f64 fallback and the
+// special values are exercised against the oracle's literal PolyDisparity
+__global__ void k_poly_probe(const float *__restrict__ c, const float *__restrict__ l, const float *__restrict__ r, const float *__restrict__ thr,
+                             float *__restrict__ delta, float *__restrict__ corr, float *__restrict__ third, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        poly_fast(c[i], l[i], r[i], thr[i], delta[i], corr[i]);
+        third[i] = (c[i] >= 0.0f || c[i] != c[i]) ? div3_nonneg(c[i]) : 0.0f;
+    }
+}
+void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n)
+{
+    hipLaunchKernelGGL(k_poly_probe, dim3((n + 255) / 256), dim3(256), 0, st, c, l, r, thr, delta, corr, third, n);
 }
 
 // ---- launchers ------------------------------------------------------------------------------

@@ -38,5 +38,7 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
+// test hook: the fused kernels' exact shortcuts (parabola fast path, x/3) on arbitrary operands
+void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);
 
 }  // namespace ugsm

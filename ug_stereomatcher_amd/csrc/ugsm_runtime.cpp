@@ -783,6 +783,18 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
     return ugsm_wait(ctx, 0);
 }
 
+int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r, const float *d_thr, float *d_delta,
+                          float *d_corr, float *d_third, int n)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_c || !d_l || !d_r || !d_thr || !d_delta || !d_corr || !d_third || n < 1) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    launch_poly_probe(s->st, d_c, d_l, d_r, d_thr, d_delta, d_corr, d_third, n);
+    HIPCHK(ctx, hipGetLastError());
+    return ugsm_wait(ctx, 0);
+}
+
 // ---- instrumentation / memory helpers ---------------------------------------------------
 
 int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap)
