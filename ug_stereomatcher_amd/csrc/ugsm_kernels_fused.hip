@@ -829,13 +829,15 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
             }
         }
         __syncthreads();
-        // columns (Ta) -> global
+        // columns (Ta) into registers, then back to LDS and out with lanes along the rows: a quad-per-lane
+        // store touches one 16-B piece per lane (4 instructions per 1-KiB row segment); the copy-out below
+        // writes whole contiguous segments
         constexpr int CMAXR = (STY + BRG - 1) / BRG;
+        float cv[CMAXR][3][4];
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
             const int r = HY + brg + u * BRG;
-            const int gy = y0 + r;
-            if (brg < BRG && r < HY + STY && gy < H) {
+            if (brg < BRG && r < HY + STY) {
                 const int at = r * LW + bc0;
 #pragma unroll
                 for (int f = 0; f < 3; f++) {
@@ -843,33 +845,41 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
                     float a[4], b[4], c[4], d[4], e[4];
                     ld4(src - 2 * LW, a); ld4(src - LW, b); ld4(src, c); ld4(src + LW, d); ld4(src + 2 * LW, e);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int gx = x0 + bc0 + i;
-                        if (gx < W) o3[f * n + (size_t)gy * W + gx] = box5(a[i], b[i], c[i], d[i], e[i]);
-                    }
+                    for (int i = 0; i < 4; i++) cv[u][f][i] = box5(a[i], b[i], c[i], d[i], e[i]);
                 }
             }
         }
-    } else {
-        constexpr int BQ = STX / 4, BRG = NT / BQ, CMAXR = (STY + BRG - 1) / BRG;
-        const int bq = tid % BQ, brg = tid / BQ;
-        const int bc0 = HX + bq * 4;
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
             const int r = HY + brg + u * BRG;
-            const int gy = y0 + r;
-            if (brg < BRG && r < HY + STY && gy < H) {
+            if (brg < BRG && r < HY + STY) {
                 const int at = r * LW + bc0;
-#pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    float v[4];
-                    ld4((f == 0 ? f0 : (f == 1 ? f1 : f2)) + at, v);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int gx = x0 + bc0 + i;
-                        if (gx < W) o3[f * n + (size_t)gy * W + gx] = v[i];
-                    }
-                }
+                st4(f0 + at, cv[u][0]); st4(f1 + at, cv[u][1]); st4(f2 + at, cv[u][2]);
+            }
+        }
+        __syncthreads();
+        for (int it = tid; it < STX * STY; it += NT) {
+            const int r = it / STX, c = it - r * STX;
+            const int gx = tx0 + c, gy = ty0 + r;
+            if (gx < W && gy < H) {
+                const size_t at = (size_t)gy * W + gx;
+                const int la = (HY + r) * LW + HX + c;
+                o3[at] = f0[la];
+                o3[n + at] = f1[la];
+                o3[2 * n + at] = f2[la];
+            }
+        }
+    } else {
+        for (int it = tid; it < STX * STY; it += NT) {
+            const int r = it / STX, c = it - r * STX;
+            const int gx = tx0 + c, gy = ty0 + r;
+            if (gx < W && gy < H) {
+                const size_t at = (size_t)gy * W + gx;
+                const int la = (HY + r) * LW + HX + c;
+                o3[at] = f0[la];
+                o3[n + at] = f1[la];
+                o3[2 * n + at] = f2[la];
             }
         }
     }
@@ -915,10 +925,11 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
-    // big levels: 128x64 tiles (halo redundancy ~1.3x, one 16-wave workgroup per CU);
+    // big levels: 64x64 tiles, 512 threads, 79 KB LDS -> two workgroups per CU, so one's load/store phase
+    // overlaps the other's passes (measured 378 us vs 406 us for 128x64x1024 at 16 MP, 77 vs 94 at 2 MP);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (px >= ((size_t)1 << 20)) launch_smooth_t<128, 64, 1024>(st, s3, o3, W, H, passes, do_box);
+    if (px >= ((size_t)1 << 19)) launch_smooth_t<64, 64, 512>(st, s3, o3, W, H, passes, do_box);
     else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, 256>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, 256>(st, s3, o3, W, H, passes, do_box);
 }
