@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU (HIP streams)")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="1080p", choices=["1080p", "full"])
+    ap.add_argument("--cpu-sample", default="full", choices=["1080p", "full"], help="full = one pair of the workload itself (about 3-6 s at 16 MP)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events on slot 0")
     args = ap.parse_args()

@@ -38,9 +38,10 @@ int main(int argc, char **argv)
     dim3 grid((W + TX - 1) / TX, (H + TY - 1) / TY);
     const int ctx = (W + TX - 1) / TX, cnt = ctx * ((H + TY - 1) / TY);
 #define COST(ABL) timeit("k_cost_fused<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_fused<ABL>, dim3(cnt), dim3(256), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
-#define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, grid, dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1); })
+#define SPLIT_PLACEHOLDER
+#define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
-        COST(0); COST(1);
+        COST(0); SPLIT(0);
     }
     {
         auto run = [&](auto kern, int stx, int sty, int nt, const char *nm) {

@@ -27,7 +27,7 @@ constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
 enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
-    {"k_cost_fused", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc"},
+    {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc"},
     {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc"}};
 
 struct EvRec {
