@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns one gpurun_out/prof_rNN directory (bench JSONs, rocprofv3 kernel trace, PMC passes) into the
+committed summaries under profiles/.   usage: make_summaries.py gpurun_out/prof_r01d r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+base, tag = sys.argv[1], sys.argv[2]
+out = os.path.join(ROOT, "profiles")
+shutil.copy(glob.glob(base + "/trace/runc/*kernel_stats.csv")[0], f"{out}/{tag}_kernel_stats.csv")
+for f in ("bench_default.json", "bench_under_rocprof.json"):
+    shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
+if os.path.exists(base + "/kbench_16mp.txt"):
+    shutil.copy(base + "/kbench_16mp.txt", f"{out}/{tag}_kbench_16mp.txt")
+
+
+def load(d):
+    f = glob.glob(f"{base}/{d}/runc/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ugsm::", "")
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+from ug_stereomatcher_amd import _lib  # noqa: E402
+pi = _lib.pixel_iterations(4928, 3264, 14, 0)
+rd, wr, fe = load("pmc_rdreq"), load("pmc_write"), load("pmc_fetch")
+lines = [f"# {tag}: HBM traffic per kernel (PMC, separate passes; `bench.py --steps 4 --warmup 1 --slots 1`, 5 pairs)\n",
+         "Read bytes = 32*RDREQ_32B + 64*(RDREQ - RDREQ_32B - RDREQ_128B) + 128*RDREQ_128B (TCC_EA0_*_sum).  FETCH_SIZE is shown "
+         "beside it doubled: on gfx950 it tallies 128-B requests at 64 B, i.e. exactly half (MI355X_MICROARCH.md, HBM section) -- the two "
+         "agree.  Write bytes = WRITE_SIZE x 1024.  Algorithmic = 48 B x pixels of the launch (SURVEY.md 8d).\n",
+         "| kernel | launches | read MB/launch | 2 x FETCH_SIZE MB/launch | write MB/launch | algorithmic MB/launch | traffic / algorithmic |",
+         "|---|---|---|---|---|---|---|"]
+traffic = {}
+for k in sorted(rd, key=lambda k: -sum(rd[k]["TCC_EA0_RDREQ_sum"])):
+    c = rd[k]
+    n = len(c["TCC_EA0_RDREQ_sum"])
+    tot, r32, r128 = sum(c["TCC_EA0_RDREQ_sum"]), sum(c["TCC_EA0_RDREQ_32B_sum"]), sum(c["TCC_EA0_RDREQ_128B_sum"])
+    rb = 32 * r32 + 64 * (tot - r32 - r128) + 128 * r128
+    f = sum(fe[k]["FETCH_SIZE"]) * 1024 * 2
+    w = sum(wr[k]["WRITE_SIZE"]) * 1024
+    a = ratio = ""
+    if k.startswith("k_cost"):
+        algb = 48.0 * pi * 5 / n
+        a, ratio = f"{algb / 1e6:.2f}", f"{(rb + w) / n / algb:.2f}"
+        traffic[k.split("<")[0]] = (rb + w) / n
+    lines.append(f"| {k} | {n} | {rb / n / 1e6:.2f} | {f / n / 1e6:.2f} | {w / n / 1e6:.2f} | {a} | {ratio} |")
+open(f"{out}/{tag}_hbm_traffic.md", "w").write("\n".join(lines) + "\n")
+json.dump({"full16mp": traffic,
+           "_note": "HBM bytes per launch (mean over the 218 launches of a 16 MP pair) of the dominant kernel: exact read bytes from "
+                    f"the size-binned TCC_EA0_RDREQ counters + WRITE_SIZE; see profiles/{tag}_hbm_traffic.md"},
+          open(f"{out}/pmc_traffic.json", "w"), indent=1)
+an = os.path.join(out, "analyze_trace.py")
+subprocess.check_call([sys.executable, an, base + "/trace", "--out", f"{out}/{tag}_trace_summary.md"], stdout=subprocess.DEVNULL)
+with open(f"{out}/{tag}_pmc_summary.md", "w") as fo:
+    fo.write(f"# {tag}: SQ counters (two separate PMC passes, single slot, 5 pairs; mean per dispatch)\n")
+    for d in ("pmc_sq1", "pmc_sq2"):
+        txt = subprocess.check_output([sys.executable, an, base + "/" + d]).decode()
+        keep = [l for l in txt.split("\n") if l.startswith("- k_cost") or l.startswith("- k_smooth")]
+        fo.write(f"\n## {d}\n" + "\n".join(keep[:14]) + "\n")
+print("\n".join(lines))
