@@ -105,6 +105,8 @@ def main():
     ud.barrier()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback); the CPU oracle is only the baseline leg")
+    if os.environ.get("UGSM_BENCH_DEVICE") is not None:  # rehearsal of N ranks on a box with fewer GPUs
+        local_rank = int(os.environ["UGSM_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -225,8 +227,8 @@ def main():
                                           "sample": f"failed: {e}"}
         print(json.dumps(result), flush=True)
     ctx.close()
-    if world > 1:
-        import torch.distributed as td
+    import torch.distributed as td
+    if td.is_initialized():
         td.destroy_process_group()
 
 

@@ -30,7 +30,9 @@ def env_rank_world():
 def init(backend: str | None = None):
     """Initialises the default process group from the torchrun environment (no-op for 1 process)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    backend = backend or os.environ.get("UGSM_DIST_BACKEND")  # rehearsals: "gloo" on a box with fewer GPUs than ranks
+    force = os.environ.get("UGSM_FORCE_DIST") == "1"          # rehearsal: a 1-rank RCCL group on a 1-GPU box
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -41,6 +43,13 @@ def init(backend: str | None = None):
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def _coll_device(device=None):
+    """Scalars reduced over RCCL live on the GPU; over gloo (CPU rehearsals) on the host."""
+    if dist.get_backend() != "nccl":
+        return "cpu"
+    return device or "cuda"
 
 
 def shard_pairs(n_pairs: int, rank: int, world: int):
@@ -57,7 +66,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     """bench.py contract: the timed region's duration is the MAX over ranks."""
     if not dist.is_initialized():
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t = torch.tensor([seconds], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -65,7 +74,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
 def sum_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
