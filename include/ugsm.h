@@ -128,6 +128,16 @@ int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state);
 int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int off_x, int off_y,
                            float *d_stack);
 
+/* ---- next row: triangulation of the full-resolution disparity ---------- */
+
+/* CdynamicCalibration::get3DPoint, non-foveated branch (src/pointcloud/getPointCloud.cpp:886-949),
+ * for every pixel of the match result instead of the node's scalar host loops (:640-660, :778).
+ * d_dispx/d_dispy: H*W device planes (e.g. planes 0 and 1 of ugsm_submit_full's d_out); P1, P2:
+ * the 3x4 projection matrices of calL.xml/calR.xml, row-major doubles on the HOST; d_xyz: 3 device
+ * planes X, Y, Z.  Enqueued on `slot`'s stream (ordered after a submit on the same slot). */
+int ugsm_triangulate(ugsm_ctx *ctx, int slot, const float *d_dispx, const float *d_dispy, int W, int H,
+                     const double *P1, const double *P2, float *d_xyz);
+
 /* ---- stage-level entry points (tests only; device pointers; synchronous) -------- */
 
 /* CreatePyramidFromImage, MatchGPULib.cpp:1033-1125: builds the pyramid of one rgb8

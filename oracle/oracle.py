@@ -230,3 +230,15 @@ def match_foveated(rgbL, rgbR, levels=14, F=7, off_x=0, off_y=0, want_pyr=False)
     if rc:
         raise RuntimeError(f"orc_match_foveated rc={rc}")
     return stack, pl, pr
+
+
+def triangulate(dispx: np.ndarray, dispy: np.ndarray, P1: np.ndarray, P2: np.ndarray) -> np.ndarray:
+    """getPointCloud.cpp:886-949 (get3DPoint, non-foveated) for every pixel -> (3, H, W) X, Y, Z."""
+    H, W = dispx.shape
+    out = np.empty((3, H, W), np.float32)
+    p1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+    p2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+    dp = C.POINTER(C.c_double)
+    lib().orc_triangulate(_fp(np.ascontiguousarray(dispx)), _fp(np.ascontiguousarray(dispy)), W, H,
+                          p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), _fp(out))
+    return out

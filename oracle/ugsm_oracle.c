@@ -695,3 +695,59 @@ int orc_match_foveated(const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, i
     for (int i = 0; i < levels; i++) { free(pl[i]); free(pr[i]); }
     return 0;
 }
+
+/* ---- triangulation of the full-resolution disparity -----------------------
+ * src/pointcloud/getPointCloud.cpp:886-949 (CdynamicCalibration::get3DPoint, non-foveated branch
+ * :909-914), called per pixel by the reconstruction loops (:640-660 with sampling, :778).
+ * P1, P2: 3x4 projection matrices, row major, double (Mat_<double>).  The closed form mixes float
+ * and double exactly as the C++ source does: a..j,x,y are floats; pow(v,2.0) promotes to double
+ * (v*v is exact in binary64 for a binary32 v, so the product restates pow); literals 2.0 are double.
+ * No contraction (host code built without -mfma). out: X, Y, Z planes. */
+static inline double sq_d(float v) { return (double)v * (double)v; }
+
+void orc_triangulate(const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz)
+{
+    const size_t n = (size_t)W * H;
+    pick_threads(n);
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < H; yy++) {
+        for (int xx = 0; xx < W; xx++) {
+            const size_t at = (size_t)yy * W + xx;
+            float x1, x2, y1, y2;
+            x1 = xx;
+            y1 = yy;
+            x2 = xx + dispx[at];
+            y2 = yy + dispy[at];
+            float a, b, c, d, e, f, g, h, i, j, x, y;
+            a = (float)P1[0];
+            b = (float)(P1[2] - x1);
+            c = (float)P1[5];
+            d = (float)(P1[6] - y1);
+            e = (float)(P2[0] - x2 * P2[8]);
+            f = (float)(P2[1] - x2 * P2[9]);
+            g = (float)(P2[2] - x2 * P2[10]);
+            h = (float)(P2[4] - y2 * P2[8]);
+            i = (float)(P2[5] - y2 * P2[9]);
+            j = (float)(P2[6] - y2 * P2[10]);
+            x = (float)(x2 * P2[11] - P2[3]);
+            y = (float)(y2 * P2[11] - P2[7]);
+            float XUp = (d*f*h - c*g*h - d*e*i + c*e*j)*(-(d*i*x) + c*j*x + d*f*y - c*g*y) +
+                        sq_d(b)*((f*h - e*i)*(-(i*x) + f*y) + sq_d(c)*(e*x + h*y)) +
+                        a*b*((-(g*i) + f*j)*(i*x - f*y) + c*d*(f*x + i*y) - sq_d(c)*(g*x + j*y));
+            float YUp = (sq_d(b)*(f*h - e*i) + d*(d*f*h - c*g*h - d*e*i + c*e*j))*(h*x - e*y) +
+                        a*b*((c*d*e + g*h*i - 2.0*f*h*j + e*i*j)*x + (c*d*h + f*g*h - 2.0*e*g*i + e*f*j)*y) +
+                        sq_d(a)*((g*i - f*j)*(-(j*x) + g*y) + sq_d(d)*(f*x + i*y) - c*d*(g*x + j*y));
+            float ZUp = c*(-(d*f*h) + c*g*h + d*e*i - c*e*j)*(h*x - e*y) - a*b*((f*h - e*i)*(-(i*x) + f*y) +
+                        sq_d(c)*(e*x + h*y)) + sq_d(a)*((g*i - f*j)*(i*x - f*y) - c*d*(f*x + i*y) +
+                        sq_d(c)*(g*x + j*y));
+            float divisor = sq_d(b)*(sq_d(c)*(sq_d(e) + sq_d(h)) + sq_d(f*h - e*i)) +
+                            sq_d(d*f*h - c*g*h - d*e*i + c*e*j) - 2.0*a*b*(-(c*d*(e*f + h*i)) +
+                            (f*h - e*i)*(-(g*i) + f*j) + sq_d(c)*(e*g + h*j)) + sq_d(a)*
+                            (sq_d(d)*(sq_d(f) + sq_d(i)) + sq_d(g*i - f*j) - 2.0*c*d*(f*g + i*j) +
+                            sq_d(c)*(sq_d(g) + sq_d(j)));
+            xyz[at] = XUp / divisor;
+            xyz[n + at] = YUp / divisor;
+            xyz[2 * n + at] = ZUp / divisor;
+        }
+    }
+}

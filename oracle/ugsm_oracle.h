@@ -98,6 +98,10 @@ void orc_fovea_geometry(int W, int H, int levels, int F, int off_x, int off_y,
                         int *fovW, int *fovH, int *org_x, int *org_y /*[F-1]*/,
                         int *crop_x, int *crop_y /*[F-1], for transition lev+1 -> lev */);
 
+/* SURVEY 8f row f-1 -- getPointCloud.cpp:886-949 (get3DPoint, non-foveated), P1/P2 row-major 3x4 doubles;
+ * xyz: X, Y, Z planes of W*H floats. */
+void orc_triangulate(const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

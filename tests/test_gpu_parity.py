@@ -450,3 +450,32 @@ def test_exact_shortcuts_of_the_fused_kernels(lib, orc):
     assert_bit_equal(got_k, ref_k, "poly_fast corr")
     pos = ~np.isnan(c)
     assert_bit_equal(got_t[pos], (c[pos] / np.float32(3.0)).astype(np.float32), "x/3 by two FMAs")
+
+
+def test_triangulation_matches_oracle(lib, orc):
+    """Row f-1: X, Y, Z planes from (dx, dy) and the rig's P1/P2 -- bit-exact against the restatement of
+    get3DPoint (getPointCloud.cpp:886-949), with the 16 MP rig's projection matrices (values as in the
+    reference's calibrations/calL.xml / calR.xml P entries, right camera's rounded here) and a generic
+    non-rectified pair."""
+    rng = np.random.Generator(np.random.PCG64(8))
+    P1 = np.array([[7.3230899280915291e+03, 0., 2.4836974544986647e+03, 0.],
+                   [0., 7.3035803715514758e+03, 1.7170248033347561e+03, 0.], [0., 0., 1., 0.]])
+    P2a = np.array([[6.78780819e+03, -1.92174329e+02, 3.52550369e+03, -2.01574768e+03],
+                    [2.8e+02, 7.29e+03, 1.69e+03, 3.1e+01], [2.0e-01, 1.0e-02, 9.8e-01, 3.0e-03]])
+    P2b = P1.copy()
+    P2b[0, 3] = -7.3230899280915291e+03 * 0.12
+    ctx = lib.Context(levels=3)
+    try:
+        for (W, H, P2) in [(317, 203, P2a), (640, 480, P2b), (33, 7, P2a)]:
+            dx = rng.normal(-40, 25, (H, W)).astype(np.float32)
+            dy = rng.normal(0, 2, (H, W)).astype(np.float32)
+            exp = orc.triangulate(dx, dy, P1, P2)
+            pdx, pdy = ctx.to_device(dx), ctx.to_device(dy)
+            pout = ctx.alloc(3 * W * H * 4)
+            ctx.triangulate(pdx, pdy, W, H, P1, P2, pout)
+            got = ctx.to_host(pout, (3, H, W))
+            for p in (pdx, pdy, pout):
+                ctx.free(p)
+            assert_bit_equal(got, exp, f"triangulation {W}x{H}")
+    finally:
+        ctx.close()

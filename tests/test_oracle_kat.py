@@ -204,3 +204,19 @@ def test_constant_shift_is_recovered(orc):
     assert abs(np.median(inner) - k) < 0.5
     assert abs(np.median(out[1][30:-30, 30:-30])) < 0.5
     assert not np.isnan(out).any()
+
+
+def test_triangulation_rectified_rig(orc):
+    """SURVEY 8f row f-1 (getPointCloud.cpp:886-949).  For a rectified rig P1 = K[I|0], P2 = K[I|t],
+    t = (-B, 0, 0), the closed form must give Z = -f*B/dx, X = (x-cx)*Z/f, Y = (y-cy)*Z/f."""
+    f, cx, cy, B = 1000.0, 320.0, 240.0, 0.1
+    P1 = np.array([[f, 0, cx, 0], [0, f, cy, 0], [0, 0, 1, 0]])
+    P2 = np.array([[f, 0, cx, -f * B], [0, f, cy, 0], [0, 0, 1, 0]])
+    H, W = 48, 64
+    Z = 2.0 + 0.5 * np.random.default_rng(1).random((H, W))
+    dx = (-f * B / Z).astype(np.float32)
+    xyz = orc.triangulate(dx, np.zeros((H, W), np.float32), P1, P2)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H))
+    assert np.abs(xyz[2] - Z).max() < 1e-3
+    assert np.abs(xyz[0] - (xs - cx) * Z / f).max() < 1e-3
+    assert np.abs(xyz[1] - (ys - cy) * Z / f).max() < 1e-3

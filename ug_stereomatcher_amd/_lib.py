@@ -29,7 +29,7 @@ EXPORTS = [
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
     "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_match_full",
     "ugsm_match_foveated", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
-    "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_stage_pyramid",
+    "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_get_kernel_stats",
     "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
@@ -90,6 +90,7 @@ def load():
     lib.ugsm_submit_pyramids.argtypes = [vp, i, vp, vp, i, i, i]
     lib.ugsm_submit_fovea_coarse.argtypes = [vp, i, vp]
     lib.ugsm_submit_fovea_fine.argtypes = [vp, i, vp, i, i, vp]
+    lib.ugsm_triangulate.argtypes = [vp, i, vp, vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
     lib.ugsm_stage_pyramid.argtypes = [vp, vp, i, i, i, i, vp]
     lib.ugsm_stage_iterate.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ugsm_stage_seed.argtypes = [vp, vp, i, i, vp, i, i, i, i, i, i]
@@ -213,6 +214,14 @@ class Context:
         out = np.empty(shape, dtype)
         self.check(self.lib.ugsm_copy_to_host(self._h, out.ctypes.data, ptr, out.nbytes))
         return out
+
+    def triangulate(self, d_dispx: int, d_dispy: int, W: int, H: int, P1, P2, d_xyz: int, slot: int = 0):
+        """SURVEY 8f row f-1 (getPointCloud.cpp:886-949): X, Y, Z planes from device (dx, dy) planes."""
+        p1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+        p2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+        dp = C.POINTER(C.c_double)
+        self.check(self.lib.ugsm_triangulate(self._h, slot, d_dispx, d_dispy, W, H, p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), d_xyz))
+        self.check(self.lib.ugsm_wait(self._h, slot))
 
     def kernel_stats(self):
         arr = (KernelStat * 16)()

@@ -902,6 +902,71 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
     }
 }
 
+// =========================================================================================
+// triangulation of the full-resolution disparity into X, Y, Z planes.
+// CdynamicCalibration::get3DPoint, non-foveated branch (src/pointcloud/getPointCloud.cpp:886-949), for
+// every pixel: the reference calls it from scalar host loops behind a progress bar (:640-660, :778).
+// Purely per-pixel (reads 8 B, writes 12 B): HBM-bound.  The closed form keeps the source's mix of float
+// and double term by term (a..j, x, y are floats; pow(v,2.0) is the exact binary64 square; the literal
+// 2.0 is a double) -- the expression text is kept identical to the CPU restatement used by the tests, no contraction.
+// =========================================================================================
+struct Proj {
+    double m[12];  // 3x4, row major
+};
+__device__ __forceinline__ double sq_d(float v) { return (double)v * (double)v; }
+
+__global__ __launch_bounds__(256) void k_triangulate(const float *__restrict__ dispx, const float *__restrict__ dispy, int W, int H, Proj P1q, Proj P2q,
+                                                     float *__restrict__ xyz)
+{
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    if (xx >= W) return;
+    const double *P1 = P1q.m, *P2 = P2q.m;
+    const size_t n = (size_t)W * H, at = (size_t)yy * W + xx;
+    float x1, x2, y1, y2;
+    x1 = xx;
+    y1 = yy;
+    x2 = xx + dispx[at];
+    y2 = yy + dispy[at];
+    float a, b, c, d, e, f, g, h, i, j, x, y;
+    a = (float)P1[0];
+    b = (float)(P1[2] - x1);
+    c = (float)P1[5];
+    d = (float)(P1[6] - y1);
+    e = (float)(P2[0] - x2 * P2[8]);
+    f = (float)(P2[1] - x2 * P2[9]);
+    g = (float)(P2[2] - x2 * P2[10]);
+    h = (float)(P2[4] - y2 * P2[8]);
+    i = (float)(P2[5] - y2 * P2[9]);
+    j = (float)(P2[6] - y2 * P2[10]);
+    x = (float)(x2 * P2[11] - P2[3]);
+    y = (float)(y2 * P2[11] - P2[7]);
+    float XUp = (d*f*h - c*g*h - d*e*i + c*e*j)*(-(d*i*x) + c*j*x + d*f*y - c*g*y) +
+                sq_d(b)*((f*h - e*i)*(-(i*x) + f*y) + sq_d(c)*(e*x + h*y)) +
+                a*b*((-(g*i) + f*j)*(i*x - f*y) + c*d*(f*x + i*y) - sq_d(c)*(g*x + j*y));
+    float YUp = (sq_d(b)*(f*h - e*i) + d*(d*f*h - c*g*h - d*e*i + c*e*j))*(h*x - e*y) +
+                a*b*((c*d*e + g*h*i - 2.0*f*h*j + e*i*j)*x + (c*d*h + f*g*h - 2.0*e*g*i + e*f*j)*y) +
+                sq_d(a)*((g*i - f*j)*(-(j*x) + g*y) + sq_d(d)*(f*x + i*y) - c*d*(g*x + j*y));
+    float ZUp = c*(-(d*f*h) + c*g*h + d*e*i - c*e*j)*(h*x - e*y) - a*b*((f*h - e*i)*(-(i*x) + f*y) +
+                sq_d(c)*(e*x + h*y)) + sq_d(a)*((g*i - f*j)*(i*x - f*y) - c*d*(f*x + i*y) +
+                sq_d(c)*(g*x + j*y));
+    float divisor = sq_d(b)*(sq_d(c)*(sq_d(e) + sq_d(h)) + sq_d(f*h - e*i)) +
+                    sq_d(d*f*h - c*g*h - d*e*i + c*e*j) - 2.0*a*b*(-(c*d*(e*f + h*i)) +
+                    (f*h - e*i)*(-(g*i) + f*j) + sq_d(c)*(e*g + h*j)) + sq_d(a)*
+                    (sq_d(d)*(sq_d(f) + sq_d(i)) + sq_d(g*i - f*j) - 2.0*c*d*(f*g + i*j) +
+                    sq_d(c)*(sq_d(g) + sq_d(j)));
+    xyz[at] = XUp / divisor;
+    xyz[n + at] = YUp / divisor;
+    xyz[2 * n + at] = ZUp / divisor;
+}
+
+void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz)
+{
+    Proj a, b;
+    for (int k = 0; k < 12; k++) { a.m[k] = P1[k]; b.m[k] = P2[k]; }
+    hipLaunchKernelGGL(k_triangulate, dim3((W + 255) / 256, H), dim3(256), 0, st, dispx, dispy, W, H, a, b, xyz);
+}
+
 // test hook (tests only): poly_fast on arbitrary operands, so that its rarely taken f64 fallback and the
 // special values are exercised against the oracle's literal PolyDisparity
 __global__ void k_poly_probe(const float *__restrict__ c, const float *__restrict__ l, const float *__restrict__ r, const float *__restrict__ thr,

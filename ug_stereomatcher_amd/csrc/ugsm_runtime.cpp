@@ -783,6 +783,21 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
     return ugsm_wait(ctx, 0);
 }
 
+int ugsm_triangulate(ugsm_ctx *ctx, int slot, const float *d_dispx, const float *d_dispy, int W, int H, const double *P1, const double *P2,
+                     float *d_xyz)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_dispx || !d_dispy || !P1 || !P2 || !d_xyz || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        Timer t(ctx, s, slot, KC_MISC, (double)W * H);
+        launch_triangulate(s->st, d_dispx, d_dispy, W, H, P1, P2, d_xyz);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
 int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r, const float *d_thr, float *d_delta,
                           float *d_corr, float *d_third, int n)
 {
