@@ -479,3 +479,29 @@ def test_triangulation_matches_oracle(lib, orc):
             assert_bit_equal(got, exp, f"triangulation {W}x{H}")
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("W,H,levels", [(333, 251, 10), (130, 97, 7), (257, 129, 8), (65, 57, 5), (1000, 31, 5)])
+def test_full_mode_odd_sizes_end_to_end(lib, ctx, orc, W, H, levels):
+    """Tile remainders in every kernel at every level of a whole coarse-to-fine run."""
+    from ug_stereomatcher_amd import MatchGPULib, synth
+    L, R, _, _ = synth.make_pair(W, H, 4000 + W)
+    m = MatchGPULib(levels=levels, kernel_path=ctx.cfg.kernel_path)
+    try:
+        out = m.match(L, R, 0)
+    finally:
+        m.close()
+    assert_bit_equal(out, orc.match_full(L, R, levels), f"{W}x{H} levels={levels}")
+
+
+def test_foveated_odd_size_and_offsets(lib, ctx, orc):
+    from ug_stereomatcher_amd import MatchGPULib, synth
+    L, R, _, _ = synth.make_pair(403, 277, 4242)
+    m = MatchGPULib(3, ["node", "x", "5"], levels=10, kernel_path=ctx.cfg.kernel_path)
+    try:
+        for off in [(0, 0), (-90, 40), (500, -500)]:  # the last one is clamped at every level
+            st = m.matchStack(L, R, *off)
+            exp, _, _ = orc.match_foveated(L, R, 10, 5, *off)
+            assert_bit_equal(st.transpose(1, 0, 2, 3), exp, f"fovea offset {off}")
+    finally:
+        m.close()
