@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--cpu-sample", default="full", choices=["1080p", "full"], help="full = one pair of the workload itself (about 3-6 s at 16 MP)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events on slot 0")
+    ap.add_argument("--all-events", action="store_true", help="bracket every kernel class, not only the dominant one (slower)")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,7 +116,7 @@ def main():
     slots = max(1, args.slots)
     F = 7
     ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path,
-                       profile_events=not args.no_events)
+                       profile_events=0 if args.no_events else (2 if args.all_events else 1))
     fw, fh = _lib.fovea_dims(W, H, 14, F)
 
     # synthetic inputs: two distinct pairs per rank, resident in HBM before the timed region

@@ -54,7 +54,7 @@ typedef struct ugsm_config {
     int fovea_levels;
     int slots;
     int kernel_path;
-    int profile_events; /* 1: slot 0 records HIP events around every match-iteration kernel */
+    int profile_events; /* slot 0 brackets kernels with HIP events: 1 = the cost kernel only, 2 = every kernel class */
     int reserved[6];
 } ugsm_config;
 

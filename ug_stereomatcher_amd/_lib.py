@@ -155,7 +155,7 @@ class Context:
     """Owns a ugsm_ctx*.  One per device; calls must be serialised by the caller."""
 
     def __init__(self, device: int = 0, levels: int = 14, fovea_levels: int = 7, slots: int = 1,
-                 kernel_path: int = 0, profile_events: bool = False):
+                 kernel_path: int = 0, profile_events: int = 0):
         lib = load()
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))

@@ -993,6 +993,12 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
     hipLaunchKernelGGL(k_cost_split<0>, dim3(n_tiles), dim3(512), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles);
 }
 
+#ifndef UGSM_SMOOTH_MID_NT
+#define UGSM_SMOOTH_MID_NT 1024  // one quad-row per thread per pass: the mid/small levels are latency-bound (16.5 vs 17.7 ms per pair)
+#endif
+#ifndef UGSM_SMOOTH_SMALL_NT
+#define UGSM_SMOOTH_SMALL_NT 512
+#endif
 template <int STX, int STY, int NT>
 static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
@@ -1014,8 +1020,8 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
     if (px >= ((size_t)1 << 19)) launch_smooth_t<64, 64, 512>(st, s3, o3, W, H, passes, do_box);
-    else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, 256>(st, s3, o3, W, H, passes, do_box);
-    else launch_smooth_t<32, 16, 256>(st, s3, o3, W, H, passes, do_box);
+    else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
+    else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }
 
 // =========================================================================================

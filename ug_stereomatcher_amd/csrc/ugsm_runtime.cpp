@@ -221,7 +221,9 @@ struct Timer {
     EvRec rec;
     Timer(ugsm_ctx *c, Slot *sl, int slot_idx, int kclass, double pixels) : ctx(c), s(sl)
     {
-        on = c->cfg.profile_events && slot_idx == 0;
+        // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
+        // has ~750 launches; bracketing all of them costs slot 0 about 20 %); 2: every kernel class
+        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && kclass == KC_COST));
         if (!on) return;
         rec.kclass = kclass;
         rec.pixels = pixels;
