@@ -161,6 +161,12 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
 int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r,
                           const float *d_thr, float *d_delta, float *d_corr, float *d_third, int n);
 
+/* K-smooth's shared-reciprocal division (three weighted sums over one sumCorr, MatchLib.cu:1131-1139)
+ * on caller-supplied operands, with the kernel's own range test and literal fallback:
+ * q_f[i] must equal the IEEE binary32 quotient a_f[i] / s[i] bit for bit. */
+int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2,
+                          const float *d_s, float *d_q0, float *d_q1, float *d_q2, int n);
+
 /* ---- instrumentation ------------------------------------------------------------ */
 
 typedef struct ugsm_kernel_stat {

@@ -161,6 +161,36 @@ def test_smooth_and_box_stage(ctx, orc):
             assert_bit_equal(got, exp, f"{W}x{H} passes={passes} box={box}")
 
 
+def test_smooth_interior_tiles_and_degenerate_confidence(ctx, orc):
+    """Sizes that reach every K-smooth tile shape with tiles whose region is strictly inside the image (the
+    select-free interior pass), and confidence fields that push sumCorr out of the shared-reciprocal range:
+    zero patches (0/0 -> NaN spreading by one pixel per pass), negative, 1e-30 and 1e30 weights."""
+    rng = np.random.Generator(np.random.PCG64(37))
+    for (W, H) in [(900, 700), (520, 300), (200, 150)]:
+        d = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 3, (H, W)), 0.1 + 0.9 * rng.random((H, W))]).astype(np.float32)
+        for variant in ("plain", "degenerate"):
+            if variant == "degenerate":
+                d = d.copy()
+                d[2, 40:60, 50:90] = 0.0
+                d[2, 100:104, 100:140] = -0.25
+                d[2, 120:124, 20:60] = 1e-30
+                d[2, 130:134, 20:60] = 1e30
+                d[0, 140:144, 20:60] = 0.0
+                d[2, H - 30:H - 10, W - 80:W - 40] = 0.0
+            for passes, box in [(5, 1), (10, 1), (2, 0)]:
+                exp = d
+                with np.errstate(all="ignore"):
+                    for _ in range(passes):
+                        exp = orc.smooth_pass(exp)
+                    if box:
+                        exp = orc.box3(exp)
+                p = ctx.to_device(d)
+                ctx.check(ctx.lib.ugsm_stage_smooth(ctx.handle, p, W, H, passes, box))
+                got = ctx.to_host(p, d.shape)
+                ctx.free(p)
+                assert_bit_equal(got, exp, f"{W}x{H} {variant} passes={passes} box={box}")
+
+
 def test_seed_stage(ctx, orc):
     rng = np.random.Generator(np.random.PCG64(31))
     src = rng.normal(0, 5, (3, 70, 99)).astype(np.float32)
@@ -450,6 +480,62 @@ def test_exact_shortcuts_of_the_fused_kernels(lib, orc):
     assert_bit_equal(got_k, ref_k, "poly_fast corr")
     pos = ~np.isnan(c)
     assert_bit_equal(got_t[pos], (c[pos] / np.float32(3.0)).astype(np.float32), "x/3 by two FMAs")
+
+
+def test_smooth_division_shared_reciprocal_is_ieee(lib):
+    """K-smooth divides three sums by one sumCorr through a binary64 reciprocal.  The
+    result must be the IEEE binary32 quotient for every operand: random mantissas over the whole exponent
+    range, the values the pipeline produces, quotients that land on subnormals / overflow, and the
+    denominators that take the literal fallback (0, -0, negative, tiny, huge, Inf, NaN)."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    n = 1 << 21
+    def rand_f32(m, emin, emax):
+        mant = rng.integers(0, 1 << 23, m, dtype=np.uint32)
+        ex = rng.integers(emin + 127, emax + 128, m, dtype=np.uint32)
+        sign = rng.integers(0, 2, m, dtype=np.uint32) << 31
+        return (sign | (ex << 23) | mant).view(np.float32)
+    a = [rand_f32(n, -126, 127) for _ in range(3)]
+    s = np.abs(rand_f32(n, -64, 63))
+    q = n // 4
+    # pipeline-like: confidences in [0.16, 1.42] summed over five taps, disparities of a few pixels
+    s[:q] = rng.uniform(0.8, 7.1, q).astype(np.float32)
+    for f in range(3):
+        a[f][:q] = (rng.normal(0, 30, q) * s[:q]).astype(np.float32)
+    # hard cases for a reciprocal-based quotient: denominators just below a power of two, numerators
+    # with all-ones mantissas, exact quotients, numerators equal to the denominator
+    s[q:q + 4096] = np.nextafter(np.float32(2.0) ** rng.integers(-60, 60, 4096).astype(np.float32), np.float32(0))
+    a[0][q:q + 4096] = np.nextafter(np.float32(2.0) ** rng.integers(-100, 100, 4096).astype(np.float32), np.float32(0))
+    a[1][q:q + 4096] = s[q:q + 4096]
+    a[2][q:q + 4096] = s[q:q + 4096] * np.float32(3.0)
+    # subnormal numerators and results, overflowing results
+    a[0][2 * q:2 * q + 4096] = rand_f32(4096, -126, -120) * np.float32(2.0 ** -20)
+    a[1][2 * q:2 * q + 4096] = rand_f32(4096, 100, 127)
+    s[2 * q:2 * q + 2048] = np.abs(rand_f32(2048, 30, 63))
+    s[2 * q + 2048:2 * q + 4096] = np.abs(rand_f32(2048, -64, -30))
+    # fallback denominators
+    special = np.array([0.0, -0.0, -1.5, np.inf, -np.inf, np.nan, 1e-30, 1e30, 2.0 ** -64, 2.0 ** 64,
+                        np.nextafter(np.float32(2.0 ** -64), np.float32(0)), np.nextafter(np.float32(2.0 ** 64), np.float32(np.inf)),
+                        1e-45, 3e38], np.float32)
+    k = len(special)
+    for j in range(8):
+        s[3 * q + j * k:3 * q + (j + 1) * k] = special
+    a[0][3 * q:3 * q + 4 * k] = 0.0
+    a[1][3 * q:3 * q + 2 * k] = np.inf
+    a[2][3 * q:3 * q + 3 * k] = np.nan
+    with np.errstate(all="ignore"):
+        exp = [(x / s).astype(np.float32) for x in a]
+    ctx = lib.Context(levels=3)
+    try:
+        ptrs = [ctx.to_device(x) for x in (*a, s)]
+        outs = [ctx.alloc(4 * n) for _ in range(3)]
+        ctx.check(ctx.lib.ugsm_stage_div3_probe(ctx.handle, *ptrs, *outs, n))
+        got = [ctx.to_host(p, (n,)) for p in outs]
+        for p in ptrs + outs:
+            ctx.free(p)
+    finally:
+        ctx.close()
+    for f in range(3):
+        assert_bit_equal(got[f], exp[f], f"shared-reciprocal quotient, plane {f}")
 
 
 def test_triangulation_matches_oracle(lib, orc):

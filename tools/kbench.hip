@@ -4,6 +4,7 @@
 // Times k_cost_fused and k_smooth_fused on one level-sized random problem with HIP events.
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,20 +44,79 @@ int main(int argc, char **argv)
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
         COST(0); SPLIT(0);
     }
+    {   // phase stamps of k_cost_split<256>
+        const int nb = std::min(cnt, 8192);
+        long long *dst; CK(hipMalloc(&dst, sizeof(long long) * 48 * nb)); CK(hipMemset(dst, 0, sizeof(long long) * 48 * nb));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cost_stamps), &dst, sizeof(dst)));
+        hipLaunchKernelGGL(k_cost_split<256>, dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt);
+        CK(hipStreamSynchronize(st));
+        std::vector<long long> hs(48 * (size_t)nb);
+        CK(hipMemcpy(hs.data(), dst, sizeof(long long) * 48 * nb, hipMemcpyDeviceToHost));
+        const char *names[16] = {"start", "P0 issued", "c0 P1+bar (data in LDS)", "c0 P2+bar", "c0 P2.5+bar", "c0 P3", "c1 P1+bar", "c1 P2+bar", "c1 P2.5+bar", "c1 P3",
+                                 "c2 P1+bar", "c2 P2+bar", "c2 P2.5+bar", "c2 P3", "bar after P3", "end"};
+        for (int role = 0; role < 2; role++) {
+            printf("k_cost_split phase stamps, role %d (mean cycles since previous stamp over %d workgroups; shader clock)\n", role, nb);
+            double tot = 0;
+            {   // P0 detail: start -> 16 (ridx computed: d3 arrived) -> 17 (L loads issued) -> 18 (R gathers issued) -> 1
+                const int seq[5] = {0, 16, 17, 18, 1};
+                const char *nm[5] = {"", "  P0: d3 in, ridx done", "  P0: L loads issued", "  P0: R gathers issued", "  P0: A/d loads issued"};
+                for (int j = 1; j < 5; j++) {
+                    double sum = 0; int m = 0;
+                    for (int b = 0; b < nb; b++) {
+                        const long long *t = &hs[((size_t)b * 2 + role) * 24];
+                        if (t[seq[j]] && t[seq[j - 1]]) { sum += (double)(t[seq[j]] - t[seq[j - 1]]); m++; }
+                    }
+                    printf("  %-26s %9.0f\n", nm[j], m ? sum / m : 0.0);
+                }
+            }
+            for (int i = 1; i < 16; i++) {
+                double sum = 0; int m = 0;
+                for (int b = 0; b < nb; b++) {
+                    const long long *t = &hs[((size_t)b * 2 + role) * 24];
+                    if (t[i] && t[i - 1]) { sum += (double)(t[i] - t[i - 1]); m++; }
+                }
+                printf("  %-26s %9.0f\n", names[i], m ? sum / m : 0.0);
+                tot += m ? sum / m : 0.0;
+            }
+            printf("  %-26s %9.0f\n", "total", tot);
+        }
+        long long t0 = hs[0], t1 = 0;
+        for (int b = 0; b < nb; b++) { t0 = std::min(t0, hs[(size_t)b * 48]); t1 = std::max(t1, hs[(size_t)b * 48 + 15]); }
+        printf("  first start -> last end of those workgroups: %lld ticks\n", t1 - t0);
+        dst = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_cost_stamps), &dst, sizeof(dst)));
+    }
     {
-        auto run = [&](auto kern, int stx, int sty, int nt, const char *nm) {
+        auto run = [&](auto kern, int stx, int sty, int nt, const char *nm, int P = 5, int box = 1) {
             const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 20) * sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             const int stxn = (W + stx - 1) / stx, stn = stxn * ((H + sty - 1) / sty);
-            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, 5, 1, stxn, stn); });
+            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn); });
         };
         for (int round = 0; round < 2; round++) {
-            run(k_smooth_fused<128, 64, 1024>, 128, 64, 1024, "smooth<128,64,1024> p5+box");
-            run(k_smooth_fused<64, 64, 512>, 64, 64, 512, "smooth<64,64,512> p5+box");
+            run((k_smooth_fused<64, 58, 512, 0>), 64, 58, 512, "smooth<64,58,512> p5+box");
+            run((k_smooth_fused<64, 58, 512, 0>), 64, 58, 512, "smooth<64,58,512> p5", 5, 0);
+            run((k_smooth_fused<64, 58, 512, 4>), 64, 58, 512, "smooth<64,58,512> lds-we p5+box");
+            run((k_smooth_fused<64, 58, 512, 4>), 64, 58, 512, "smooth<64,58,512> lds-we p5", 5, 0);
+            run((k_smooth_fused<64, 58, 512, 5>), 64, 58, 512, "smooth<64,58,512> old-arith p5+box");
+            run((k_smooth_fused<64, 58, 512, 2>), 64, 58, 512, "smooth<64,58,512> +interior p5+box");
+            run((k_smooth_fused<64, 34, 512, 0>), 64, 34, 512, "smooth<64,34,512> p5+box");
+            run((k_smooth_fused<64, 34, 512, 0>), 64, 34, 512, "smooth<64,34,512> p5", 5, 0);
+            run((k_smooth_fused<64, 58, 384, 0>), 64, 58, 384, "smooth<64,58,384> p5+box");
+            run((k_smooth_fused<64, 58, 384, 0>), 64, 58, 384, "smooth<64,58,384> p5", 5, 0);
+            run((k_smooth_fused<64, 40, 384, 0>), 64, 40, 384, "smooth<64,40,384> p5+box");
+            run((k_smooth_fused<64, 40, 384, 0>), 64, 40, 384, "smooth<64,40,384> p5", 5, 0);
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });
     timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 1); });
+    {
+        const int W1 = (int)(W / 1.41421356), H1 = (int)(H / 1.41421356), W2 = W / 2, H2 = H / 2;
+        for (int round = 0; round < 2; round++) {
+            timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f); });
+            timeit("blur_decimate 2", [&]() { launch_blur_decimate(st, L, W, H, o, W2, H2, 2.0f); });
+            timeit("sqblur", [&]() { launch_sqblur_clamp(st, iL, W, H, o); });
+        }
+    }
     CK(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,7 @@
 // Citations: /root/reference/src/gpu_matcher/<file>:<line>.
 #include "ugsm_device.hpp"
 #include "ugsm_launch.hpp"
+#include <type_traits>
 
 namespace ugsm {
 
@@ -416,6 +417,17 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
 //                             role 1 (threads 256..511) = shifts (0,-1), (0,+1), the R'^2 passes + parabola y.
 // The roles are wave-uniform (no divergence).  They meet once per tile: role 0 hands Q(0,0) to role 1,
 // role 1 hands rho_y back (two 3.5 KB LDS exchanges in the dead sRow planes).
+// development only (tools/kbench.hip, ABL & 256): s_memtime stamps at the phase boundaries of wave 0 (role 0) and
+// wave 4 (role 1) of the first workgroups, 16 stamps each
+__device__ long long *g_cost_stamps = nullptr;
+#define UGSM_STAMP(i)                                                                                              \
+    do {                                                                                                           \
+        if constexpr (ABL & 256) {                                                                                 \
+            if ((tid & 255) == 0 && blockIdx.x < 8192 && g_cost_stamps)                                            \
+                g_cost_stamps[((size_t)blockIdx.x * 2 + (tid >> 8)) * 24 + (i)] = (long long)__builtin_readcyclecounter(); \
+        }                                                                                                          \
+    } while (0)
+
 template <int ABL>
 __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                     float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles)
@@ -437,38 +449,58 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
     const int cx = qx * 4;
     const int gy = y0 + trow, gx0 = x0 + cx;
     const bool live = trow < TY && gy < H && gx0 < W;
+    UGSM_STAMP(0);
 
-    // ---- P0: all global reads of the tile up front (see k_cost_fused) ---------------------------
+    // ---- P0: all global reads of the tile up front (see k_cost_fused).  Every load is unconditional on a
+    // clamped address and the out-of-range value is selected afterwards: loads inside `if (in)` blocks were
+    // compiled to one branch per load, and the six (dx,dy) loads that the warp addresses depend on to six
+    // load -> s_waitcnt vmcnt(0) round trips in a row (8.4k of the 48k cycles a tile takes, tools/kbench stamps).
+    // Addresses are a 32-bit byte offset against a uniform plane base (a plane is < 4 GiB).
     constexpr int NR = (IDX_H * IDX_W + 511) / 512;
     constexpr int NL = (SL_H * (TX + 4) + 511) / 512;
+    auto ldoff = [](const float *base, unsigned off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
     float rv[3][NR], lv[3][NL];
     int ridx[NR];
+    {
+        float ddx[NR], ddy[NR];
+        int gxh[NR], gyh[NR];
 #pragma unroll
-    for (int u = 0; u < NR; u++) {  // warped source offsets (warpAbyB, MatchLib.cu:510-515)
-        const int it = tid + u * 512;
-        ridx[u] = -1;
-        if (it < IDX_H * IDX_W) {
+        for (int u = 0; u < NR; u++) {  // (dx,dy) at the pixels whose warped fetch the tile needs
+            const int it = min(tid + u * 512, IDX_H * IDX_W - 1);
             const int r = it / IDX_W, c = it - r * IDX_W;
-            const int gxh = clampi(x0 + c - 3, 0, W - 1), gyh = clampi(y0 + r - 3, 0, H - 1);
-            const size_t at = (size_t)gyh * W + gxh;
-            const int sx = tex_index(((float)gxh + 0.5f) + d3[at], W);
-            const int sy = tex_index(((float)gyh + 0.5f) + d3[n + at], H);
-            ridx[u] = sy * R.pitch + sx;
+            gxh[u] = clampi(x0 + c - 3, 0, W - 1);
+            gyh[u] = clampi(y0 + r - 3, 0, H - 1);
+            const unsigned off = ((unsigned)gyh[u] * (unsigned)W + (unsigned)gxh[u]) * 4u;
+            ddx[u] = ldoff(d3, off);
+            ddy[u] = ldoff(d3 + n, off);
         }
-    }
+        UGSM_STAMP(16);
 #pragma unroll
-    for (int u = 0; u < NL; u++) {
-        const int it = tid + u * 512;
-        const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
-        const int gxl = x0 + c - 2, gyl = y0 + r - 2;
-        const bool in = it < SL_H * (TX + 4) && gxl >= 0 && gxl < W && gyl >= 0 && gyl < H;
+        for (int u = 0; u < NL; u++) {
+            const int it = min(tid + u * 512, SL_H * (TX + 4) - 1);
+            const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
+            const int gxl = x0 + c - 2, gyl = y0 + r - 2;
+            const bool in = gxl >= 0 && gxl < W && gyl >= 0 && gyl < H;
+            const unsigned off = ((unsigned)clampi(gyl, 0, H - 1) * (unsigned)L.pitch + (unsigned)clampi(gxl, 0, W - 1)) * 4u;
 #pragma unroll
-        for (int k = 0; k < 3; k++) lv[k][u] = in ? L.p[(size_t)k * L.plane + (size_t)gyl * L.pitch + gxl] : 0.0f;
+            for (int k = 0; k < 3; k++) {
+                const float t = ldoff(L.p + (size_t)k * L.plane, off);
+                lv[k][u] = in ? t : 0.0f;
+            }
+        }
+        UGSM_STAMP(17);
+#pragma unroll
+        for (int u = 0; u < NR; u++) {  // warped source offsets (warpAbyB, MatchLib.cu:510-515)
+            const int sx = tex_index(((float)gxh[u] + 0.5f) + ddx[u], W);
+            const int sy = tex_index(((float)gyh[u] + 0.5f) + ddy[u], H);
+            ridx[u] = (sy * R.pitch + sx) * 4;
+        }
     }
 #pragma unroll
     for (int u = 0; u < NR; u++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) rv[k][u] = (ridx[u] >= 0) ? R.p[(size_t)k * R.plane + ridx[u]] : 0.0f;
+        for (int k = 0; k < 3; k++) rv[k][u] = ldoff(R.p + (size_t)k * R.plane, (unsigned)ridx[u]);
+    UGSM_STAMP(18);
     constexpr int NA = (TX * TY + 511) / 512;
     float aq[3][NA], od[3][NA];  // A and the tile's own (dx,dy,conf), lanes along the rows (coalesced)
 #pragma unroll
@@ -476,11 +508,12 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
         const int it = tid + u * 512;
         const int r = it / TX, c = it - r * TX;
         const bool in = it < TX * TY && x0 + c < W && y0 + r < H;
-        const size_t at = in ? (size_t)(y0 + r) * W + x0 + c : 0;
+        const unsigned off = in ? ((unsigned)(y0 + r) * (unsigned)W + (unsigned)(x0 + c)) * 4u : 0u;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
-            aq[kk][u] = in ? A3[kk * n + at] : 1.0f;
-            od[kk][u] = in ? d3[kk * n + at] : 0.0f;
+            const float ta = ldoff(A3 + (size_t)kk * n, off), td = ldoff(d3 + (size_t)kk * n, off);
+            aq[kk][u] = in ? ta : 1.0f;
+            od[kk][u] = in ? td : 0.0f;
         }
     }
 
@@ -489,6 +522,7 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
     for (int s = 0; s < 3; s++)
 #pragma unroll
         for (int i = 0; i < 4; i++) Q[s][i] = 0.0f;
+    UGSM_STAMP(1);
 
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -510,6 +544,7 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
             }
         }
         __syncthreads();
+        UGSM_STAMP(2 + 4 * k);
 #pragma unroll
         for (int u = 0; u < NA; u++) {  // sA's readers (P3 of the previous channel) are behind the barrier above
             const int it = tid + u * 512;
@@ -579,6 +614,7 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
             }
         }
         __syncthreads();
+        UGSM_STAMP(3 + 4 * k);
         // ---- P2.5: column pass of R'^2 -> B on tile+halo1 (role 1) ------------------------------
         if (role == 1) {
             for (int it = t; it < SB_H * SB_Q; it += 256) {
@@ -592,6 +628,7 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
             }
         }
         __syncthreads();
+        UGSM_STAMP(4 + 4 * k);
         // ---- P3: column pass of the products, correlation, channel accumulate ---------------
         if (live) {
             const float *pb = &sB[(trow + 1) * SB_W + cx - 4 + SB_OX];
@@ -641,11 +678,13 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
                 accum(1, N, b);
             }
         }
+        UGSM_STAMP(5 + 4 * k);
     }
 
     // ---- epilogue: parabola x (role 0) / y (role 1) in the compute mapping, hand-over through LDS, then
     // update + blend + coalesced stores with lanes along the rows ---------------------------------------
     __syncthreads();  // every P3 is done with sRow: planes 0..3 become hand-over buffers
+    UGSM_STAMP(14);
     float *xq = &sRow[(0 * ROW_H + trow) * ROW_W + cx];
     if (role == 0 && live) st4(xq, Q[2]);  // Q(0,0) for the y parabola
     __syncthreads();
@@ -678,6 +717,40 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
             nd3[2 * n + at] = kap;
         }
     }
+    UGSM_STAMP(15);
+}
+
+// The value the neighbouring lane holds in `v` (DPP wave shifts; lane 0 / lane 63 keep their own value).
+__device__ __forceinline__ float lane_below(float v)  // from lane - 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_above(float v)  // from lane + 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// smoothKernel divides the three weighted sums of a pixel by the same sumCorr (MatchLib.cu:1131-1139).
+// Exact shortcut: one reciprocal in binary64, refined to <= 2^-53 relative error (two Newton steps from
+// v_rcp_f32), then q_f = RN32(RN64(a_f * r)).  The binary64 product is within 2^-51.4 (relative) of the
+// true quotient, and a quotient of two binary32 numbers is never closer than 2^-49 (relative) to a
+// binary32 rounding boundary (x/y - m = (X*2^k - M*Y)*2^(b+c)/y with X, Y < 2^24, M < 2^25 odd: a nonzero
+// integer over Y), so the final rounding equals that of the IEEE binary32 quotient, overflow and
+// subnormal results included.  16 VALU operations for three quotients instead of 36.  A quad with any
+// denominator outside [2^-64, 2^64] (zero, negative, NaN, Inf, tiny) redoes those pixels with the literal
+// division.  tests: test_smooth_division_*.
+__device__ __forceinline__ bool div3_shared_ok(const float s) { return s >= 0x1p-64f && s <= 0x1p64f; }
+__device__ __forceinline__ void div3_shared(const float a0, const float a1, const float a2, const float s, float &q0, float &q1, float &q2)
+{
+    const double sd = (double)s;
+    double r = (double)__builtin_amdgcn_rcpf(s);
+    double e = __builtin_fma(-sd, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-sd, r, 1.0);
+    r = __builtin_fma(e, r, r);
+    q0 = (float)((double)a0 * r);
+    q1 = (float)((double)a1 * r);
+    q2 = (float)((double)a2 * r);
 }
 
 // =========================================================================================
@@ -693,8 +766,11 @@ __global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float 
 // barrier, writes back, barrier.  A pass leaves global row 0 / column 0 untouched (ix>0 && iy>0
 // guard) and clamps x+1 / y+1 at the image edge.  Out-of-image LDS cells hold the clamped pixel;
 // they are refreshed once before the box so that its clamp addressing needs no index logic.
-template <int STX, int STY, int NT>
-__global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
+// VAR (development switches, tools/kbench.hip): bit 0 = literal per-plane division, bit 1 = select-free copy of
+// the pass for interior tiles, bit 2 = west/east neighbours from LDS instead of the neighbouring lanes.
+// Product: VAR = 0.
+template <int STX, int STY, int NT, int VAR = 0>
+__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
                                                   int tiles_x, int n_tiles)
 {
     constexpr int HX = 8, HY = 7;
@@ -702,7 +778,9 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
     constexpr int LW = RWID + 4;             // LDS row stride: +4 keeps rows 16-B aligned and off a 32-bank multiple
     constexpr int LH = STY + 2 * HY;
     constexpr int QW = RWID / 4;             // quad columns
-    constexpr int RG = NT / QW;              // row groups
+    constexpr int RPW = 64 / QW;             // whole region rows per wave: lane -> (row lane / QW, quad lane % QW), so
+                                             // that a quad's west / east neighbours sit in the neighbouring lanes
+    constexpr int RG = (NT / 64) * RPW;      // row groups
     constexpr int MAXR = (LH + RG - 1) / RG; // rows per thread per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *f0 = smem, *f1 = smem + LH * LW, *f2 = smem + 2 * LH * LW;
@@ -715,82 +793,154 @@ __global__ __launch_bounds__(NT) void k_smooth_fused(const float *__restrict__ s
     const size_t n = (size_t)W * H;
     const int h = P + (do_box ? 2 : 0);      // halo actually needed
 
-    // ---- load tile + needed halo (clamped onto the image) -----------------------------------
+    // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
+    // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
     {
         const int r_lo = HY - h, r_hi = LH - (HY - h);
-        for (int it = tid; it < LH * RWID; it += NT) {
+        constexpr int NLD = (LH * RWID + NT - 1) / NT;
+        float v[NLD][3];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
-                const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
-                const size_t at = (size_t)gy * W + gx;
-                f0[r * LW + c] = s3[at];
-                f1[r * LW + c] = s3[n + at];
-                f2[r * LW + c] = s3[2 * n + at];
+            const bool need = it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
+            const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
+            // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
+            // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
+            const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
+            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
+            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
+            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * NT;
+            const int r = it / RWID, c = it - r * RWID;
+            if (it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+                f0[r * LW + c] = v[u][0];
+                f1[r * LW + c] = v[u][1];
+                f2[r * LW + c] = v[u][2];
             }
         }
     }
     __syncthreads();
 
-    const int q = tid % QW, rg = tid / QW;
+    const int lane = tid & 63;
+    const int q = lane % QW, rg = (tid >> 6) * RPW + lane / QW;
     const int c0 = q * 4, gx0 = x0 + c0;
-    const bool lane_on = rg < RG;
+    const bool lane_on = lane < RPW * QW;
+
+    // VAR & 2: a tile whose whole LDS region lies strictly inside the image (no row 0 / column 0 pass-through, no
+    // clamped east / south neighbour) takes a copy of the pass without the per-pixel selects.  Measured: no
+    // faster (the selects are ~10 of ~50 issue slots per pixel, but the second copy costs 24 VGPRs) -- off.
+    const bool interior = (VAR & 2) && x0 >= 1 && y0 >= 1 && x0 + RWID <= W - 1 && y0 + LH <= H - 1;
 
     for (int p = 1; p <= P; p++) {
         // pass p is needed (and valid) on the region shrunk to halo h-p
         const int r_lo = HY - (h - p), r_hi = LH - (HY - (h - p));
         const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p)));
         float nv[MAXR][3][4];
+        // one quad-row: the five-point sums and the division from registers, results into nv[u].  LIT = literal
+        // division per plane; otherwise the shared-reciprocal form, and the return value says whether every
+        // denominator of the quad was in its range (if not, the row is simply redone with LIT).
+        auto quad_row = [&](const int u, const int gy, const float (&c4)[3][4], const float (&n4)[3][4], const float (&s4)[3][4],
+                            const float (&wl)[3], const float (&er)[3], auto edge_tag, auto lit_tag) -> bool {
+            constexpr bool EDGE = decltype(edge_tag)::value, LIT = decltype(lit_tag)::value;
+            const bool row_ok = gy > 0 && gy < H;
+            const bool south_in = gy + 1 <= H - 1;
+            bool ok = true;
 #pragma unroll
-        for (int u = 0; u < MAXR; u++) {
-            const int r = r_lo + rg + u * RG;
-            if (col_on && r < r_hi) {
-                const int gy = y0 + r;
-                const int at = r * LW + c0;
-                float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
-                ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
-                ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
-                ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
-                {   // west / east neighbours of the quad: whole-quad reads (a lane-strided ds_read_b32
-                    // here is a 4-way bank conflict: 65 % of LDS cycles in the first version)
-                    float t[4];
-                    ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
-                    ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
+            for (int i = 0; i < 4; i++) {
+                const int gx = gx0 + i;
+                const bool act = row_ok && gx > 0 && gx < W;
+                const bool east_in = gx + 1 <= W - 1;
+                float vw[3], ve[3], vs[3];
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    vw[f] = (i == 0) ? wl[f] : c4[f][i > 0 ? i - 1 : 0];
+                    const float e_raw = (i == 3) ? er[f] : c4[f][i < 3 ? i + 1 : 3];
+                    ve[f] = (!EDGE || east_in) ? e_raw : c4[f][i];
+                    vs[f] = (!EDGE || south_in) ? s4[f][i] : c4[f][i];
                 }
-                const bool row_ok = gy > 0 && gy < H;
-                const bool south_in = gy + 1 <= H - 1;
+                const float wc = c4[2][i], ww = vw[2], we = ve[2], wn = n4[2][i], ws = vs[2];
+                float sumCorr = 0.0f;
+                sumCorr = sumCorr + wc;
+                sumCorr = sumCorr + ww;
+                sumCorr = sumCorr + we;
+                sumCorr = sumCorr + wn;
+                sumCorr = sumCorr + ws;
+                float acc[3], qf[3];
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int gx = gx0 + i;
-                    const bool act = row_ok && gx > 0 && gx < W;
-                    const bool east_in = gx + 1 <= W - 1;
-                    float vw[3], ve[3], vs[3];
-#pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        vw[f] = (i == 0) ? wl[f] : c4[f][i > 0 ? i - 1 : 0];
-                        const float e_raw = (i == 3) ? er[f] : c4[f][i < 3 ? i + 1 : 3];
-                        ve[f] = east_in ? e_raw : c4[f][i];
-                        vs[f] = south_in ? s4[f][i] : c4[f][i];
-                    }
-                    const float wc = c4[2][i], ww = vw[2], we = ve[2], wn = n4[2][i], ws = vs[2];
-                    float sumCorr = 0.0f;
-                    sumCorr = sumCorr + wc;
-                    sumCorr = sumCorr + ww;
-                    sumCorr = sumCorr + we;
-                    sumCorr = sumCorr + wn;
-                    sumCorr = sumCorr + ws;
-#pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        float a = 0.0f;
-                        a = c4[f][i] * wc + a;
-                        a = vw[f] * ww + a;
-                        a = ve[f] * we + a;
-                        a = n4[f][i] * wn + a;
-                        a = vs[f] * ws + a;
-                        nv[u][f][i] = act ? a / sumCorr : c4[f][i];
-                    }
+                for (int f = 0; f < 3; f++) {
+                    float a = 0.0f;
+                    a = c4[f][i] * wc + a;
+                    a = vw[f] * ww + a;
+                    a = ve[f] * we + a;
+                    a = n4[f][i] * wn + a;
+                    a = vs[f] * ws + a;
+                    acc[f] = a;
                 }
+                if constexpr (LIT) {
+#pragma unroll
+                    for (int f = 0; f < 3; f++) qf[f] = acc[f] / sumCorr;
+                } else {
+                    div3_shared(acc[0], acc[1], acc[2], sumCorr, qf[0], qf[1], qf[2]);
+                    ok = ok && div3_shared_ok(sumCorr);
+                }
+#pragma unroll
+                for (int f = 0; f < 3; f++) nv[u][f][i] = (!EDGE || act) ? qf[f] : c4[f][i];
+                __builtin_amdgcn_sched_barrier(0);  // keep the binary64 temporaries of one pixel at a time
             }
-        }
+            return ok;
+        };
+        auto pass = [&](auto edge_tag) {
+#pragma unroll
+            for (int u = 0; u < MAXR; u++) {
+                const int r = r_lo + rg + u * RG;
+                if (lane_on && r < r_hi) {
+                    // every quad of the row loads (the neighbouring lanes' quads feed the west / east taps)
+                    const int at = r * LW + c0;
+                    float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
+                    ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
+                    ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
+                    ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
+                    if constexpr (VAR & 4) {
+                        float t[4];
+                        ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
+                        ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
+                    } else {
+                        // west / east neighbours from the neighbouring lanes' registers instead of LDS (a narrowed,
+                        // lane-strided ds_read_b32 there is a 4-way bank conflict).  At q = 0 / QW-1 the value comes
+                        // from another row: those are region-edge columns, never valid in any pass.
+#pragma unroll
+                        for (int f = 0; f < 3; f++) {
+                            wl[f] = lane_below(c4[f][3]);
+                            er[f] = lane_above(c4[f][0]);
+                        }
+                    }
+                    bool redo = false;
+                    if (col_on) {
+                        const int gy = y0 + r;
+                        if constexpr (VAR & 1) quad_row(u, gy, c4, n4, s4, wl, er, edge_tag, std::true_type{});
+                        else redo = !quad_row(u, gy, c4, n4, s4, wl, er, edge_tag, std::false_type{});
+                    }
+                    if (__builtin_expect(redo, 0)) {
+                        // rare: a denominator out of range.  Reload the row (so that nothing has to stay in registers
+                        // for this path; LDS still holds the previous pass) and divide literally.
+                        float c4r[3][4], n4r[3][4], s4r[3][4], wlr[3], err[3];
+                        ld4(f0 + at, c4r[0]); ld4(f1 + at, c4r[1]); ld4(f2 + at, c4r[2]);
+                        ld4(f0 + at - LW, n4r[0]); ld4(f1 + at - LW, n4r[1]); ld4(f2 + at - LW, n4r[2]);
+                        ld4(f0 + at + LW, s4r[0]); ld4(f1 + at + LW, s4r[1]); ld4(f2 + at + LW, s4r[2]);
+                        wlr[0] = f0[at - 1]; wlr[1] = f1[at - 1]; wlr[2] = f2[at - 1];
+                        err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
+                        quad_row(u, y0 + r, c4r, n4r, s4r, wlr, err, edge_tag, std::true_type{});
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
+            }
+        };
+        if (interior) pass(std::false_type{});
+        else pass(std::true_type{});
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < MAXR; u++) {
@@ -983,6 +1133,30 @@ void launch_poly_probe(hipStream_t st, const float *c, const float *l, const flo
     hipLaunchKernelGGL(k_poly_probe, dim3((n + 255) / 256), dim3(256), 0, st, c, l, r, thr, delta, corr, third, n);
 }
 
+// test hook (tests only): the shared-reciprocal division exactly as k_smooth_fused applies it (fast form,
+// range test, literal redo)
+__global__ void k_div3_probe(const float *__restrict__ a0, const float *__restrict__ a1, const float *__restrict__ a2, const float *__restrict__ s,
+                             float *__restrict__ q0, float *__restrict__ q1, float *__restrict__ q2, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float x, y, z;
+        div3_shared(a0[i], a1[i], a2[i], s[i], x, y, z);
+        if (!div3_shared_ok(s[i])) {
+            x = a0[i] / s[i];
+            y = a1[i] / s[i];
+            z = a2[i] / s[i];
+        }
+        q0[i] = x;
+        q1[i] = y;
+        q2[i] = z;
+    }
+}
+void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n)
+{
+    hipLaunchKernelGGL(k_div3_probe, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, a2, s, q0, q1, q2, n);
+}
+
 // ---- launchers ------------------------------------------------------------------------------
 
 void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend)
@@ -1019,7 +1193,7 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
     // overlaps the other's passes (measured 378 us vs 406 us for 128x64x1024 at 16 MP, 77 vs 94 at 2 MP);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (px >= ((size_t)1 << 19)) launch_smooth_t<64, 64, 512>(st, s3, o3, W, H, passes, do_box);
+    if (px >= ((size_t)1 << 19)) launch_smooth_t<64, 58, 512>(st, s3, o3, W, H, passes, do_box);
     else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }
@@ -1045,11 +1219,22 @@ __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__rest
     const int ox1 = min(ox0 + PTX, W2) - 1, oy1 = min(oy0 + PTY, H2) - 1;
     const int rx0 = tex_index(((float)ox0 + 0.5f) * sf, W) - 2, ry0 = tex_index(((float)oy0 + 0.5f) * sf, H) - 2;
     const int rw = tex_index(((float)ox1 + 0.5f) * sf, W) + 2 - rx0 + 1, rh = tex_index(((float)oy1 + 0.5f) * sf, H) + 2 - ry0 + 1;
-    for (int it = tid; it < rh * PRW; it += 256) {
-        const int r = it / PRW, c = it - r * PRW;
-        if (c < rw) {
+    {   // all of the thread's global loads first, then the LDS stores (a rolled loop pays one HBM round
+        // trip per 256 pixels of the region)
+        constexpr int NLD = (PRH * PRW + 255) / 256;
+        float v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * 256;
+            const int r = it / PRW, c = it - r * PRW;
             const int gx = rx0 + c, gy = ry0 + r;
-            sS[it] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * W + gx] : 0.0f;  // zero padding (U2/U3)
+            const bool in = r < rh && c < rw && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            v[u] = in ? src[(size_t)gy * W + gx] : 0.0f;  // zero padding (U2/U3)
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * 256;
+            if (it < rh * PRW) sS[it] = v[u];
         }
     }
     __syncthreads();
@@ -1088,10 +1273,20 @@ __global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, fl
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * PTX, y0 = blockIdx.y * PTY;
     const float *s = src.p + (size_t)blockIdx.z * src.plane;
-    for (int it = tid; it < RH * RW; it += 256) {
-        const int r = it / RW, c = it - r * RW;
-        const float v = s[(size_t)clampi(y0 + r - 2, 0, H - 1) * src.pitch + clampi(x0 + c - 2, 0, W - 1)];
-        sS[it] = v * v;
+    {
+        constexpr int NLD = (RH * RW + 255) / 256;
+        float v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = min(tid + u * 256, RH * RW - 1);
+            const int r = it / RW, c = it - r * RW;
+            v[u] = s[(size_t)clampi(y0 + r - 2, 0, H - 1) * src.pitch + clampi(x0 + c - 2, 0, W - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * 256;
+            if (it < RH * RW) sS[it] = v[u] * v[u];
+        }
     }
     __syncthreads();
     const int lx = tid & (PTX - 1);

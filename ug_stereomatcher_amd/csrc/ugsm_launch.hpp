@@ -41,6 +41,7 @@ void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
 // X, Y, Z planes from the full-resolution (dx, dy) and the two 3x4 projection matrices
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);
 // test hook: the fused kernels' exact shortcuts (parabola fast path, x/3) on arbitrary operands
+void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n);
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);
 
 }  // namespace ugsm

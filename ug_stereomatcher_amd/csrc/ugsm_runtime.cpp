@@ -812,6 +812,18 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
     return ugsm_wait(ctx, 0);
 }
 
+int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2, const float *d_s, float *d_q0, float *d_q1,
+                          float *d_q2, int n)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_a0 || !d_a1 || !d_a2 || !d_s || !d_q0 || !d_q1 || !d_q2 || n < 1) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    launch_div3_probe(s->st, d_a0, d_a1, d_a2, d_s, d_q0, d_q1, d_q2, n);
+    HIPCHK(ctx, hipGetLastError());
+    return ugsm_wait(ctx, 0);
+}
+
 // ---- instrumentation / memory helpers ---------------------------------------------------
 
 int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap)
