@@ -103,6 +103,13 @@ int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR,
                         int stride, int off_x, int off_y, float *stackH, float *stackV,
                         float *stackC, float *pyrL, float *pyrR);
 
+/* MatchGPULib::match(L, R, fov == 1) (MatchGPULib.cpp:354-360): foveated matching followed by
+ * hierarchicalDisparity (:2589-2701) -- one full-resolution (dx, dy, conf) field whose centre window comes from
+ * the fine fovea levels and whose periphery from the coarser ones.  Host buffers as ugsm_match_full.
+ * The reference node never takes this path (UG_GPU_matcher.cpp:421-423,644-645); SURVEY 8f row f-3. */
+int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
+                             int stride, int off_x, int off_y, float *outH, float *outV, float *outC);
+
 /* ---- throughput path: device buffers, asynchronous, one slot = one stream ------- */
 
 /* Same computation as ugsm_match_full on device-resident inputs/outputs.
@@ -137,6 +144,26 @@ int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int of
  * planes X, Y, Z.  Enqueued on `slot`'s stream (ordered after a submit on the same slot). */
 int ugsm_triangulate(ugsm_ctx *ctx, int slot, const float *d_dispx, const float *d_dispy, int W, int H,
                      const double *P1, const double *P2, float *d_xyz);
+
+/* Row f-1, foveated branch.  Where level `src_level` of the fovea stack sits in level `dest_level` of the
+ * full pyramid and the coordinate scale between them: CdynamicCalibration::left_marginOf_in /
+ * upper_marginOf_in / mapXcoord (src/pointcloud/getPointCloud.cpp:387-484).  Host only. */
+int ugsm_fovea_mapping(int W, int H, int src_level, int dest_level, int *left_margin, int *upper_margin,
+                       float *scale);
+/* get3DPoint with foveated == 1 (getPointCloud.cpp:892-903) for every pixel of level `src_level` of the
+ * (F*fovH) x fovW device stacks d_stackx / d_stacky (the layout ugsm_match_foveated returns);
+ * d_xyz: X, Y, Z planes of fovH x fovW floats.  Asynchronous on `slot`, like ugsm_triangulate. */
+int ugsm_triangulate_fovea(ugsm_ctx *ctx, int slot, const float *d_stackx, const float *d_stacky, int fovW,
+                           int fovH, int src_level, int left_margin, int upper_margin, float scale,
+                           const double *P1, const double *P2, float *d_xyz);
+
+/* Row f-3: MatchGPULib::hierarchicalDisparity (MatchGPULib.cpp:2589-2701, kernel MatchLib.cu:435-462):
+ * one full-resolution (dx, dy, conf) field from the foveated stacks -- the coarsest fovea level (the whole
+ * frame) upsampled level by level (x SCALE, every channel), each finer fovea pasted at its window.
+ * d_stackH/V/C: device, (fovea_levels*fovH) x fovW each; d_out3: device, 3 planes W x H.
+ * off_x/off_y as passed to ugsm_match_foveated.  Asynchronous on `slot`; ugsm_wait(ctx, slot) to finish. */
+int ugsm_reconstruct_full(ugsm_ctx *ctx, int slot, const float *d_stackH, const float *d_stackV,
+                          const float *d_stackC, int W, int H, int off_x, int off_y, float *d_out3);
 
 /* ---- stage-level entry points (tests only; device pointers; synchronous) -------- */
 

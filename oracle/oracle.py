@@ -242,3 +242,34 @@ def triangulate(dispx: np.ndarray, dispy: np.ndarray, P1: np.ndarray, P2: np.nda
     lib().orc_triangulate(_fp(np.ascontiguousarray(dispx)), _fp(np.ascontiguousarray(dispy)), W, H,
                           p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), _fp(out))
     return out
+
+
+def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):
+    """getPointCloud.cpp:387-484 -> (left_margin, upper_margin, scale)."""
+    l, u, sc = C.c_int(), C.c_int(), C.c_float()
+    rc = lib().orc_fovea_mapping(W, H, src_level, dest_level, C.byref(l), C.byref(u), C.byref(sc))
+    if rc:
+        raise ValueError("level out of range")
+    return l.value, u.value, np.float32(sc.value)
+
+
+def triangulate_fovea(stackx: np.ndarray, stacky: np.ndarray, src_level: int, left: int, upper: int, scale, P1, P2) -> np.ndarray:
+    """get3DPoint, foveated branch, for level src_level of (F, fovH, fovW) stacks -> (3, fovH, fovW)."""
+    F, fh, fw = stackx.shape
+    out = np.empty((3, fh, fw), np.float32)
+    p1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+    p2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+    dp = C.POINTER(C.c_double)
+    lib().orc_triangulate_fovea(_fp(np.ascontiguousarray(stackx)), _fp(np.ascontiguousarray(stacky)), fw, fh, int(src_level),
+                                int(left), int(upper), C.c_float(float(scale)), p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), _fp(out))
+    return out
+
+
+def reconstruct_full(stack3: np.ndarray, W: int, H: int, levels: int = 14, off_x: int = 0, off_y: int = 0) -> np.ndarray:
+    """hierarchicalDisparity (MatchGPULib.cpp:2589-2701): (3, F, fovH, fovW) stack -> (3, H, W)."""
+    _, F, fh, fw = stack3.shape
+    out = np.empty((3, H, W), np.float32)
+    rc = lib().orc_reconstruct_full(_fp(np.ascontiguousarray(stack3)), W, H, levels, F, off_x, off_y, _fp(out))
+    if rc:
+        raise RuntimeError(f"orc_reconstruct_full rc={rc}")
+    return out

@@ -705,6 +705,41 @@ int orc_match_foveated(const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, i
  * No contraction (host code built without -mfma). out: X, Y, Z planes. */
 static inline double sq_d(float v) { return (double)v * (double)v; }
 
+/* The closed form of get3DPoint (getPointCloud.cpp:908-948) for one left/right correspondence. */
+static inline void tri_point(float x1, float y1, float x2, float y2, const double *P1, const double *P2, float *X, float *Y, float *Z)
+{
+    float a, b, c, d, e, f, g, h, i, j, x, y;
+    a = (float)P1[0];
+    b = (float)(P1[2] - x1);
+    c = (float)P1[5];
+    d = (float)(P1[6] - y1);
+    e = (float)(P2[0] - x2 * P2[8]);
+    f = (float)(P2[1] - x2 * P2[9]);
+    g = (float)(P2[2] - x2 * P2[10]);
+    h = (float)(P2[4] - y2 * P2[8]);
+    i = (float)(P2[5] - y2 * P2[9]);
+    j = (float)(P2[6] - y2 * P2[10]);
+    x = (float)(x2 * P2[11] - P2[3]);
+    y = (float)(y2 * P2[11] - P2[7]);
+    float XUp = (d*f*h - c*g*h - d*e*i + c*e*j)*(-(d*i*x) + c*j*x + d*f*y - c*g*y) +
+                sq_d(b)*((f*h - e*i)*(-(i*x) + f*y) + sq_d(c)*(e*x + h*y)) +
+                a*b*((-(g*i) + f*j)*(i*x - f*y) + c*d*(f*x + i*y) - sq_d(c)*(g*x + j*y));
+    float YUp = (sq_d(b)*(f*h - e*i) + d*(d*f*h - c*g*h - d*e*i + c*e*j))*(h*x - e*y) +
+                a*b*((c*d*e + g*h*i - 2.0*f*h*j + e*i*j)*x + (c*d*h + f*g*h - 2.0*e*g*i + e*f*j)*y) +
+                sq_d(a)*((g*i - f*j)*(-(j*x) + g*y) + sq_d(d)*(f*x + i*y) - c*d*(g*x + j*y));
+    float ZUp = c*(-(d*f*h) + c*g*h + d*e*i - c*e*j)*(h*x - e*y) - a*b*((f*h - e*i)*(-(i*x) + f*y) +
+                sq_d(c)*(e*x + h*y)) + sq_d(a)*((g*i - f*j)*(i*x - f*y) - c*d*(f*x + i*y) +
+                sq_d(c)*(g*x + j*y));
+    float divisor = sq_d(b)*(sq_d(c)*(sq_d(e) + sq_d(h)) + sq_d(f*h - e*i)) +
+                    sq_d(d*f*h - c*g*h - d*e*i + c*e*j) - 2.0*a*b*(-(c*d*(e*f + h*i)) +
+                    (f*h - e*i)*(-(g*i) + f*j) + sq_d(c)*(e*g + h*j)) + sq_d(a)*
+                    (sq_d(d)*(sq_d(f) + sq_d(i)) + sq_d(g*i - f*j) - 2.0*c*d*(f*g + i*j) +
+                    sq_d(c)*(sq_d(g) + sq_d(j)));
+    *X = XUp / divisor;
+    *Y = YUp / divisor;
+    *Z = ZUp / divisor;
+}
+
 void orc_triangulate(const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz)
 {
     const size_t n = (size_t)W * H;
@@ -718,36 +753,99 @@ void orc_triangulate(const float *dispx, const float *dispy, int W, int H, const
             y1 = yy;
             x2 = xx + dispx[at];
             y2 = yy + dispy[at];
-            float a, b, c, d, e, f, g, h, i, j, x, y;
-            a = (float)P1[0];
-            b = (float)(P1[2] - x1);
-            c = (float)P1[5];
-            d = (float)(P1[6] - y1);
-            e = (float)(P2[0] - x2 * P2[8]);
-            f = (float)(P2[1] - x2 * P2[9]);
-            g = (float)(P2[2] - x2 * P2[10]);
-            h = (float)(P2[4] - y2 * P2[8]);
-            i = (float)(P2[5] - y2 * P2[9]);
-            j = (float)(P2[6] - y2 * P2[10]);
-            x = (float)(x2 * P2[11] - P2[3]);
-            y = (float)(y2 * P2[11] - P2[7]);
-            float XUp = (d*f*h - c*g*h - d*e*i + c*e*j)*(-(d*i*x) + c*j*x + d*f*y - c*g*y) +
-                        sq_d(b)*((f*h - e*i)*(-(i*x) + f*y) + sq_d(c)*(e*x + h*y)) +
-                        a*b*((-(g*i) + f*j)*(i*x - f*y) + c*d*(f*x + i*y) - sq_d(c)*(g*x + j*y));
-            float YUp = (sq_d(b)*(f*h - e*i) + d*(d*f*h - c*g*h - d*e*i + c*e*j))*(h*x - e*y) +
-                        a*b*((c*d*e + g*h*i - 2.0*f*h*j + e*i*j)*x + (c*d*h + f*g*h - 2.0*e*g*i + e*f*j)*y) +
-                        sq_d(a)*((g*i - f*j)*(-(j*x) + g*y) + sq_d(d)*(f*x + i*y) - c*d*(g*x + j*y));
-            float ZUp = c*(-(d*f*h) + c*g*h + d*e*i - c*e*j)*(h*x - e*y) - a*b*((f*h - e*i)*(-(i*x) + f*y) +
-                        sq_d(c)*(e*x + h*y)) + sq_d(a)*((g*i - f*j)*(i*x - f*y) - c*d*(f*x + i*y) +
-                        sq_d(c)*(g*x + j*y));
-            float divisor = sq_d(b)*(sq_d(c)*(sq_d(e) + sq_d(h)) + sq_d(f*h - e*i)) +
-                            sq_d(d*f*h - c*g*h - d*e*i + c*e*j) - 2.0*a*b*(-(c*d*(e*f + h*i)) +
-                            (f*h - e*i)*(-(g*i) + f*j) + sq_d(c)*(e*g + h*j)) + sq_d(a)*
-                            (sq_d(d)*(sq_d(f) + sq_d(i)) + sq_d(g*i - f*j) - 2.0*c*d*(f*g + i*j) +
-                            sq_d(c)*(sq_d(g) + sq_d(j)));
-            xyz[at] = XUp / divisor;
-            xyz[n + at] = YUp / divisor;
-            xyz[2 * n + at] = ZUp / divisor;
+            tri_point(x1, y1, x2, y2, P1, P2, &xyz[at], &xyz[n + at], &xyz[2 * n + at]);
         }
     }
+}
+
+/* getPointCloud.cpp:387-484: where level `src_level` of the fovea stack sits in level `dest_level` of the
+ * full pyramid (left_marginOf_in / upper_marginOf_in) and the coordinate scale of mapXcoord / mapYcoord
+ * (pow(float, float) on the float-rounded M_SQRT2 / M_SQRT1_2). */
+int orc_fovea_mapping(int W, int H, int src_level, int dest_level, int *left_margin, int *upper_margin, float *scale)
+{
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    int scaled = 6 - src_level;
+    if (src_level < dest_level) scaled = src_level + dest_level;
+    if (scaled < 0 || scaled >= 15 || dest_level < 0 || dest_level >= 15) return -1;
+    w[0] = W;
+    h[0] = H;
+    for (int i = 0; i < 14; i++) {
+        w[i + 1] = (int)(w[i] / 1.41421356);
+        h[i + 1] = (int)(h[i] / 1.41421356);
+    }
+    *left_margin = w[dest_level] / 2 - w[scaled] / 2;
+    *upper_margin = h[dest_level] / 2 - h[scaled] / 2;
+    float root = (src_level < dest_level) ? (float)0.70710678118654752440 : (float)1.41421356237309504880;
+    *scale = powf(root, (float)abs(src_level - dest_level));
+    return 0;
+}
+
+/* get3DPoint, foveated branch (getPointCloud.cpp:892-903) for every pixel of level `src_level` of the
+ * (F*fovH) x fovW disparity stacks.  mapXcoord / mapYcoord take an int: the right-image coordinate
+ * xx + disparity is truncated toward zero before it is scaled (as in the reference). */
+void orc_triangulate_fovea(const float *stackx, const float *stacky, int fovW, int fovH, int src_level, int left_margin,
+                           int upper_margin, float scale, const double *P1, const double *P2, float *xyz)
+{
+    const size_t n = (size_t)fovW * fovH;
+    pick_threads(n);
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < fovH; yy++) {
+        for (int xx = 0; xx < fovW; xx++) {
+            const size_t at = (size_t)yy * fovW + xx;
+            const size_t sat = ((size_t)yy + (size_t)fovH * src_level) * fovW + xx;
+            const float x1 = (float)left_margin + (float)xx * scale;
+            const float y1 = (float)upper_margin + (float)yy * scale;
+            const int sx = (int)(xx + stackx[sat]);
+            const int sy = (int)(yy + stacky[sat]);
+            const float x2 = (float)left_margin + (float)sx * scale;
+            const float y2 = (float)upper_margin + (float)sy * scale;
+            tri_point(x1, y1, x2, y2, P1, P2, &xyz[at], &xyz[n + at], &xyz[2 * n + at]);
+        }
+    }
+}
+
+/* hierarchicalDisparity (MatchGPULib.cpp:2589-2701) + partsubsampleDispKernel (MatchLib.cu:435-462):
+ * full-frame field from the foveated stack.  Level F-1 (whole frame at w[F-1] x h[F-1]) is upsampled level by
+ * level, out[x,y] = s * in[tex((x+.5)/s), tex((y+.5)/s)] with s = (float)SCALE applied to every channel, and the
+ * fovea of the finer level is pasted at its crop origin.  stack3: 3 planes of F x fovH x fovW (level 0 first). */
+int orc_reconstruct_full(const float *stack3, int W, int H, int levels, int F, int off_x, int off_y, float *out3)
+{
+    int w[ORC_MAX_LEVELS], h[ORC_MAX_LEVELS];
+    if (orc_level_dims(W, H, levels, w, h)) return -1;
+    if (F < 1 || F > levels) return -1;
+    int fovW, fovH, ox[ORC_MAX_LEVELS], oy[ORC_MAX_LEVELS], cx[ORC_MAX_LEVELS], cy[ORC_MAX_LEVELS];
+    orc_fovea_geometry(W, H, levels, F, off_x, off_y, &fovW, &fovH, ox, oy, cx, cy);
+    const size_t fl = (size_t)fovW * fovH;
+    const float s = (float)1.41421356;
+    float *cur = (float *)malloc(3 * fl * sizeof(float));
+    for (int c = 0; c < 3; c++) memcpy(cur + c * fl, stack3 + ((size_t)c * F + (F - 1)) * fl, fl * sizeof(float));
+    int cw = w[F - 1], ch = h[F - 1];
+    for (int level = F - 1; level > 0; level--) {
+        const int nw = w[level - 1], nh = h[level - 1];
+        float *nxt = (level == 1) ? out3 : (float *)malloc(3 * (size_t)nw * nh * sizeof(float));
+        pick_threads((size_t)nw * nh);
+        for (int c = 0; c < 3; c++) {
+            const float *src = cur + (size_t)c * cw * ch;
+            const float *fov = stack3 + ((size_t)c * F + (level - 1)) * fl;
+            float *dst = nxt + (size_t)c * nw * nh;
+#pragma omp parallel for schedule(static)
+            for (int iy = 0; iy < nh; iy++) {
+                const int ty = tex_index(((float)iy + 0.5f) / s, ch);
+                for (int ix = 0; ix < nw; ix++) {
+                    const int fx = ix - ox[level - 1], fy = iy - oy[level - 1];
+                    if (fx >= 0 && fx < fovW && fy >= 0 && fy < fovH) dst[(size_t)iy * nw + ix] = fov[(size_t)fy * fovW + fx];
+                    else dst[(size_t)iy * nw + ix] = s * src[(size_t)ty * cw + tex_index(((float)ix + 0.5f) / s, cw)];
+                }
+            }
+        }
+        free(cur);
+        cur = nxt;
+        cw = nw;
+        ch = nh;
+    }
+    if (F == 1) {
+        memcpy(out3, cur, 3 * fl * sizeof(float));
+        free(cur);
+    }
+    return 0;
 }

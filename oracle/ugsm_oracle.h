@@ -102,6 +102,14 @@ void orc_fovea_geometry(int W, int H, int levels, int F, int off_x, int off_y,
  * xyz: X, Y, Z planes of W*H floats. */
 void orc_triangulate(const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);
 
+/* getPointCloud.cpp:431-484 (margins) and :387-421 (scale of mapXcoord / mapYcoord). Returns 0 or -1. */
+int orc_fovea_mapping(int W, int H, int src_level, int dest_level, int *left_margin, int *upper_margin, float *scale);
+/* getPointCloud.cpp:892-903 + the closed form: level src_level of the (F*fovH) x fovW stacks -> X, Y, Z planes fovH x fovW */
+void orc_triangulate_fovea(const float *stackx, const float *stacky, int fovW, int fovH, int src_level, int left_margin,
+                           int upper_margin, float scale, const double *P1, const double *P2, float *xyz);
+/* SURVEY 8f row f-3 -- MatchGPULib.cpp:2589-2701 + MatchLib.cu:435-462.  stack3: 3 x F x fovH x fovW; out3: 3 x H x W. */
+int orc_reconstruct_full(const float *stack3, int W, int H, int levels, int F, int off_x, int off_y, float *out3);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -58,11 +58,12 @@ public:
     float **match(ImgPtr L, ImgPtr R, int fov)
     {
         foveatedmatching = fov;
-        if (fov == 1) return nullptr;  // hierarchicalDisparity: unreachable from the node, out of scope
         const int W = L->image.cols, H = L->image.rows;
         if (R->image.cols != W || R->image.rows != H) return nullptr;
         float **fin = alloc_planes(3, (size_t)W * H);
-        const int st = ugsm_match_full(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, fin[0], fin[1], fin[2]);
+        // fov == 1: foveated matching + hierarchicalDisparity (MatchGPULib.cpp:354-360)
+        const int st = fov == 1 ? ugsm_match_foveated_full(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, 0, 0, fin[0], fin[1], fin[2])
+                                : ugsm_match_full(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, fin[0], fin[1], fin[2]);
         if (st != UGSM_OK) return fail(fin, 3, st);
         return fin;
     }
@@ -75,6 +76,32 @@ public:
     // UG_GPU_matcher.cpp:169-179; levels < foveatelevel are filled.
     template <class ImgPtr>
     float ***matchStackPyramid(ImgPtr L, ImgPtr R, float ***leftFov, float ***rightFov) { return stack(L, R, leftFov, rightFov); }
+
+    // MatchGPULib.cpp:2589-2701.  foveated[level][channel] = fovW*fovH floats for level < foveatelevel (what
+    // matchStack returns); `im` is unused, as in the reference.  Returns 3 malloc'd planes widthInit*heightInit.
+    float **hierarchicalDisparity(float ** /*im*/, float ***foveated, int channels, int widthInit, int heightInit)
+    {
+        if (channels != 3 || !foveated) return nullptr;
+        const int F = foveatelevel;
+        if (ugsm_fovea_dims(widthInit, heightInit, 14, F, &fovW, &fovH) != UGSM_OK) return nullptr;
+        const size_t fn = (size_t)fovW * fovH, sn = fn * F, n = (size_t)widthInit * heightInit;
+        void *d_stack = nullptr, *d_out = nullptr;
+        float **fin = alloc_planes(3, n);
+        int st = ugsm_dev_alloc(ctx_, &d_stack, (long long)(3 * sn * sizeof(float)));
+        if (st == UGSM_OK) st = ugsm_dev_alloc(ctx_, &d_out, (long long)(3 * n * sizeof(float)));
+        for (int c = 0; c < 3 && st == UGSM_OK; c++)
+            for (int k = 0; k < F && st == UGSM_OK; k++)
+                st = ugsm_copy_to_device(ctx_, (float *)d_stack + c * sn + k * fn, foveated[k][c], (long long)(fn * sizeof(float)));
+        if (st == UGSM_OK)
+            st = ugsm_reconstruct_full(ctx_, 0, (float *)d_stack, (float *)d_stack + sn, (float *)d_stack + 2 * sn, widthInit, heightInit, 0, 0,
+                                       (float *)d_out);
+        if (st == UGSM_OK) st = ugsm_wait(ctx_, 0);
+        for (int c = 0; c < 3 && st == UGSM_OK; c++) st = ugsm_copy_to_host(ctx_, fin[c], (float *)d_out + c * n, (long long)(n * sizeof(float)));
+        if (d_stack) ugsm_dev_free(ctx_, d_stack);
+        if (d_out) ugsm_dev_free(ctx_, d_out);
+        if (st != UGSM_OK) return fail(fin, 3, st);
+        return fin;
+    }
 
 private:
     ugsm_ctx *ctx_;

@@ -29,6 +29,17 @@ int main(int argc, char **argv)
         float ***st = m.matchStack(L, R);
         if (!st) return 2;
         std::printf("stack[0][0][centre] = %f\n", st[0][0][(m.getFoveaHeight() / 2) * m.getFoveaWidth() + m.getFoveaWidth() / 2]);
+        // match(L, R, 1) == matchStack + hierarchicalDisparity (MatchGPULib.cpp:354-360)
+        float **full = m.hierarchicalDisparity(nullptr, st, 3, W, H);
+        float **one = m.match(L, R, 1);
+        if (!full || !one) return 3;
+        size_t diff = 0;
+        for (int c = 0; c < 3; c++) diff += std::memcmp(full[c], one[c], sizeof(float) * W * H) != 0;
+        std::printf("hierarchicalDisparity vs match(fov=1): %s, dx[centre] = %f, dx[corner] = %f\n", diff ? "DIFFER" : "identical",
+                    full[0][(H / 2) * W + W / 2], full[0][0]);
+        for (int c = 0; c < 3; c++) { free(full[c]); free(one[c]); }
+        free(full);
+        free(one);
         for (int k = 0; k < m.getFoveateLevel(); k++) { for (int i = 0; i < 3; i++) free(st[k][i]); free(st[k]); }
         free(st);
     } catch (const std::exception &e) {

@@ -94,3 +94,12 @@ def test_product_does_not_import_the_oracle():
                 assert "ugsm_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
     for f in os.listdir(os.path.join(ROOT, "include")):
         assert "oracle" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+def test_fovea_mapping_matches_oracle(orc):
+    from ug_stereomatcher_amd import _lib
+    for (W, H) in [(4928, 3264), (1920, 1080), (640, 480), (333, 217)]:
+        for src in range(0, 7):
+            assert _lib.fovea_mapping(W, H, src) == orc.fovea_mapping(W, H, src)
+        for dest in (1, 3):
+            assert _lib.fovea_mapping(W, H, 0, dest) == orc.fovea_mapping(W, H, 0, dest)

@@ -424,6 +424,7 @@ def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fovea 159x119 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout
+    assert "hierarchicalDisparity vs match(fov=1): identical" in out.stdout, out.stdout
 
 
 def test_exact_shortcuts_of_the_fused_kernels(lib, orc):
@@ -591,3 +592,90 @@ def test_foveated_odd_size_and_offsets(lib, ctx, orc):
             assert_bit_equal(st.transpose(1, 0, 2, 3), exp, f"fovea offset {off}")
     finally:
         m.close()
+
+
+def test_fovea_triangulation_matches_oracle(lib, orc):
+    """Row f-1, foveated branch: X, Y, Z for each level of a foveated result, mapped into the full-resolution
+    frame as CdynamicCalibration does (getPointCloud.cpp:387-484, 892-903), bit-exact."""
+    from ug_stereomatcher_amd import _lib
+    rng = np.random.Generator(np.random.PCG64(14))
+    W, H = 4928, 3264
+    P1 = np.array([[7.3230899280915291e+03, 0., 2.4836974544986647e+03, 0.],
+                   [0., 7.3035803715514758e+03, 1.7170248033347561e+03, 0.], [0., 0., 1., 0.]])
+    P2 = P1.copy()
+    P2[0, 3] = -7.3230899280915291e+03 * 0.12
+    F, fh, fw = 7, 407, 615
+    sx = rng.normal(-40, 25, (F, fh, fw)).astype(np.float32)
+    sy = rng.normal(0, 2, (F, fh, fw)).astype(np.float32)
+    ctx = lib.Context(levels=14)
+    try:
+        px, py = ctx.to_device(sx), ctx.to_device(sy)
+        pout = ctx.alloc(3 * fh * fw * 4)
+        for src in (0, 3, 6):
+            left, upper, scale = _lib.fovea_mapping(W, H, src)
+            assert (left, upper, scale) == orc.fovea_mapping(W, H, src)
+            exp = orc.triangulate_fovea(sx, sy, src, left, upper, scale, P1, P2)
+            ctx.triangulate_fovea(px, py, fw, fh, src, left, upper, scale, P1, P2, pout)
+            got = ctx.to_host(pout, (3, fh, fw))
+            assert_bit_equal(got, exp, f"fovea triangulation, level {src}")
+        for p in (px, py, pout):
+            ctx.free(p)
+    finally:
+        ctx.close()
+
+
+def test_reconstruct_full_matches_oracle(lib, orc):
+    """Row f-3: hierarchicalDisparity on the device against its restatement: random stacks at several sizes and
+    window offsets, and the stacks of a real foveated match."""
+    rng = np.random.Generator(np.random.PCG64(15))
+    for (W, H, levels, F, off) in [(400, 300, 9, 4, (0, 0)), (517, 389, 10, 5, (60, -40)), (640, 480, 10, 2, (0, 0)),
+                                   (320, 240, 8, 1, (0, 0)), (700, 500, 10, 4, (-1000, 1000))]:
+        fw, fh, *_ = orc.fovea_geometry(W, H, levels, F, *off)
+        stack = rng.normal(0, 5, (3, F, fh, fw)).astype(np.float32)
+        exp = orc.reconstruct_full(stack, W, H, levels, *off)
+        ctx = lib.Context(levels=levels, fovea_levels=F)
+        try:
+            ps = [ctx.to_device(stack[c]) for c in range(3)]
+            pout = ctx.alloc(3 * W * H * 4)
+            ctx.reconstruct_full(ps[0], ps[1], ps[2], W, H, pout, *off)
+            got = ctx.to_host(pout, (3, H, W))
+            for p in ps + [pout]:
+                ctx.free(p)
+        finally:
+            ctx.close()
+        assert_bit_equal(got, exp, f"reconstruct {W}x{H} F={F} off={off}")
+    # after a real foveated match, on the same slot
+    from ug_stereomatcher_amd import MatchGPULib, synth
+    L, R, *_ = synth.make_pair(320, 240, seed=5)
+    m = MatchGPULib(3, ["node", "-device=0", "4"], levels=9)
+    try:
+        stk = m.matchStack(L, R)                      # (F, 3, fovH, fovW)
+        st3 = np.ascontiguousarray(np.transpose(stk, (1, 0, 2, 3)))
+        exp = orc.reconstruct_full(st3, 320, 240, 9)
+        ctx = m._ctx
+        ps = [ctx.to_device(st3[c]) for c in range(3)]
+        pout = ctx.alloc(3 * 320 * 240 * 4)
+        ctx.reconstruct_full(ps[0], ps[1], ps[2], 320, 240, pout)
+        got = ctx.to_host(pout, (3, 240, 320))
+        assert_bit_equal(got, exp, "reconstruct after matchStack")
+        assert np.isfinite(got).all()
+    finally:
+        m.close()
+
+
+def test_match_fov1_is_stack_plus_hierarchical(lib, orc):
+    """MatchGPULib::match(L, R, 1) (MatchGPULib.cpp:354-360) = foveated matching + hierarchicalDisparity: equal to the
+    oracle's foveated match run through the oracle's reconstruction, and to the mirror's own two-step route."""
+    from ug_stereomatcher_amd import MatchGPULib, synth
+    L, R, *_ = synth.make_pair(400, 300, seed=9)
+    m = MatchGPULib(3, ["node", "-device=0", "4"], levels=9)
+    try:
+        got = m.match(L, R, 1)
+        stk = m.matchStack(L, R)
+        two = m.hierarchicalDisparity(stk, 400, 300)
+    finally:
+        m.close()
+    est, _, _ = orc.match_foveated(L, R, 9, 4)
+    exp = orc.reconstruct_full(est, 400, 300, 9)
+    assert_bit_equal(got, exp, "match(fov=1) vs oracle")
+    assert_bit_equal(two, got, "matchStack + hierarchicalDisparity vs match(fov=1)")

@@ -220,3 +220,60 @@ def test_triangulation_rectified_rig(orc):
     assert np.abs(xyz[2] - Z).max() < 1e-3
     assert np.abs(xyz[0] - (xs - cx) * Z / f).max() < 1e-3
     assert np.abs(xyz[1] - (ys - cy) * Z / f).max() < 1e-3
+
+
+def test_fovea_mapping_known_answers(orc):
+    """getPointCloud.cpp:431-484 at 16 MP: level 0 of the fovea stack is the 615x407 centre crop of the full
+    frame (Appendix B), level k covers width[6-k] x height[6-k] full-resolution pixels; scale = sqrt2^k."""
+    l, u, sc = orc.fovea_mapping(4928, 3264, 0)
+    assert (l, u) == (4928 // 2 - 615 // 2, 3264 // 2 - 407 // 2) == (2157, 1429)
+    assert sc == np.float32(1.0)
+    w, h = orc.level_dims(4928, 3264, 14)
+    for k in range(1, 7):
+        l, u, sc = orc.fovea_mapping(4928, 3264, k)
+        assert (l, u) == (w[0] // 2 - w[6 - k] // 2, h[0] // 2 - h[6 - k] // 2)
+        assert abs(float(sc) - 2.0 ** (k / 2)) < 2e-6 * 2.0 ** (k / 2)
+    l, u, sc = orc.fovea_mapping(4928, 3264, 6)
+    assert (l, u) == (0, 0)     # the coarsest fovea level is the whole frame
+
+
+def test_fovea_triangulation_reduces_to_full_res_formula(orc):
+    """With scale 1 and zero margins the foveated branch differs from the full-resolution one only by the
+    int truncation of the right-image coordinate (mapXcoord takes an int)."""
+    rng = np.random.Generator(np.random.PCG64(12))
+    P1 = np.array([[700.0, 0, 320, 0], [0, 700, 240, 0], [0, 0, 1, 0]])
+    P2 = np.array([[700.0, 0, 320, -84], [0, 700, 240, 0], [0, 0, 1, 0]])
+    F, fh, fw = 3, 20, 31
+    sx = rng.normal(-12, 4, (F, fh, fw)).astype(np.float32)
+    sy = rng.normal(0, 1, (F, fh, fw)).astype(np.float32)
+    lev = 1
+    got = orc.triangulate_fovea(sx, sy, lev, 0, 0, 1.0, P1, P2)
+    xx, yy = np.meshgrid(np.arange(fw, dtype=np.float32), np.arange(fh, dtype=np.float32))
+    tx = np.trunc(xx + sx[lev]).astype(np.float32) - xx
+    ty = np.trunc(yy + sy[lev]).astype(np.float32) - yy
+    exp = orc.triangulate(tx.astype(np.float32), ty.astype(np.float32), P1, P2)
+    np.testing.assert_array_equal(got, exp)
+    # rectified rig, no vertical disparity: Z = f*B/d with B = 84/700
+    got0 = orc.triangulate_fovea(sx, np.zeros_like(sy), lev, 0, 0, 1.0, P1, P2)
+    ok = tx < -0.5
+    np.testing.assert_allclose(got0[2][ok], (700.0 * 0.12 / -tx)[ok], rtol=1e-2)   # binary32 closed form
+
+
+def test_reconstruct_full_known_answers(orc):
+    """hierarchicalDisparity: constant coarse level c with zero finer foveae -> outside every window the value is
+    c * f32(sqrt2)^k after k upsamplings, inside the level-0 window it is the level-0 fovea."""
+    W, H, levels, F = 400, 300, 9, 4
+    fw, fh, ox, oy, _, _ = orc.fovea_geometry(W, H, levels, F)
+    stack = np.zeros((3, F, fh, fw), np.float32)
+    stack[:, F - 1] = 1.0
+    for k in range(F - 1):
+        stack[:, k] = 10.0 + k
+    out = orc.reconstruct_full(stack, W, H, levels)
+    s = np.float32(1.41421356)
+    corner = np.float32(1.0)
+    for _ in range(F - 1):
+        corner = np.float32(s * corner)
+    assert out[0, 0, 0] == corner and out[2, H - 1, W - 1] == corner
+    assert (out[:, oy[0]:oy[0] + fh, ox[0]:ox[0] + fw] == 10.0).all()
+    # ring of level-1 fovea (value 11) upsampled once, just outside the level-0 window
+    assert out[1, oy[0] - 1, ox[0] + fw // 2] == np.float32(s * np.float32(11.0))

@@ -43,6 +43,7 @@ int main(int argc, char **argv)
 #define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
         COST(0); SPLIT(0);
+        timeit("k_cost_split<0, 6 waves>", [&]() { hipLaunchKernelGGL((k_cost_split<0, 6>), dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); });
     }
     {   // phase stamps of k_cost_split<256>
         const int nb = std::min(cnt, 8192);

@@ -28,8 +28,8 @@ EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
     "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_match_full",
-    "ugsm_match_foveated", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
-    "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_stage_pyramid",
+    "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
+    "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_get_kernel_stats",
     "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
@@ -83,6 +83,7 @@ def load():
     lib.ugsm_pixel_iterations.restype = C.c_longlong
     lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_match_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
+    lib.ugsm_match_foveated_full.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp]
     lib.ugsm_submit_full.argtypes = [vp, i, vp, vp, i, i, i, vp]
     lib.ugsm_submit_foveated.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, vp, vp]
     lib.ugsm_wait.argtypes = [vp, i]
@@ -91,6 +92,9 @@ def load():
     lib.ugsm_submit_fovea_coarse.argtypes = [vp, i, vp]
     lib.ugsm_submit_fovea_fine.argtypes = [vp, i, vp, i, i, vp]
     lib.ugsm_triangulate.argtypes = [vp, i, vp, vp, i, i, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    lib.ugsm_fovea_mapping.argtypes = [i, i, i, i, C.POINTER(i), C.POINTER(i), C.POINTER(C.c_float)]
+    lib.ugsm_triangulate_fovea.argtypes = [vp, i, vp, vp, i, i, i, i, i, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    lib.ugsm_reconstruct_full.argtypes = [vp, i, vp, vp, vp, i, i, i, i, vp]
     lib.ugsm_stage_pyramid.argtypes = [vp, vp, i, i, i, i, vp]
     lib.ugsm_stage_iterate.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ugsm_stage_seed.argtypes = [vp, vp, i, i, vp, i, i, i, i, i, i]
@@ -224,6 +228,22 @@ class Context:
         self.check(self.lib.ugsm_triangulate(self._h, slot, d_dispx, d_dispy, W, H, p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), d_xyz))
         self.check(self.lib.ugsm_wait(self._h, slot))
 
+    def triangulate_fovea(self, d_stackx: int, d_stacky: int, fovW: int, fovH: int, src_level: int, left: int, upper: int, scale,
+                          P1, P2, d_xyz: int, slot: int = 0):
+        """Row f-1, foveated branch (getPointCloud.cpp:892-903): X, Y, Z planes for one level of the fovea stacks."""
+        p1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+        p2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+        dp = C.POINTER(C.c_double)
+        self.check(self.lib.ugsm_triangulate_fovea(self._h, slot, d_stackx, d_stacky, fovW, fovH, src_level, left, upper,
+                                                   C.c_float(float(scale)), p1.ctypes.data_as(dp), p2.ctypes.data_as(dp), d_xyz))
+        self.check(self.lib.ugsm_wait(self._h, slot))
+
+    def reconstruct_full(self, d_stackH: int, d_stackV: int, d_stackC: int, W: int, H: int, d_out3: int, off_x: int = 0, off_y: int = 0,
+                         slot: int = 0):
+        """Row f-3 (MatchGPULib.cpp:2589-2701): full-resolution field from the foveated stacks."""
+        self.check(self.lib.ugsm_reconstruct_full(self._h, slot, d_stackH, d_stackV, d_stackC, W, H, off_x, off_y, d_out3))
+        self.check(self.lib.ugsm_wait(self._h, slot))
+
     def kernel_stats(self):
         arr = (KernelStat * 16)()
         n = self.lib.ugsm_get_kernel_stats(self._h, arr, 16)
@@ -232,3 +252,13 @@ class Context:
 
     def reset_kernel_stats(self):
         self.check(self.lib.ugsm_reset_kernel_stats(self._h))
+
+
+def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):
+    """getPointCloud.cpp:387-484 -> (left_margin, upper_margin, scale); host only."""
+    lib = load()
+    l, u, sc = C.c_int(), C.c_int(), C.c_float()
+    st = lib.ugsm_fovea_mapping(W, H, src_level, dest_level, C.byref(l), C.byref(u), C.byref(sc))
+    if st != 0:
+        raise UgsmError(st, "ugsm_fovea_mapping")
+    return l.value, u.value, np.float32(sc.value)

@@ -428,8 +428,11 @@ __device__ long long *g_cost_stamps = nullptr;
         }                                                                                                          \
     } while (0)
 
-template <int ABL>
-__global__ __launch_bounds__(512) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+#ifndef UGSM_SPLIT_WAVES
+#define UGSM_SPLIT_WAVES 4  // waves per SIMD the register allocation aims at (2 workgroups per CU)
+#endif
+template <int ABL, int WAVES = UGSM_SPLIT_WAVES>
+__global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                     float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) float sR[SR_H * SR_W];
@@ -1065,19 +1068,9 @@ struct Proj {
 };
 __device__ __forceinline__ double sq_d(float v) { return (double)v * (double)v; }
 
-__global__ __launch_bounds__(256) void k_triangulate(const float *__restrict__ dispx, const float *__restrict__ dispy, int W, int H, Proj P1q, Proj P2q,
-                                                     float *__restrict__ xyz)
+// the closed form of get3DPoint (getPointCloud.cpp:908-948) for one left/right correspondence
+__device__ __forceinline__ void tri_point(float x1, float y1, float x2, float y2, const double *P1, const double *P2, float &X, float &Y, float &Z)
 {
-    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int yy = blockIdx.y;
-    if (xx >= W) return;
-    const double *P1 = P1q.m, *P2 = P2q.m;
-    const size_t n = (size_t)W * H, at = (size_t)yy * W + xx;
-    float x1, x2, y1, y2;
-    x1 = xx;
-    y1 = yy;
-    x2 = xx + dispx[at];
-    y2 = yy + dispy[at];
     float a, b, c, d, e, f, g, h, i, j, x, y;
     a = (float)P1[0];
     b = (float)(P1[2] - x1);
@@ -1105,9 +1098,53 @@ __global__ __launch_bounds__(256) void k_triangulate(const float *__restrict__ d
                     (f*h - e*i)*(-(g*i) + f*j) + sq_d(c)*(e*g + h*j)) + sq_d(a)*
                     (sq_d(d)*(sq_d(f) + sq_d(i)) + sq_d(g*i - f*j) - 2.0*c*d*(f*g + i*j) +
                     sq_d(c)*(sq_d(g) + sq_d(j)));
-    xyz[at] = XUp / divisor;
-    xyz[n + at] = YUp / divisor;
-    xyz[2 * n + at] = ZUp / divisor;
+    X = XUp / divisor;
+    Y = YUp / divisor;
+    Z = ZUp / divisor;
+}
+
+__global__ __launch_bounds__(256) void k_triangulate(const float *__restrict__ dispx, const float *__restrict__ dispy, int W, int H, Proj P1q, Proj P2q,
+                                                     float *__restrict__ xyz)
+{
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    if (xx >= W) return;
+    const size_t n = (size_t)W * H, at = (size_t)yy * W + xx;
+    float x1, x2, y1, y2;
+    x1 = xx;
+    y1 = yy;
+    x2 = xx + dispx[at];
+    y2 = yy + dispy[at];
+    float X, Y, Z;
+    tri_point(x1, y1, x2, y2, P1q.m, P2q.m, X, Y, Z);
+    xyz[at] = X;
+    xyz[n + at] = Y;
+    xyz[2 * n + at] = Z;
+}
+
+// get3DPoint, foveated branch (getPointCloud.cpp:892-903): level src_level of the (F*fovH) x fovW stacks, pixel
+// coordinates mapped into the full-resolution frame by mapXcoord / mapYcoord (:387-421).  Those take an int, so the
+// right-image coordinate xx + disparity is truncated toward zero before scaling -- kept as in the reference.
+__global__ __launch_bounds__(256) void k_triangulate_fovea(const float *__restrict__ stackx, const float *__restrict__ stacky, int fovW, int fovH,
+                                                           int src_level, int left_margin, int upper_margin, float scale, Proj P1q, Proj P2q,
+                                                           float *__restrict__ xyz)
+{
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    if (xx >= fovW) return;
+    const size_t n = (size_t)fovW * fovH, at = (size_t)yy * fovW + xx;
+    const size_t sat = ((size_t)yy + (size_t)fovH * src_level) * fovW + xx;
+    const float x1 = (float)left_margin + (float)xx * scale;
+    const float y1 = (float)upper_margin + (float)yy * scale;
+    const int sx = (int)(xx + stackx[sat]);
+    const int sy = (int)(yy + stacky[sat]);
+    const float x2 = (float)left_margin + (float)sx * scale;
+    const float y2 = (float)upper_margin + (float)sy * scale;
+    float X, Y, Z;
+    tri_point(x1, y1, x2, y2, P1q.m, P2q.m, X, Y, Z);
+    xyz[at] = X;
+    xyz[n + at] = Y;
+    xyz[2 * n + at] = Z;
 }
 
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz)
@@ -1115,6 +1152,51 @@ void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, 
     Proj a, b;
     for (int k = 0; k < 12; k++) { a.m[k] = P1[k]; b.m[k] = P2[k]; }
     hipLaunchKernelGGL(k_triangulate, dim3((W + 255) / 256, H), dim3(256), 0, st, dispx, dispy, W, H, a, b, xyz);
+}
+
+void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *stacky, int fovW, int fovH, int src_level, int left_margin,
+                              int upper_margin, float scale, const double *P1, const double *P2, float *xyz)
+{
+    Proj a, b;
+    for (int k = 0; k < 12; k++) { a.m[k] = P1[k]; b.m[k] = P2[k]; }
+    hipLaunchKernelGGL(k_triangulate_fovea, dim3((fovW + 255) / 256, fovH), dim3(256), 0, st, stackx, stacky, fovW, fovH, src_level, left_margin,
+                       upper_margin, scale, a, b, xyz);
+}
+
+// =========================================================================================
+// one step of hierarchicalDisparity (MatchGPULib.cpp:2643-2683) -- upsample the coarser
+// full-frame field by partsubsampleDispKernel (MatchLib.cu:435-462: dst = s * src[tex((x+.5)/s), tex((y+.5)/s)],
+// every channel scaled, confidence included) and paste the finer level's fovea at its crop origin, fused: a
+// pasted pixel never computes the upsample it would overwrite.  HBM-bound (12 B written per pixel).
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_upsample_paste(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3, int W2, int H2,
+                                                        const float *__restrict__ fovH_, const float *__restrict__ fovV_, const float *__restrict__ fovC_,
+                                                        int fovW, int fovH, int org_x, int org_y)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    const int iy = blockIdx.y;
+    if (ix >= W2) return;
+    const float s = (float)1.41421356;
+    const size_t n = (size_t)W * H, n2 = (size_t)W2 * H2, at2 = (size_t)iy * W2 + ix;
+    const int fx = ix - org_x, fy = iy - org_y;
+    if (fx >= 0 && fx < fovW && fy >= 0 && fy < fovH) {
+        const size_t fa = (size_t)fy * fovW + fx;
+        dst3[at2] = fovH_[fa];
+        dst3[n2 + at2] = fovV_[fa];
+        dst3[2 * n2 + at2] = fovC_[fa];
+    } else {
+        const size_t at = (size_t)tex_index(((float)iy + 0.5f) / s, H) * W + tex_index(((float)ix + 0.5f) / s, W);
+        dst3[at2] = s * src3[at];
+        dst3[n2 + at2] = s * src3[n + at];
+        dst3[2 * n2 + at2] = s * src3[2 * n + at];
+    }
+}
+
+void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, const float *fovH_, const float *fovV_,
+                           const float *fovC_, int fovW, int fovH, int org_x, int org_y)
+{
+    hipLaunchKernelGGL(k_upsample_paste, dim3((W2 + 255) / 256, H2), dim3(256), 0, st, src3, W, H, dst3, W2, H2, fovH_, fovV_, fovC_, fovW, fovH,
+                       org_x, org_y);
 }
 
 // test hook (tests only): poly_fast on arbitrary operands, so that its rarely taken f64 fallback and the

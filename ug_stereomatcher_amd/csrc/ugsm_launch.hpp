@@ -41,6 +41,10 @@ void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
 // X, Y, Z planes from the full-resolution (dx, dy) and the two 3x4 projection matrices
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);
 // test hook: the fused kernels' exact shortcuts (parabola fast path, x/3) on arbitrary operands
+void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *stacky, int fovW, int fovH, int src_level, int left_margin,
+                              int upper_margin, float scale, const double *P1, const double *P2, float *xyz);
+void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, const float *fovH_, const float *fovV_,
+                           const float *fovC_, int fovW, int fovH, int org_x, int org_y);
 void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n);
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);
 

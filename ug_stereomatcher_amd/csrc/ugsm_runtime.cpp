@@ -720,6 +720,32 @@ int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR,
     return ugsm_wait(ctx, 0);
 }
 
+// match(L, R, fov == 1), MatchGPULib.cpp:354-360: foveated matching, then hierarchicalDisparity on the stacks
+int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                             float *outH, float *outV, float *outC)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!outH || !outV || !outC) return UGSM_ERR_BAD_ARG;
+    const int F = ctx->cfg.fovea_levels;
+    if (F < 2) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    int fw, fh;
+    UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
+    UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
+    const size_t fn = (size_t)fw * fh, stackn = (size_t)F * fn, n = (size_t)W * H;
+    UCHK(grow(ctx, s->hout, s->hout_cap, 3 * fn + 3 * stackn + 3 * n));  // [state][stack][full field]
+    float *d_state = s->hout, *d_stack = d_state + 3 * fn, *d_full = d_stack + 3 * stackn;
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
+    UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
+    UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, nullptr, nullptr));
+    UCHK(ugsm_reconstruct_full(ctx, 0, d_stack, d_stack + stackn, d_stack + 2 * stackn, W, H, off_x, off_y, d_full));
+    HIPCHK(ctx, hipMemcpyAsync(outH, d_full, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(outV, d_full + n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(ctx, hipMemcpyAsync(outC, d_full + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    return ugsm_wait(ctx, 0);
+}
+
 // ---- stage-level ------------------------------------------------------------------------
 
 int ugsm_stage_pyramid(ugsm_ctx *ctx, const uint8_t *d_rgb, int W, int H, int stride, int level, float *d_out3)
@@ -795,6 +821,82 @@ int ugsm_triangulate(ugsm_ctx *ctx, int slot, const float *d_dispx, const float 
     {
         Timer t(ctx, s, slot, KC_MISC, (double)W * H);
         launch_triangulate(s->st, d_dispx, d_dispy, W, H, P1, P2, d_xyz);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
+// CdynamicCalibration::left_marginOf_in / upper_marginOf_in / mapXcoord (getPointCloud.cpp:387-484)
+int ugsm_fovea_mapping(int W, int H, int src_level, int dest_level, int *left_margin, int *upper_margin, float *scale)
+{
+    if (!left_margin || !upper_margin || !scale || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    int scaled = 6 - src_level;  // :435 (the reference hard-codes its 7 fovea levels here)
+    if (src_level < dest_level) scaled = src_level + dest_level;
+    if (scaled < 0 || scaled >= 15 || dest_level < 0 || dest_level >= 15 || src_level < 0) return UGSM_ERR_BAD_ARG;
+    int w[16], h[16];
+    w[0] = W;
+    h[0] = H;
+    for (int i = 0; i < 14; i++) {  // :441-443
+        w[i + 1] = (int)(w[i] / kScale);
+        h[i + 1] = (int)(h[i] / kScale);
+    }
+    *left_margin = w[dest_level] / 2 - w[scaled] / 2;
+    *upper_margin = h[dest_level] / 2 - h[scaled] / 2;
+    const float root = (src_level < dest_level) ? (float)0.70710678118654752440 : (float)1.41421356237309504880;
+    *scale = powf(root, (float)std::abs(src_level - dest_level));  // pow(float, float), :397
+    return UGSM_OK;
+}
+
+int ugsm_triangulate_fovea(ugsm_ctx *ctx, int slot, const float *d_stackx, const float *d_stacky, int fovW, int fovH, int src_level,
+                           int left_margin, int upper_margin, float scale, const double *P1, const double *P2, float *d_xyz)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_stackx || !d_stacky || !P1 || !P2 || !d_xyz || fovW < 1 || fovH < 1 || src_level < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    {
+        Timer t(ctx, s, slot, KC_MISC, (double)fovW * fovH);
+        launch_triangulate_fovea(s->st, d_stackx, d_stacky, fovW, fovH, src_level, left_margin, upper_margin, scale, P1, P2, d_xyz);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return UGSM_OK;
+}
+
+// hierarchicalDisparity, MatchGPULib.cpp:2589-2701
+int ugsm_reconstruct_full(ugsm_ctx *ctx, int slot, const float *d_stackH, const float *d_stackV, const float *d_stackC, int W, int H,
+                          int off_x, int off_y, float *d_out3)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!d_stackH || !d_stackV || !d_stackC || !d_out3) return UGSM_ERR_BAD_ARG;
+    const int levels = ctx->cfg.levels, F = ctx->cfg.fovea_levels;
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    UCHK(level_dims(W, H, levels, w, h));
+    if (F < 1 || F > levels) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    FoveaGeom g;
+    if (F >= 2) fovea_geometry(w, h, F, off_x, off_y, g);
+    else { g.fw = w[0]; g.fh = h[0]; }
+    const size_t fl = (size_t)g.fw * g.fh;
+    if (F == 1) {  // the stack is the full frame already
+        const float *src[3] = {d_stackH, d_stackV, d_stackC};
+        for (int c = 0; c < 3; c++) HIPCHK(ctx, hipMemcpyAsync(d_out3 + c * fl, src[c], fl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+        return UGSM_OK;
+    }
+    UCHK(ensure_level_bufs(ctx, *s, 3 * (size_t)w[1] * h[1]));
+    // level F-1 (whole frame) as a 3-plane field
+    float *cur = s->d0, *other = s->d1;
+    {
+        const float *src[3] = {d_stackH, d_stackV, d_stackC};
+        for (int c = 0; c < 3; c++)
+            HIPCHK(ctx, hipMemcpyAsync(cur + c * fl, src[c] + (size_t)(F - 1) * fl, fl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    }
+    for (int level = F - 1; level > 0; level--) {
+        float *dst = (level == 1) ? d_out3 : other;
+        Timer t(ctx, s, slot, KC_MISC, (double)w[level - 1] * h[level - 1]);
+        launch_upsample_paste(s->st, cur, w[level], h[level], dst, w[level - 1], h[level - 1], d_stackH + (size_t)(level - 1) * fl,
+                              d_stackV + (size_t)(level - 1) * fl, d_stackC + (size_t)(level - 1) * fl, g.fw, g.fh, g.ox[level - 1], g.oy[level - 1]);
+        std::swap(cur, other);
     }
     HIPCHK(ctx, hipGetLastError());
     return UGSM_OK;

@@ -87,10 +87,6 @@ class MatchGPULib:
     # -- match, MatchGPULib.cpp:303-403 --
     def match(self, cv_ptrL, cv_ptrR, fov: int = 0) -> np.ndarray:
         """Returns finDisp: float32 (3, rows, cols) = horizontal, vertical disparity and confidence."""
-        if fov == 1:
-            # match(..., fov==1) -> hierarchicalDisparity is unreachable from the node
-            # (UG_GPU_matcher.cpp:421-423,644-645) and is out of scope (SURVEY.md section 8a).
-            raise UgsmError(_lib.UGSM_ERR_BAD_ARG, "match(fov=1) (hierarchicalDisparity) is not part of the hot path")
         L, R = _as_rgb8(cv_ptrL), _as_rgb8(cv_ptrR)
         if L.shape != R.shape or L.strides[0] != R.strides[0]:
             raise UgsmError(_lib.UGSM_ERR_SIZE_MISMATCH, "left/right images differ in size")
@@ -98,9 +94,30 @@ class MatchGPULib:
         rows, cols = L.shape[:2]
         out = np.empty((3, rows, cols), np.float32)
         c = self._ctx
+        if fov == 1:
+            # foveated matching + hierarchicalDisparity (MatchGPULib.cpp:354-360); the node never asks for it
+            # (UG_GPU_matcher.cpp:421-423,644-645), SURVEY 8f row f-3
+            self.fovW, self.fovH = _lib.fovea_dims(cols, rows, self._levels, self.foveatelevel)
+            c.check(c.lib.ugsm_match_foveated_full(c.handle, L.ctypes.data, R.ctypes.data, cols, rows, L.strides[0], 0, 0,
+                                                   out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+            return out
         c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, cols, rows, L.strides[0],
                                       out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
         return out
+
+    # -- hierarchicalDisparity, MatchGPULib.cpp:2589-2701 --
+    def hierarchicalDisparity(self, foveated: np.ndarray, widthInit: int, heightInit: int) -> np.ndarray:
+        """foveated: (foveatelevel, 3, fovH, fovW) as matchStack returns it -> (3, heightInit, widthInit)."""
+        st = np.ascontiguousarray(np.transpose(np.asarray(foveated, np.float32), (1, 0, 2, 3)))
+        c = self._ctx
+        ps = [c.to_device(st[k]) for k in range(3)]
+        pout = c.alloc(3 * widthInit * heightInit * 4)
+        try:
+            c.reconstruct_full(ps[0], ps[1], ps[2], widthInit, heightInit, pout)
+            return c.to_host(pout, (3, heightInit, widthInit))
+        finally:
+            for p in ps + [pout]:
+                c.free(p)
 
     def _stack(self, cv_ptrL, cv_ptrR, want_pyr: bool, off_x: int = 0, off_y: int = 0):
         L, R = _as_rgb8(cv_ptrL), _as_rgb8(cv_ptrR)
