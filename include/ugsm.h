@@ -29,7 +29,7 @@ extern "C" {
 
 /* status codes */
 #define UGSM_OK                0
-#define UGSM_ERR_BAD_ARG       1  /* null pointer, non-positive size, bad slot/level */
+#define UGSM_ERR_BAD_ARG       1  /* null pointer, non-positive size, bad slot/level, image above 2^28 pixels */
 #define UGSM_ERR_SIZE_MISMATCH 2  /* left/right differ, or stride < 3*W (ref: unchecked, MatchGPULib.cpp:315-323) */
 #define UGSM_ERR_TOO_SMALL     3  /* a pyramid level would be < 1 px (ref: zero-size malloc, MatchGPULib.cpp:1247) */
 #define UGSM_ERR_NO_DEVICE     4  /* no HIP device / HIP runtime unusable */

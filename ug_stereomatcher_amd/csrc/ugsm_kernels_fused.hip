@@ -69,6 +69,11 @@ __device__ __forceinline__ void ld4(const float *p, float *o)
     const float4 t = *reinterpret_cast<const float4 *>(p);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
 }
+__device__ __forceinline__ void ld2(const float *p, float *o)
+{
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    o[0] = t.x; o[1] = t.y;
+}
 __device__ __forceinline__ void st4(float *p, const float *o)
 {
     *reinterpret_cast<float4 *>(p) = make_float4(o[0], o[1], o[2], o[3]);
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         }
     }
 
-    float Q[3][4];  // role 0: shifts 0,1,4; role 1: shifts 2,3 (Q[2] unused)
+    float Q[3][4];  // role 0: shifts 0,1 and pixels 0,1 of shift 4; role 1: shifts 2,3 and pixels 2,3 of shift 4
 #pragma unroll
     for (int s = 0; s < 3; s++)
 #pragma unroll
@@ -618,17 +623,15 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         }
         __syncthreads();
         UGSM_STAMP(3 + 4 * k);
-        // ---- P2.5: column pass of R'^2 -> B on tile+halo1 (role 1) ------------------------------
-        if (role == 1) {
-            for (int it = t; it < SB_H * SB_Q; it += 256) {
-                const int q = it / SB_H, r = it - q * SB_H;  // r: tile row + 1
-                float a[4], b[4], c[4], d[4], e[4], o[4];
-                const float *pb = &sBrow[r * SB_W + q * 4];
-                ld4(pb, a); ld4(pb + SB_W, b); ld4(pb + 2 * SB_W, c); ld4(pb + 3 * SB_W, d); ld4(pb + 4 * SB_W, e);
+        // ---- P2.5: column pass of R'^2 -> B on tile+halo1: 300 quads, one per thread over both roles ----
+        if (tid < SB_H * SB_Q) {
+            const int q = tid / SB_H, r = tid - q * SB_H;  // r: tile row + 1
+            float a[4], b[4], c[4], d[4], e[4], o[4];
+            const float *pb = &sBrow[r * SB_W + q * 4];
+            ld4(pb, a); ld4(pb + SB_W, b); ld4(pb + 2 * SB_W, c); ld4(pb + 3 * SB_W, d); ld4(pb + 4 * SB_W, e);
 #pragma unroll
-                for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
-                st4(&sB[r * SB_W + q * 4], o);
-            }
+            for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
+            st4(&sB[r * SB_W + q * 4], o);
         }
         __syncthreads();
         UGSM_STAMP(4 + 4 * k);
@@ -653,6 +656,22 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
                     else Q[slot][i] = div3_nonneg(Q[slot][i] + q);
                 }
             };
+            // shift (0,0): each role takes two pixels of the quad (role 0: 0,1; role 1: 2,3), which evens out the
+            // three-shifts / two-shifts split of the phase; Q[2][2h], Q[2][2h+1] hold them
+            auto half4 = [&](const int hsel, const float *bq) {
+                float r0[2], r1[2], r2[2], r3[2], r4[2];
+                const float *ps = &sRow[(4 * ROW_H + trow) * ROW_W + cx + 2 * hsel];
+                ld2(ps, r0); ld2(ps + ROW_W, r1); ld2(ps + 2 * ROW_W, r2); ld2(ps + 3 * ROW_W, r3); ld2(ps + 4 * ROW_W, r4);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int i = 2 * hsel + j;
+                    const float Nn = tap5p(r0[j], r1[j], r2[j], r3[j], r4[j]);
+                    const float q = ncc2_nn(Nn, a4[i], bq[i]);
+                    if (k == 0) Q[2][i] = q;
+                    else if (k == 1) Q[2][i] = q + Q[2][i];
+                    else Q[2][i] = div3_nonneg(Q[2][i] + q);
+                }
+            };
             float N[4], b[4];
             if (role == 0) {
                 float bc[12];
@@ -665,8 +684,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #pragma unroll
                 for (int i = 0; i < 4; i++) b[i] = (gx0 + i >= W - 1) ? bc[i + 4] : bc[i + 5];
                 accum(1, N, b);
-                colpass(4, N);
-                accum(2, N, bc + 4);
+                half4(0, bc + 4);
             } else {
                 float bm[4], bu[4], bd[4];
                 ld4(pb + 4, bm); ld4(pb - SB_W + 4, bu); ld4(pb + SB_W + 4, bd);
@@ -679,6 +697,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #pragma unroll
                 for (int i = 0; i < 4; i++) b[i] = bot ? bm[i] : bd[i];
                 accum(1, N, b);
+                half4(1, bm);
             }
         }
         UGSM_STAMP(5 + 4 * k);
@@ -689,16 +708,14 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
     __syncthreads();  // every P3 is done with sRow: planes 0..3 become hand-over buffers
     UGSM_STAMP(14);
     float *xq = &sRow[(0 * ROW_H + trow) * ROW_W + cx];
-    if (role == 0 && live) st4(xq, Q[2]);  // Q(0,0) for the y parabola
+    if (live) {  // Q(0,0): each role publishes its two pixels, both parabolas need the four
+        if (role == 0) { xq[0] = Q[2][0]; xq[1] = Q[2][1]; }
+        else { xq[2] = Q[2][2]; xq[3] = Q[2][3]; }
+    }
     __syncthreads();
     if (live) {
         float c4[4], dd[4], rho[4];
-        if (role == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) c4[i] = Q[2][i];
-        } else {
-            ld4(xq, c4);
-        }
+        ld4(xq, c4);
 #pragma unroll
         for (int i = 0; i < 4; i++) poly_fast(c4[i], Q[0][i], Q[1][i], thr, dd[i], rho[i]);  // x: shifts (-1,0),(+1,0); y: (0,-1),(0,+1)
         st4(&sRow[((1 + role) * ROW_H + trow) * ROW_W + cx], dd);   // plane 1: delta x, plane 2: delta y

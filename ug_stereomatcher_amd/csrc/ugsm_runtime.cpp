@@ -83,9 +83,12 @@ namespace {
         if (r__ != UGSM_OK) return r__;  \
     } while (0)
 
+constexpr long long kMaxPixels = 1LL << 28;  // 268 Mpx: 4 B x pixels of one plane stays below 2^31
+
 int level_dims(int W, int H, int levels, int *w, int *h)
 {
     if (W < 1 || H < 1 || levels < 1 || levels > UGSM_MAX_LEVELS) return UGSM_ERR_BAD_ARG;
+    if ((long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;  // the kernels address a plane by 32-bit byte offsets
     w[0] = W;
     h[0] = H;
     for (int i = 0; i < levels - 1; i++) {  // MatchGPULib.cpp:1224-1228
@@ -768,6 +771,7 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
     Slot *s;
     UCHK(get_slot(ctx, 0, &s));
     if (!d_L3 || !d_R3 || !d_d3 || W < 1 || H < 1 || mi < 1 || m_from < 1 || m_to > mi || S < 0) return UGSM_ERR_BAD_ARG;
+    if ((long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;
     if (d_dbg8 && ctx->cfg.kernel_path != 1) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     // level buffers sized for this image; the pyramid buffers are not needed here
@@ -799,7 +803,7 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
 {
     Slot *s;
     UCHK(get_slot(ctx, 0, &s));
-    if (!d_d3 || W < 1 || H < 1 || passes < 0) return UGSM_ERR_BAD_ARG;
+    if (!d_d3 || W < 1 || H < 1 || passes < 0 || (long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     const size_t lvl = 3 * (size_t)W * H;
     UCHK(ensure_level_bufs(ctx, *s, lvl));
