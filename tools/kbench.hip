@@ -94,18 +94,13 @@ int main(int argc, char **argv)
             timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn); });
         };
         for (int round = 0; round < 2; round++) {
-            run((k_smooth_fused<64, 58, 512, 0>), 64, 58, 512, "smooth<64,58,512> p5+box");
-            run((k_smooth_fused<64, 58, 512, 0>), 64, 58, 512, "smooth<64,58,512> p5", 5, 0);
-            run((k_smooth_fused<64, 58, 512, 4>), 64, 58, 512, "smooth<64,58,512> lds-we p5+box");
-            run((k_smooth_fused<64, 58, 512, 4>), 64, 58, 512, "smooth<64,58,512> lds-we p5", 5, 0);
-            run((k_smooth_fused<64, 58, 512, 5>), 64, 58, 512, "smooth<64,58,512> old-arith p5+box");
-            run((k_smooth_fused<64, 58, 512, 2>), 64, 58, 512, "smooth<64,58,512> +interior p5+box");
-            run((k_smooth_fused<64, 34, 512, 0>), 64, 34, 512, "smooth<64,34,512> p5+box");
-            run((k_smooth_fused<64, 34, 512, 0>), 64, 34, 512, "smooth<64,34,512> p5", 5, 0);
-            run((k_smooth_fused<64, 58, 384, 0>), 64, 58, 384, "smooth<64,58,384> p5+box");
-            run((k_smooth_fused<64, 58, 384, 0>), 64, 58, 384, "smooth<64,58,384> p5", 5, 0);
-            run((k_smooth_fused<64, 40, 384, 0>), 64, 40, 384, "smooth<64,40,384> p5+box");
-            run((k_smooth_fused<64, 40, 384, 0>), 64, 40, 384, "smooth<64,40,384> p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 8>), 112, 36, 512, "smooth<112,36,512> p5 halo7", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0+box", 0, 1);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1+box", 1, 1);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });

@@ -90,6 +90,17 @@ __device__ __forceinline__ float tap5p(float a, float b, float c, float d, float
     return sum;
 }
 
+// box5 (ugsm_device.hpp) with its two zero taps folded into FMAs: a*0.0f is exact (+-0, or NaN for a = NaN / Inf), so
+// fma(a, 0, s) rounds the same sum the two-step form rounds.  8 operations instead of 10.
+__device__ __forceinline__ float box5f(float a, float b, float c, float d, float e)
+{
+    float sum = __builtin_fmaf(a, 0.0f, 0.0f);
+    sum += b * UGSM_BOX;
+    sum += c * UGSM_BOX;
+    sum += d * UGSM_BOX;
+    return __builtin_fmaf(e, 0.0f, sum);
+}
+
 // ---- exact shortcuts used by the fused kernels only (the one-stage-per-kernel path and the CPU
 // oracle keep the literal forms; the parity tests compare the two) ------------------------------
 //
@@ -811,7 +822,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     const int tx0 = tile_x * STX, ty0 = tile_y * STY;
     const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
-    const int h = P + (do_box ? 2 : 0);      // halo actually needed
+    const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
 
     // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
     // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
@@ -1002,7 +1013,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                     float v[12];
                     ld4(src - 4, v); ld4(src, v + 4); ld4(src + 4, v + 8);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) bv[u][f][i] = box5(v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
+                    for (int i = 0; i < 4; i++) bv[u][f][i] = box5f(v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
                 }
             }
         }
@@ -1032,7 +1043,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                     float a[4], b[4], c[4], d[4], e[4];
                     ld4(src - 2 * LW, a); ld4(src - LW, b); ld4(src, c); ld4(src + LW, d); ld4(src + 2 * LW, e);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) cv[u][f][i] = box5(a[i], b[i], c[i], d[i], e[i]);
+                    for (int i = 0; i < 4; i++) cv[u][f][i] = box5f(a[i], b[i], c[i], d[i], e[i]);
                 }
             }
         }
@@ -1288,11 +1299,13 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
-    // big levels: 64x64 tiles, 512 threads, 79 KB LDS -> two workgroups per CU, so one's load/store phase
-    // overlaps the other's passes (measured 378 us vs 406 us for 128x64x1024 at 16 MP, 77 vs 94 at 2 MP);
+    // big levels: 112x36 tiles, 512 threads, 79 KB LDS -> two workgroups per CU, so one's load/store phase overlaps
+    // the other's passes.  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
+    // columns every pass recomputes are 12.5 % of the row instead of 20 % (at 16 MP: 5 passes 227 us against 266 us for
+    // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (px >= ((size_t)1 << 19)) launch_smooth_t<64, 58, 512>(st, s3, o3, W, H, passes, do_box);
+    if (px >= ((size_t)1 << 19)) launch_smooth_t<112, 36, 512>(st, s3, o3, W, H, passes, do_box);
     else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }
