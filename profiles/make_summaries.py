@@ -14,15 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 base, tag = sys.argv[1], sys.argv[2]
 out = os.path.join(ROOT, "profiles")
-shutil.copy(glob.glob(base + "/trace/runc/*kernel_stats.csv")[0], f"{out}/{tag}_kernel_stats.csv")
+shutil.copy(glob.glob(base + "/trace/**/*kernel_stats.csv", recursive=True)[0], f"{out}/{tag}_kernel_stats.csv")
 for f in ("bench_default.json", "bench_under_rocprof.json"):
     shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
-if os.path.exists(base + "/kbench_16mp.txt"):
-    shutil.copy(base + "/kbench_16mp.txt", f"{out}/{tag}_kbench_16mp.txt")
+for f in ("kbench_16mp.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json", "bench_fovea16mp.json"):
+    if os.path.exists(f"{base}/{f}"):
+        shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 
 
 def load(d):
-    f = glob.glob(f"{base}/{d}/runc/*counter_collection.csv")[0]
+    f = glob.glob(f"{base}/{d}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ugsm::", "")

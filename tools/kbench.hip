@@ -41,6 +41,13 @@ int main(int argc, char **argv)
 #define COST(ABL) timeit("k_cost_fused<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_fused<ABL>, dim3(cnt), dim3(256), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
 #define SPLIT_PLACEHOLDER
 #define SPLIT(ABL) timeit("k_cost_split<" #ABL ">", [&]() { hipLaunchKernelGGL(k_cost_split<ABL>, dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); })
+    if (argc > 4 && atoi(argv[4]) == 1) {  // counter runs: the two production kernels only
+        for (int i = 0; i < reps; i++) launch_cost_fused(st, iL, iR, A, d, o, W, H, 1.0f, 1);
+        for (int i = 0; i < reps; i++) launch_smooth_fused(st, d, o, W, H, 5, 0);
+        for (int i = 0; i < reps; i++) launch_smooth_fused(st, d, o, W, H, 5, 1);
+        CK(hipStreamSynchronize(st));
+        return 0;
+    }
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)
         COST(0); SPLIT(0);
         timeit("k_cost_split<0, 6 waves>", [&]() { hipLaunchKernelGGL((k_cost_split<0, 6>), dim3(cnt), dim3(512), 0, st, iL, iR, A, d, o, W, H, 1.0f, 1, ctx, cnt); });

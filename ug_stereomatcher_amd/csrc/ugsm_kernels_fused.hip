@@ -64,6 +64,22 @@ __device__ __forceinline__ void xcd_tile(int n_tiles, int tiles_x, int &tx, int 
     tx = t - ty * tiles_x;
 }
 
+// Global accesses as scalar base + 32-bit lane byte offset: the base is pinned to SGPRs (readfirstlane) and the
+// access is made in the global address space explicitly, so that the plane offset does not migrate into a 64-bit vector
+// add per access and the access does not degrade to a flat one.
+typedef __attribute__((address_space(1))) const char gchar_c;
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) const float gfloat_c;
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gchar_c *uniform_base(const float *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gchar_c *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float ld_at(gchar_c *base, unsigned off) { return *(gfloat_c *)(base + off); }
+__device__ __forceinline__ void st_at(gchar_c *base, unsigned off, float v) { *(gfloat *)((gchar *)base + off) = v; }
+
 __device__ __forceinline__ void ld4(const float *p, float *o)
 {
     const float4 t = *reinterpret_cast<const float4 *>(p);
@@ -477,7 +493,10 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
     // Addresses are a 32-bit byte offset against a uniform plane base (a plane is < 4 GiB).
     constexpr int NR = (IDX_H * IDX_W + 511) / 512;
     constexpr int NL = (SL_H * (TX + 4) + 511) / 512;
-    auto ldoff = [](const float *base, unsigned off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
+    gchar_c *const Lb[3] = {uniform_base(L.p), uniform_base(L.p + L.plane), uniform_base(L.p + 2 * L.plane)};
+    gchar_c *const Rb[3] = {uniform_base(R.p), uniform_base(R.p + R.plane), uniform_base(R.p + 2 * R.plane)};
+    gchar_c *const Ab[3] = {uniform_base(A3), uniform_base(A3 + n), uniform_base(A3 + 2 * n)};
+    gchar_c *const Db[3] = {uniform_base(d3), uniform_base(d3 + n), uniform_base(d3 + 2 * n)};
     float rv[3][NR], lv[3][NL];
     int ridx[NR];
     {
@@ -490,8 +509,8 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
             gxh[u] = clampi(x0 + c - 3, 0, W - 1);
             gyh[u] = clampi(y0 + r - 3, 0, H - 1);
             const unsigned off = ((unsigned)gyh[u] * (unsigned)W + (unsigned)gxh[u]) * 4u;
-            ddx[u] = ldoff(d3, off);
-            ddy[u] = ldoff(d3 + n, off);
+            ddx[u] = ld_at(Db[0], off);
+            ddy[u] = ld_at(Db[1], off);
         }
         UGSM_STAMP(16);
 #pragma unroll
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
             const unsigned off = ((unsigned)clampi(gyl, 0, H - 1) * (unsigned)L.pitch + (unsigned)clampi(gxl, 0, W - 1)) * 4u;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float t = ldoff(L.p + (size_t)k * L.plane, off);
+                const float t = ld_at(Lb[k], off);
                 lv[k][u] = in ? t : 0.0f;
             }
         }
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #pragma unroll
     for (int u = 0; u < NR; u++)
 #pragma unroll
-        for (int k = 0; k < 3; k++) rv[k][u] = ldoff(R.p + (size_t)k * R.plane, (unsigned)ridx[u]);
+        for (int k = 0; k < 3; k++) rv[k][u] = ld_at(Rb[k], (unsigned)ridx[u]);
     UGSM_STAMP(18);
     constexpr int NA = (TX * TY + 511) / 512;
     float aq[3][NA], od[3][NA];  // A and the tile's own (dx,dy,conf), lanes along the rows (coalesced)
@@ -530,7 +549,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         const unsigned off = in ? ((unsigned)(y0 + r) * (unsigned)W + (unsigned)(x0 + c)) * 4u : 0u;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
-            const float ta = ldoff(A3 + (size_t)kk * n, off), td = ldoff(d3 + (size_t)kk * n, off);
+            const float ta = ld_at(Ab[kk], off), td = ld_at(Db[kk], off);
             aq[kk][u] = in ? ta : 1.0f;
             od[kk][u] = in ? td : 0.0f;
         }
@@ -733,19 +752,20 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         st4(&sRow[((3 + role) * ROW_H + trow) * ROW_W + cx], rho);  // plane 3: rho x,  plane 4: rho y
     }
     __syncthreads();
+    gchar_c *const Nb[3] = {uniform_base(nd3), uniform_base(nd3 + n), uniform_base(nd3 + 2 * n)};
 #pragma unroll
     for (int u = 0; u < NA; u++) {
         const int it = tid + u * 512;
         const int r = it / TX, c = it - r * TX;
         const int gxo = x0 + c, gyo = y0 + r;
         if (it < TX * TY && gxo < W && gyo < H) {
-            const size_t at = (size_t)gyo * W + gxo;
+            const unsigned off = ((unsigned)gyo * (unsigned)W + (unsigned)gxo) * 4u;
             const float ddx = sRow[(1 * ROW_H + r) * ROW_W + c], ddy = sRow[(2 * ROW_H + r) * ROW_W + c];
             float kap = sRow[(4 * ROW_H + r) * ROW_W + c] * sRow[(3 * ROW_H + r) * ROW_W + c];  // rho_y * rho_x
             if (blend) kap = blend_conf(od[2][u], kap);
-            nd3[at] = od[0][u] + ddx;
-            nd3[n + at] = od[1][u] + ddy;
-            nd3[2 * n + at] = kap;
+            st_at(Nb[0], off, od[0][u] + ddx);
+            st_at(Nb[1], off, od[1][u] + ddy);
+            st_at(Nb[2], off, kap);
         }
     }
     UGSM_STAMP(15);
