@@ -103,10 +103,9 @@ int main(int argc, char **argv)
         for (int round = 0; round < 2; round++) {
             run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
             run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 8>), 112, 36, 512, "smooth<112,36,512> p5 halo7", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0+box", 0, 1);
+            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
+            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
             run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1+box", 1, 1);
             run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }

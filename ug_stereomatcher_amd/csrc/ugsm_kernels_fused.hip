@@ -817,9 +817,9 @@ __device__ __forceinline__ void div3_shared(const float a0, const float a1, cons
 // barrier, writes back, barrier.  A pass leaves global row 0 / column 0 untouched (ix>0 && iy>0
 // guard) and clamps x+1 / y+1 at the image edge.  Out-of-image LDS cells hold the clamped pixel;
 // they are refreshed once before the box so that its clamp addressing needs no index logic.
-// VAR (development switches, tools/kbench.hip): bit 0 = literal per-plane division, bit 1 = select-free copy of
-// the pass for interior tiles, bit 2 = west/east neighbours from LDS instead of the neighbouring lanes.
-// Product: VAR = 0.
+// VAR (development switches, tools/kbench.hip): bit 0 = literal per-plane division, bit 1 = per-pixel border selects
+// instead of the replica / repair scheme, bit 2 = west/east neighbours from LDS instead of the neighbouring lanes,
+// bit 3 = the box's halo without the box.  Product: VAR = 0.
 template <int STX, int STY, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
                                                   int tiles_x, int n_tiles)
@@ -881,10 +881,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     const int c0 = q * 4, gx0 = x0 + c0;
     const bool lane_on = lane < RPW * QW;
 
-    // VAR & 2: a tile whose whole LDS region lies strictly inside the image (no row 0 / column 0 pass-through, no
-    // clamped east / south neighbour) takes a copy of the pass without the per-pixel selects.  Measured: no
-    // faster (the selects are ~10 of ~50 issue slots per pixel, but the second copy costs 24 VGPRs) -- off.
-    const bool interior = (VAR & 2) && x0 >= 1 && y0 >= 1 && x0 + RWID <= W - 1 && y0 + LH <= H - 1;
+    // Image borders without per-pixel selects.  smoothKernel clamps x+1 / y+1 at the last column / row and leaves
+    // row 0 / column 0 untouched (MatchLib.cu:1105-1143).  Here every cell of the region is computed alike; the
+    // few tiles that touch a border repair it afterwards, under tile-uniform branches:
+    //  * east / south clamp: the LDS cell just outside the image (column W, row H) is a replica of its in-image
+    //    neighbour -- true after the load, re-established after every write-back (edge_e / edge_s);
+    //  * pass-through of row 0 / column 0: their results are replaced by the old values (edge_nw).
+    // Cells outside the image otherwise hold whatever the pass produces; no in-image pixel reads them.
+    // (VAR & 2, development: the earlier per-pixel selects.)
+    const bool edge_e = x0 + RWID > W, edge_s = y0 + LH > H, edge_nw = x0 <= 0 || y0 <= 0;
 
     for (int p = 1; p <= P; p++) {
         // pass p is needed (and valid) on the region shrunk to halo h-p
@@ -895,8 +900,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
         // division per plane; otherwise the shared-reciprocal form, and the return value says whether every
         // denominator of the quad was in its range (if not, the row is simply redone with LIT).
         auto quad_row = [&](const int u, const int gy, const float (&c4)[3][4], const float (&n4)[3][4], const float (&s4)[3][4],
-                            const float (&wl)[3], const float (&er)[3], auto edge_tag, auto lit_tag) -> bool {
-            constexpr bool EDGE = decltype(edge_tag)::value, LIT = decltype(lit_tag)::value;
+                            const float (&wl)[3], const float (&er)[3], auto lit_tag) -> bool {
+            constexpr bool EDGE = (VAR & 2) != 0, LIT = decltype(lit_tag)::value;
             const bool row_ok = gy > 0 && gy < H;
             const bool south_in = gy + 1 <= H - 1;
             bool ok = true;
@@ -944,54 +949,58 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
             return ok;
         };
-        auto pass = [&](auto edge_tag) {
 #pragma unroll
-            for (int u = 0; u < MAXR; u++) {
-                const int r = r_lo + rg + u * RG;
-                if (lane_on && r < r_hi) {
-                    // every quad of the row loads (the neighbouring lanes' quads feed the west / east taps)
-                    const int at = r * LW + c0;
-                    float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
-                    ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
-                    ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
-                    ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
-                    if constexpr (VAR & 4) {
-                        float t[4];
-                        ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
-                        ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
-                    } else {
-                        // west / east neighbours from the neighbouring lanes' registers instead of LDS (a narrowed,
-                        // lane-strided ds_read_b32 there is a 4-way bank conflict).  At q = 0 / QW-1 the value comes
-                        // from another row: those are region-edge columns, never valid in any pass.
+        for (int u = 0; u < MAXR; u++) {
+            const int r = r_lo + rg + u * RG;
+            if (lane_on && r < r_hi) {
+                // every quad of the row loads (the neighbouring lanes' quads feed the west / east taps)
+                const int at = r * LW + c0;
+                float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
+                ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
+                ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
+                ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
+                if constexpr (VAR & 4) {
+                    float t[4];
+                    ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
+                    ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
+                } else {
+                    // west / east neighbours from the neighbouring lanes' registers instead of LDS (a narrowed,
+                    // lane-strided ds_read_b32 there is a 4-way bank conflict).  At q = 0 / QW-1 the value comes
+                    // from another row: those are region-edge columns, never valid in any pass.
 #pragma unroll
-                        for (int f = 0; f < 3; f++) {
-                            wl[f] = lane_below(c4[f][3]);
-                            er[f] = lane_above(c4[f][0]);
-                        }
-                    }
-                    bool redo = false;
-                    if (col_on) {
-                        const int gy = y0 + r;
-                        if constexpr (VAR & 1) quad_row(u, gy, c4, n4, s4, wl, er, edge_tag, std::true_type{});
-                        else redo = !quad_row(u, gy, c4, n4, s4, wl, er, edge_tag, std::false_type{});
-                    }
-                    if (__builtin_expect(redo, 0)) {
-                        // rare: a denominator out of range.  Reload the row (so that nothing has to stay in registers
-                        // for this path; LDS still holds the previous pass) and divide literally.
-                        float c4r[3][4], n4r[3][4], s4r[3][4], wlr[3], err[3];
-                        ld4(f0 + at, c4r[0]); ld4(f1 + at, c4r[1]); ld4(f2 + at, c4r[2]);
-                        ld4(f0 + at - LW, n4r[0]); ld4(f1 + at - LW, n4r[1]); ld4(f2 + at - LW, n4r[2]);
-                        ld4(f0 + at + LW, s4r[0]); ld4(f1 + at + LW, s4r[1]); ld4(f2 + at + LW, s4r[2]);
-                        wlr[0] = f0[at - 1]; wlr[1] = f1[at - 1]; wlr[2] = f2[at - 1];
-                        err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
-                        quad_row(u, y0 + r, c4r, n4r, s4r, wlr, err, edge_tag, std::true_type{});
+                    for (int f = 0; f < 3; f++) {
+                        wl[f] = lane_below(c4[f][3]);
+                        er[f] = lane_above(c4[f][0]);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
+                bool redo = false;
+                const int gy = y0 + r;
+                if (col_on) {
+                    if constexpr (VAR & 1) quad_row(u, gy, c4, n4, s4, wl, er, std::true_type{});
+                    else redo = !quad_row(u, gy, c4, n4, s4, wl, er, std::false_type{});
+                }
+                if (__builtin_expect(redo, 0)) {
+                    // rare: a denominator out of range.  Reload the row (so that nothing has to stay in registers
+                    // for this path; LDS still holds the previous pass) and divide literally.
+                    float c4r[3][4], n4r[3][4], s4r[3][4], wlr[3], err[3];
+                    ld4(f0 + at, c4r[0]); ld4(f1 + at, c4r[1]); ld4(f2 + at, c4r[2]);
+                    ld4(f0 + at - LW, n4r[0]); ld4(f1 + at - LW, n4r[1]); ld4(f2 + at - LW, n4r[2]);
+                    ld4(f0 + at + LW, s4r[0]); ld4(f1 + at + LW, s4r[1]); ld4(f2 + at + LW, s4r[2]);
+                    wlr[0] = f0[at - 1]; wlr[1] = f1[at - 1]; wlr[2] = f2[at - 1];
+                    err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
+                    quad_row(u, gy, c4r, n4r, s4r, wlr, err, std::true_type{});
+                }
+                if (!(VAR & 2) && edge_nw && col_on) {  // row 0 / column 0 (and anything left / above the image) keeps its value
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (gy <= 0 || gx0 + i <= 0) {
+#pragma unroll
+                            for (int f = 0; f < 3; f++) nv[u][f][i] = c4[f][i];
+                        }
+                }
             }
-        };
-        if (interior) pass(std::false_type{});
-        else pass(std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < MAXR; u++) {
@@ -1002,6 +1011,21 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
         __syncthreads();
+        if (!(VAR & 2) && (edge_e || edge_s)) {  // re-establish the east / south replicas
+            if (edge_e) {
+                const int cW = W - x0;
+                for (int r = tid; r < LH; r += NT) {
+                    f0[r * LW + cW] = f0[r * LW + cW - 1]; f1[r * LW + cW] = f1[r * LW + cW - 1]; f2[r * LW + cW] = f2[r * LW + cW - 1];
+                }
+            }
+            if (edge_s) {
+                const int rH = H - y0;
+                for (int c = tid; c < RWID; c += NT) {
+                    f0[rH * LW + c] = f0[(rH - 1) * LW + c]; f1[rH * LW + c] = f1[(rH - 1) * LW + c]; f2[rH * LW + c] = f2[(rH - 1) * LW + c];
+                }
+            }
+            __syncthreads();
+        }
     }
 
     if (do_box) {
