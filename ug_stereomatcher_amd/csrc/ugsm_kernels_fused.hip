@@ -782,23 +782,22 @@ __device__ __forceinline__ float lane_above(float v)  // from lane + 1
 }
 
 // smoothKernel divides the three weighted sums of a pixel by the same sumCorr (MatchLib.cu:1131-1139).
-// Exact shortcut: one reciprocal in binary64, refined to <= 2^-53 relative error (two Newton steps from
-// v_rcp_f32), then q_f = RN32(RN64(a_f * r)).  The binary64 product is within 2^-51.4 (relative) of the
+// Exact shortcut: one reciprocal in binary64, refined to <= 2^-53 relative error (one third-order step from
+// v_rcp_f32: r0 (1 + e + e^2), three FMAs), then q_f = RN32(RN64(a_f * r)).  The binary64 product is within 2^-51.4 (relative) of the
 // true quotient, and a quotient of two binary32 numbers is never closer than 2^-49 (relative) to a
 // binary32 rounding boundary (x/y - m = (X*2^k - M*Y)*2^(b+c)/y with X, Y < 2^24, M < 2^25 odd: a nonzero
 // integer over Y), so the final rounding equals that of the IEEE binary32 quotient, overflow and
-// subnormal results included.  16 VALU operations for three quotients instead of 36.  A quad with any
+// subnormal results included.  15 VALU operations for three quotients instead of 36.  A quad with any
 // denominator outside [2^-64, 2^64] (zero, negative, NaN, Inf, tiny) redoes those pixels with the literal
 // division.  tests: test_smooth_division_*.
 __device__ __forceinline__ bool div3_shared_ok(const float s) { return s >= 0x1p-64f && s <= 0x1p64f; }
 __device__ __forceinline__ void div3_shared(const float a0, const float a1, const float a2, const float s, float &q0, float &q1, float &q2)
 {
     const double sd = (double)s;
-    double r = (double)__builtin_amdgcn_rcpf(s);
-    double e = __builtin_fma(-sd, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    e = __builtin_fma(-sd, r, 1.0);
-    r = __builtin_fma(e, r, r);
+    const double r0 = (double)__builtin_amdgcn_rcpf(s);  // relative error e, |e| <= 2^-22
+    const double e = __builtin_fma(-sd, r0, 1.0);         // e = 1 - s*r0, exact up to 2^-75
+    const double t = __builtin_fma(e, e, e);              // e + e^2
+    const double r = __builtin_fma(r0, t, r0);            // r0 (1 + e + e^2) = (1 - e^3) / s
     q0 = (float)((double)a0 * r);
     q1 = (float)((double)a1 * r);
     q2 = (float)((double)a2 * r);
