@@ -210,6 +210,11 @@ int ugsm_reset_kernel_stats(ugsm_ctx *ctx);
 /* Device-memory helpers so a C/C++ host (the ROS node) needs no HIP headers. */
 int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes);
 int ugsm_dev_free(ugsm_ctx *ctx, void *d_ptr);
+/* Page-locked host memory (optional): images and result planes placed here make the host<->device copies
+ * of ugsm_match_full / ugsm_match_foveated plain DMA (the reference's node mallocs and frees its planes,
+ * UG_GPU_matcher.cpp:414-418; a node that adopts these two calls keeps them for the life of the context). */
+int ugsm_host_alloc(ugsm_ctx *ctx, void **h_ptr, long long bytes);
+int ugsm_host_free(ugsm_ctx *ctx, void *h_ptr);
 int ugsm_copy_to_device(ugsm_ctx *ctx, void *d_dst, const void *h_src, long long bytes);
 int ugsm_copy_to_host(ugsm_ctx *ctx, void *h_dst, const void *d_src, long long bytes);
 

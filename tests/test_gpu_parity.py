@@ -679,3 +679,23 @@ def test_match_fov1_is_stack_plus_hierarchical(lib, orc):
     exp = orc.reconstruct_full(est, 400, 300, 9)
     assert_bit_equal(got, exp, "match(fov=1) vs oracle")
     assert_bit_equal(two, got, "matchStack + hierarchicalDisparity vs match(fov=1)")
+
+
+def test_page_locked_host_buffers_give_the_same_result(lib):
+    """ugsm_host_alloc: images and result planes in page-locked memory go through the same entry point."""
+    from ug_stereomatcher_amd import synth
+    W, H = 320, 240
+    L, R, *_ = synth.make_pair(W, H, seed=21)
+    ctx = lib.Context(levels=8)
+    try:
+        ref = np.empty((3, H, W), np.float32)
+        ctx.check(ctx.lib.ugsm_match_full(ctx.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, ref[0].ctypes.data, ref[1].ctypes.data, ref[2].ctypes.data))
+        pl, pr, out = ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W))
+        pl[...] = L
+        pr[...] = R
+        ctx.check(ctx.lib.ugsm_match_full(ctx.handle, pl.ctypes.data, pr.ctypes.data, W, H, 3 * W, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        got = np.array(out)
+        del pl, pr, out
+    finally:
+        ctx.close()
+    assert_bit_equal(got, ref, "page-locked vs pageable host buffers")

@@ -31,7 +31,7 @@ EXPORTS = [
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_get_kernel_stats",
-    "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
+    "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
 
 
@@ -105,6 +105,8 @@ def load():
     lib.ugsm_reset_kernel_stats.argtypes = [vp]
     lib.ugsm_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]
     lib.ugsm_dev_free.argtypes = [vp, vp]
+    lib.ugsm_host_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]
+    lib.ugsm_host_free.argtypes = [vp, vp]
     lib.ugsm_copy_to_device.argtypes = [vp, vp, vp, C.c_longlong]
     lib.ugsm_copy_to_host.argtypes = [vp, vp, vp, C.c_longlong]
     _lib = lib
@@ -168,6 +170,7 @@ class Context:
         cfg.device, cfg.levels, cfg.fovea_levels, cfg.slots = device, levels, min(fovea_levels, levels), slots
         cfg.kernel_path, cfg.profile_events = kernel_path, int(profile_events)
         self.cfg = cfg
+        self._pinned = []
         self._h = C.c_void_p()
         st = lib.ugsm_create(C.byref(cfg), C.byref(self._h))
         if st:
@@ -177,6 +180,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.ugsm_host_free(self._h, p)
+            self._pinned = []
             self.lib.ugsm_destroy(self._h)
             self._h = None
 
@@ -219,6 +225,15 @@ class Context:
         out = np.empty(shape, dtype)
         self.check(self.lib.ugsm_copy_to_host(self._h, out.ctypes.data, ptr, out.nbytes))
         return out
+
+    def host_array(self, shape, dtype=np.float32) -> np.ndarray:
+        """A numpy array in page-locked host memory (ugsm_host_alloc); freed when the context closes."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self.check(self.lib.ugsm_host_alloc(self._h, C.byref(p), nbytes))
+        self._pinned.append(p.value)
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def triangulate(self, d_dispx: int, d_dispy: int, W: int, H: int, P1, P2, d_xyz: int, slot: int = 0):
         """SURVEY 8f row f-1 (getPointCloud.cpp:886-949): X, Y, Z planes from device (dx, dy) planes."""

@@ -968,6 +968,25 @@ int ugsm_dev_free(ugsm_ctx *ctx, void *d_ptr)
     if (d_ptr) HIPCHK(ctx, hipFree(d_ptr));
     return UGSM_OK;
 }
+// Page-locked host memory for callers that can place their images / result planes in it: the copies of
+// ugsm_match_* then run as plain DMA instead of being staged through the runtime's bounce buffers.
+int ugsm_host_alloc(ugsm_ctx *ctx, void **h_ptr, long long bytes)
+{
+    if (!ctx || !h_ptr || bytes < 0) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    hipError_t e = hipHostMalloc(h_ptr, (size_t)std::max<long long>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipHostMalloc failed: ") + hipGetErrorString(e);
+        return UGSM_ERR_NOMEM;
+    }
+    return UGSM_OK;
+}
+int ugsm_host_free(ugsm_ctx *ctx, void *h_ptr)
+{
+    if (!ctx) return UGSM_ERR_BAD_ARG;
+    if (h_ptr) HIPCHK(ctx, hipHostFree(h_ptr));
+    return UGSM_OK;
+}
 int ugsm_copy_to_device(ugsm_ctx *ctx, void *d_dst, const void *h_src, long long bytes)
 {
     if (!ctx || !d_dst || !h_src || bytes < 0) return UGSM_ERR_BAD_ARG;
