@@ -408,6 +408,28 @@ def test_16mp_determinism_and_sanity(lib):
         c.close()
 
 
+def test_16mp_full_and_foveated_vs_oracle_bit_exact(lib, orc):
+    """BASELINE configs[2] and configs[3] at their full size against the live oracle (about 3 s of CPU on the GPU
+    box's 16 threads for the full pyramid): every one of the 3 x 16.1 M output floats identical, RMSE 0."""
+    from ug_stereomatcher_amd import MatchGPULib, synth
+    W, H = 4928, 3264
+    L, R, *_ = synth.make_pair(W, H, synth.BASE_SEED + 2)
+    orc.set_num_threads(16)
+    m = MatchGPULib()
+    try:
+        got = m.match(L, R, 0)
+        exp = orc.match_full(L, R, 14)
+        assert_bit_equal(got, exp, "16 MP full pyramid vs oracle")
+        rmse = float(np.sqrt(np.mean((got[:2].astype(np.float64) - exp[:2].astype(np.float64)) ** 2)))
+        assert rmse == 0.0     # north_star's tolerance is RMSE < 1e-3 px; the float contract makes it exactly 0
+        stk = m.matchStack(L, R)
+        est, _, _ = orc.match_foveated(L, R, 14, 7)
+        assert_bit_equal(np.transpose(stk, (1, 0, 2, 3)), est, "16 MP foveated stack vs oracle")
+    finally:
+        m.close()
+        orc.set_num_threads(8)
+
+
 def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
     """ros/MatchGPULib_ugsm.hpp (the class the ROS node includes) against the built library,
     without OpenCV/ROS: ros/shim_selftest.cpp supplies a struct with cv::Mat's field names."""
