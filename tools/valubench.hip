@@ -43,6 +43,8 @@
 #define B_MOV(i) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
 #define B_CMPCND(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
 #define B_CMPCND64(i) asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[20:21]" : "+v"(a[i]) : "v"(b), "v"(c) : "s20", "s21");
+#define B_MINIMUM3(i) asm volatile("v_minimum3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
+#define B_MIN3(i) asm volatile("v_min3_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
 #define B_FMA64(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 #define B_MUL64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
 #define B_ADD64(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[i]) : "v"(b));
@@ -78,6 +80,8 @@ __global__ __launch_bounds__(256) void k_cnd_vccinit(float *out, int iters)
     }
     out[blockIdx.x * 256 + threadIdx.x] = a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7];
 }
+KERNEL(k_minimum3, DECLF, B_MINIMUM3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_min3, DECLF, B_MIN3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_dpp, DECLF, B_DPP, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_fma64, DECLD, B_FMA64, (float)(a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7]))
 KERNEL(k_mul64, DECLD, B_MUL64, (float)(a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7]))
@@ -129,7 +133,7 @@ int main()
         printf("%-16s %d wave/SIMD  %6.2f cycles per wave-instruction (at nominal clock)\n", name, wg_per_cu, cyc);
     };
 #define RUN(k) run(#k, k, 1); run(#k, k, 4);
-    RUN(k_fma) RUN(k_mul) RUN(k_add) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma) RUN(k_rcp) RUN(k_dscale) RUN(k_dfmas) RUN(k_dfix) RUN(k_cnd) RUN(k_cnd_vccinit) RUN(k_cmp_cnd_vcc) RUN(k_cmp_cnd_sgpr) RUN(k_cnd64) RUN(k_cnd_nodep) RUN(k_max) RUN(k_med3) RUN(k_cmp_vcc) RUN(k_cmp_sgpr) RUN(k_mov) RUN(k_dpp)
+    RUN(k_fma) RUN(k_mul) RUN(k_add) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma) RUN(k_rcp) RUN(k_dscale) RUN(k_dfmas) RUN(k_dfix) RUN(k_minimum3) RUN(k_min3) RUN(k_cnd) RUN(k_cnd_vccinit) RUN(k_cmp_cnd_vcc) RUN(k_cmp_cnd_sgpr) RUN(k_cnd64) RUN(k_cnd_nodep) RUN(k_max) RUN(k_med3) RUN(k_cmp_vcc) RUN(k_cmp_sgpr) RUN(k_mov) RUN(k_dpp)
     RUN(k_fma64) RUN(k_mul64) RUN(k_add64) RUN(k_rcp64) RUN(k_cvt_f64_f32) RUN(k_cvt_f32_f64)
     return 0;
 }

@@ -131,9 +131,11 @@ __device__ __forceinline__ float div3_nonneg(float x)
     return __builtin_fmaf(r, c, q);
 }
 // MoveCorrelation (MatchLib.cu:681-687): N*N >= +0 and A*B >= +0 (or NaN), so the quotient is never
-// negative and the "< 0" arm of the clamp is dead; NaN (0/0) still passes through untouched.
+// negative (and never -0) and the "< 0" arm of the clamp is dead; NaN (0/0) still passes through.
 __device__ __forceinline__ float ncc2_nn(float n, float a, float b)
 {
+    // (IEEE-754-2019 minimum, one v_minimum3_f32 on gfx950, has the same NaN-keeping semantics as this compare +
+    // select pair, but measured 4 % slower on the whole kernel: 550 vs 527 us at 16 MP)
     float v = (n * n) / (a * b);
     if (v > 1.0f) v = 1.0f;
     return v;
