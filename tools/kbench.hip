@@ -1,5 +1,5 @@
 // kbench -- stand-alone timing harness for the fused kernels (development tool, not product).
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/kbench.hip -o tools/kbench
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Iinclude tools/kbench.hip -o tools/kbench
 //   ./kbench [W H reps]
 // Times k_cost_fused and k_smooth_fused on one level-sized random problem with HIP events.
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
@@ -20,6 +20,12 @@ int main(int argc, char **argv)
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (size_t i = 0; i < 3 * n; i++) { hL[i] = 1 + 254 * rnd(); hR[i] = 1 + 254 * rnd(); }
     for (size_t i = 0; i < n; i++) { int x = i % W, y = i / W; hd[i] = 30.0f * sinf(x * 0.002f) * cosf(y * 0.003f) + 0.3f * (rnd() - 0.5f); hd[n + i] = 0.75f * sinf(y * 0.002f) + 0.3f * (rnd() - 0.5f); hd[2 * n + i] = 0.3f + 0.7f * rnd(); }
+    if (argc > 5) {  // real data: 9 planes of W*H floats (L0 L1 L2 R0 R1 R2 dx dy conf), e.g. from tools/kbench_real.py
+        FILE *f = fopen(argv[5], "rb");
+        if (!f || fread(hL.data(), 4, 3 * n, f) != 3 * n || fread(hR.data(), 4, 3 * n, f) != 3 * n || fread(hd.data(), 4, 3 * n, f) != 3 * n) { printf("cannot read %s\n", argv[5]); return 1; }
+        fclose(f);
+        printf("inputs from %s\n", argv[5]);
+    }
     float *L, *R, *A, *d, *o;
     CK(hipMalloc(&L, 12 * n)); CK(hipMalloc(&R, 12 * n)); CK(hipMalloc(&A, 12 * n)); CK(hipMalloc(&d, 12 * n)); CK(hipMalloc(&o, 12 * n));
     CK(hipMemcpy(L, hL.data(), 12 * n, hipMemcpyHostToDevice)); CK(hipMemcpy(R, hR.data(), 12 * n, hipMemcpyHostToDevice));
