@@ -91,6 +91,11 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record HIP events on slot 0")
     ap.add_argument("--all-events", action="store_true", help="bracket every kernel class, not only the dominant one (slower)")
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1 on the way
+    # (the RCCL version banner at communicator creation, driver notices) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -226,7 +231,8 @@ def main():
             except Exception as e:  # the baseline leg must never take the measurement down
                 result["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
                                           "sample": f"failed: {e}"}
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     ctx.close()
     import torch.distributed as td
     if td.is_initialized():
