@@ -191,6 +191,29 @@ def test_smooth_interior_tiles_and_degenerate_confidence(ctx, orc):
                 assert_bit_equal(got, exp, f"{W}x{H} {variant} passes={passes} box={box}")
 
 
+def test_smooth_borders_at_tile_multiples(ctx, orc):
+    """The replica / repair border scheme of K-smooth at image sizes one below, at and one above multiples of each
+    tile shape (112x36 for >= 2^19 px, 64x32, 32x16), so that the image edge falls on the tile edge, inside the halo of the
+    neighbouring tile, and one pixel into a new tile."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    sizes = [(1007, 539), (1008, 540), (1009, 541), (1120, 469),          # 112x36 tiles
+             (511, 287), (512, 288), (513, 289),                          # 64x32 tiles
+             (95, 47), (96, 48), (97, 49), (33, 17), (31, 15), (5, 3), (1, 40), (40, 1)]   # 32x16 tiles
+    for (W, H) in sizes:
+        d = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 3, (H, W)), 0.1 + 0.9 * rng.random((H, W))]).astype(np.float32)
+        for passes, box in [(5, 1), (5, 0)]:
+            exp = d
+            for _ in range(passes):
+                exp = orc.smooth_pass(exp)
+            if box:
+                exp = orc.box3(exp)
+            p = ctx.to_device(d)
+            ctx.check(ctx.lib.ugsm_stage_smooth(ctx.handle, p, W, H, passes, box))
+            got = ctx.to_host(p, d.shape)
+            ctx.free(p)
+            assert_bit_equal(got, exp, f"{W}x{H} passes={passes} box={box}")
+
+
 def test_seed_stage(ctx, orc):
     rng = np.random.Generator(np.random.PCG64(31))
     src = rng.normal(0, 5, (3, 70, 99)).astype(np.float32)
