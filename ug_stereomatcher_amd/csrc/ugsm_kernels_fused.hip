@@ -1,6 +1,7 @@
 // ugsm_kernels_fused.hip -- kernel_path 0: the production gfx950 kernels.
 //
-// K-cost  (k_cost_fused):   one matcher iteration's warp + 5-shift squared-NCC cost (3 channels) +
+// K-cost  (k_cost_split; k_cost_fused = the one-thread-per-quad variant kept for A/B):
+//                           one matcher iteration's warp + 5-shift squared-NCC cost (3 channels) +
 //                           parabola + confidence blend + disparity update, one launch, LDS tiled.
 // K-smooth (k_smooth_fused): up to 5 confidence-weighted Jacobi passes + the 3x3 box, one launch.
 // K-pyr / K-sq:             blur+decimate evaluated only at the sampled sites; G_clamp*(L^2).
@@ -21,9 +22,9 @@ namespace ugsm {
 // K-cost
 // =========================================================================================
 //
-// Tile TX x TY = 32 x 28 output pixels per 256-thread workgroup (4 waves).  A thread owns a
-// "quad" (4 consecutive x) so that every LDS access is a 16-byte ds_read/write_b128; thread
-// (row = tid&31, qx = tid>>5) -> tile row `row`, quad column qx.
+// Tile TX x TY = 32 x 28 output pixels per workgroup: 256 threads in k_cost_fused (a thread owns a "quad", 4
+// consecutive x, so that every LDS access is a 16-byte ds_read/write_b128; thread (row = tid&31, qx = tid>>5)
+// -> tile row `row`, quad column qx), 512 in the production k_cost_split (two threads per quad, below).
 //
 // LDS images (float, tile-relative column c stored at [c + OX]):
 //   sR    [34][52]  R' = warped right plane, tile+halo3, edge-replicated (texture clamp)   OX=8
@@ -31,7 +32,8 @@ namespace ugsm {
 //   sRow  [5][32][36] row-pass of the five product images, rows tile+halo2
 //   sBrow [34][44]  row-pass of R'^2, rows tile+halo3, cols tile+halo4                       OX=4
 //   sB    [30][44]  B = G_clamp*(R'^2), tile+halo1 (only in-image entries are ever read)     OX=4
-// = 47.0 KB -> 3 workgroups (12 waves) per CU.
+//   sA    [28][36]  A = G_clamp*(L^2) of the tile, current channel
+// = 51 KB; k_cost_split: 96 VGPRs -> 2 workgroups (16 waves) per CU.
 //
 // Per channel: P1 fill sL,sR | barrier | P2 row passes | barrier | P2.5 B column pass | barrier |
 // P3 column pass of the 5 products + correlation, accumulated over channels in registers.
@@ -39,7 +41,8 @@ namespace ugsm {
 // (row = tid & 31, quad column = tid >> 5): the 16-lane groups of ds_read_b128 then hit 16 distinct
 // 4-bank slots (odd multiplier mod 16 is a bijection) -- conflict-free; with lanes walking along a
 // row the same reads cost 2-3x (rows of 40/48 floats alias in the 64 banks).  Measured:
-// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 47 % -> see profiles/.
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE still reads 47 %; tools/ldsbench.hip times these layouts within 5 % of
+// the conflict-free floor.
 constexpr int TX = 32, TY = 28;
 constexpr int SR_W = TX + 20, SR_H = TY + 6, SR_OX = 8;
 constexpr int SL_W = TX + 12, SL_H = TY + 4, SL_OX = 4;
@@ -444,13 +447,13 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
 
 // -----------------------------------------------------------------------------------------
 // k_cost_split: the same tile and LDS images as k_cost_fused, but TWO threads per quad (512-thread
-// workgroup).  The kernel is latency-bound, not issue-bound (profiles/: 3 waves/SIMD reach ~40 % of
-// the VALU issue rate, and going to 2 waves/SIMD costs 30 %), and the LDS footprint per tile -- not
-// registers -- caps the wave count; so the waves per LDS byte are doubled by splitting each quad's
-// work by correlation shift:  role 0 (threads 0..255)  = shifts (-1,0), (+1,0), (0,0)  + parabola x
-//                             role 1 (threads 256..511) = shifts (0,-1), (0,+1), the R'^2 passes + parabola y.
-// The roles are wave-uniform (no divergence).  They meet once per tile: role 0 hands Q(0,0) to role 1,
-// role 1 hands rho_y back (two 3.5 KB LDS exchanges in the dead sRow planes).
+// workgroup): the LDS footprint per tile -- not registers -- caps the workgroups per CU, so the waves per LDS
+// byte are doubled by splitting each quad's work by correlation shift:
+//   role 0 (threads 0..255)   = shifts (-1,0), (+1,0), pixels 0,1 of shift (0,0), parabola x
+//   role 1 (threads 256..511) = shifts (0,-1), (0,+1), pixels 2,3 of shift (0,0), the R'^2 row pass, parabola y
+// (the B column pass is shared by both).  The roles are wave-uniform (no divergence).  They meet once per tile:
+// each publishes its two pixels of Q(0,0), then the x / y parabola results (LDS exchanges in the dead sRow planes).
+// Where the time goes (SQ counters, profiles/): 70 % VALU-busy at 4 waves/SIMD, 1 460 VALU instructions per wave.
 // development only (tools/kbench.hip, ABL & 256): s_memtime stamps at the phase boundaries of wave 0 (role 0) and
 // wave 4 (role 1) of the first workgroups, 16 stamps each
 __device__ long long *g_cost_stamps = nullptr;
