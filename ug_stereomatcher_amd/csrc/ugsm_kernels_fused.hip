@@ -1467,6 +1467,126 @@ __global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, fl
     }
 }
 
+// =========================================================================================
+// K-pyr-base: the three finest levels of one image in one pass over the rgb8 input --
+//   level 0 = the planar float image (MatchGPULib.cpp:332-338),
+//   level 1 = blur(level 0) sampled at floor((i+.5f)*(float)SCALE)   (MatchGPULib.cpp:1071-1087),
+//   level 2 = blur(level 0) sampled at floor((i+.5f)*2.0f)           (:1088-1096).
+// Separately (k_rgb_planes, then k_blur_decimate_tiled twice) level 0 is written once and read twice: 771 MB of
+// traffic per 16 MP image; here the rgb8 tile is read once and the three levels written: 385 MB.  Same arithmetic:
+// zero-padded row pass at the sampled columns of every region row (rounded to binary32), then the column pass at the
+// sampled rows.  One workgroup = a 64x16 tile of level 0 (+ halo 2); every level-1 / level-2 pixel belongs to the tile
+// that contains its sampling site, so each output is written exactly once.
+// =========================================================================================
+constexpr int BTX = 64, BTY = 16, BRW = BTX + 4, BRH = BTY + 4, BC1 = 52, BR1 = 16, BC2 = 32, BR2 = 8;
+
+__global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
+                                                  float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2)
+{
+    __shared__ float sS[3][BRH * BRW];
+    __shared__ float sT1[3][BRH * BC1];
+    __shared__ float sT2[3][BRH * BC2];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BTX, y0 = blockIdx.y * BTY;
+    const float sf1 = (float)1.41421356, sf2 = 2.0f;
+    {   // rgb8 -> float planes of tile + halo 2, zero outside the image (the blur's zero padding, U2/U3)
+        constexpr int NLD = (BRH * BRW + 255) / 256;
+        float v[NLD][3];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = min(tid + u * 256, BRH * BRW - 1);
+            const int r = it / BRW, c = it - r * BRW;
+            const int gx = x0 - 2 + c, gy = y0 - 2 + r;
+            const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const uint8_t *p = rgb + (size_t)min(max(gy, 0), H - 1) * stride + 3 * min(max(gx, 0), W - 1);
+            const float a = (float)p[0], b = (float)p[1], c2 = (float)p[2];
+            v[u][0] = in ? a : 0.0f;
+            v[u][1] = in ? b : 0.0f;
+            v[u][2] = in ? c2 : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * 256;
+            if (it < BRH * BRW) {
+                sS[0][it] = v[u][0];
+                sS[1][it] = v[u][1];
+                sS[2][it] = v[u][2];
+            }
+        }
+    }
+    __syncthreads();
+    {   // level 0: the tile itself, rows of 64 floats
+        const size_t n = (size_t)W * H;
+        for (int it = tid; it < BTX * BTY; it += 256) {
+            const int r = it / BTX, c = it - r * BTX;
+            const int gx = x0 + c, gy = y0 + r;
+            if (gx < W && gy < H) {
+                const size_t at = (size_t)gy * W + gx;
+                const int la = (r + 2) * BRW + c + 2;
+                lvl0[at] = sS[0][la];
+                lvl0[n + at] = sS[1][la];
+                lvl0[2 * n + at] = sS[2][la];
+            }
+        }
+    }
+    // candidate outputs of this tile: columns i = ib + lx, rows j = jb + ly; valid when the sampling site lies in the tile.
+    // Level 1: the sites in a 64-wide tile are at most 46 consecutive i starting 1..3 above ib1 (52 candidates cover a
+    // rounding slip of the float quotient); at most 12 rows, 16 candidates.  Level 2: site = 2i+1, exactly 32 x 8.
+    const int ib1 = max((int)((float)x0 / sf1) - 1, 0), jb1 = max((int)((float)y0 / sf1) - 1, 0);
+    const int ib2 = x0 / 2, jb2 = y0 / 2;
+    // row pass at the sampled columns, every region row, three channels
+    for (int it = tid; it < BRH * (BC1 + BC2); it += 256) {
+        const int r = it / (BC1 + BC2), l = it - r * (BC1 + BC2);
+        const bool one = l < BC1;
+        const int lx = one ? l : l - BC1;
+        const int i = (one ? ib1 : ib2) + lx;
+        if (i < (one ? W1 : W2)) {
+            const int site = tex_index(((float)i + 0.5f) * (one ? sf1 : sf2), W);
+            if (site >= x0 && site < x0 + BTX) {
+                const int c = site - (x0 - 2);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float *p = &sS[k][r * BRW + c];
+                    const float t = tap5(p[-2], p[-1], p[0], p[1], p[2]);
+                    if (one) sT1[k][r * BC1 + lx] = t;
+                    else sT2[k][r * BC2 + lx] = t;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // column pass at the sampled rows
+    for (int it = tid; it < BR1 * BC1 + BR2 * BC2; it += 256) {
+        const bool one = it < BR1 * BC1;
+        const int l = one ? it : it - BR1 * BC1;
+        const int cw = one ? BC1 : BC2;
+        const int ly = l / cw, lx = l - ly * cw;
+        const int i = (one ? ib1 : ib2) + lx, j = (one ? jb1 : jb2) + ly;
+        const int Wd = one ? W1 : W2, Hd = one ? H1 : H2;
+        if (i < Wd && j < Hd) {
+            const float sf = one ? sf1 : sf2;
+            const int sx = tex_index(((float)i + 0.5f) * sf, W), sy = tex_index(((float)j + 0.5f) * sf, H);
+            if (sx >= x0 && sx < x0 + BTX && sy >= y0 && sy < y0 + BTY) {
+                const int cy = sy - (y0 - 2);
+                float *dst = one ? lvl1 : lvl2;
+                const size_t nd = (size_t)Wd * Hd, at = (size_t)j * Wd + i;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float *p = (one ? &sT1[k][cy * BC1 + lx] : &sT2[k][cy * BC2 + lx]);
+                    dst[k * nd + at] = tap5(p[-2 * cw], p[-cw], p[0], p[cw], p[2 * cw]);
+                }
+            }
+        }
+    }
+}
+
+void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
+                     int H2)
+{
+    hipLaunchKernelGGL(k_pyr_base, dim3((W + BTX - 1) / BTX, (H + BTY - 1) / BTY), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
+                       H2);
+}
+
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
 {
     if (sf > 2.0f || sf < 1.0f) {  // region bound assumes 1 <= sf <= 2 (the reference uses sqrt2 and 2)

@@ -37,6 +37,8 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
+void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
+                     int H2);
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
 // X, Y, Z planes from the full-resolution (dx, dy) and the two 3x4 projection matrices
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);

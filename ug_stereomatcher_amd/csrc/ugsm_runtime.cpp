@@ -270,20 +270,25 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
 {
     const int levels = s.levels;
     const bool ref = ctx->cfg.kernel_path == 1;
-    {
+    // levels 0, 1, 2 in one pass over the rgb8 input (k_pyr_base); the one-stage-per-kernel path keeps the three launches
+    const bool base = !ref && levels >= 3;
+    if (base) {
+        Timer t(ctx, &s, si, KC_PYR, (double)s.W * s.H);
+        launch_pyr_base(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2]);
+    } else {
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
         launch_rgb_planes(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
     }
     // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
     for (int i = 0; i < levels; i++) {
-        if (i == 0 && levels > 1) {
+        if (i == 0 && levels > 1 && !base) {
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
             float sf = (float)kScale;
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
             else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
         }
-        if (i + 2 < levels) {
+        if (i + 2 < levels && !(base && i == 0)) {
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
