@@ -301,7 +301,8 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
 
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
 // result and `b` is scratch.
-int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, int H, int S, bool do_box)
+// final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
+int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, int H, int S, bool do_box, float *final_out = nullptr)
 {
     const double px = (double)W * H;
     if (ctx->cfg.kernel_path == 1) {
@@ -322,8 +323,13 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             left -= p;
             if (p == 0 && !do_box) break;
             Timer t(ctx, &s, si, KC_SMOOTH, px);
-            launch_smooth_fused(s.st, a, b, W, H, p, do_box && left == 0);
-            std::swap(a, b);
+            if (left == 0 && final_out) {
+                launch_smooth_fused(s.st, a, final_out, W, H, p, do_box);
+                a = final_out;
+            } else {
+                launch_smooth_fused(s.st, a, b, W, H, p, do_box && left == 0);
+                std::swap(a, b);
+            }
         } while (left > 0);
     }
     return UGSM_OK;
@@ -331,8 +337,10 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
 
 // matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
 // on entry and on exit; other is scratch of the same size.
+// final_out (optional, fused path only): where the last iteration leaves its result instead of the ping-pong buffer
+// (saves the device-to-device copy of the finished level); cur/other are then not meaningful afterwards.
 int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int mi, int S, bool is_top, int m_from,
-              int m_to, float *&cur, float *&other, float *dbg8)
+              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr)
 {
     const bool ref = ctx->cfg.kernel_path == 1;
     const double px = (double)W * H;
@@ -361,7 +369,8 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
         float *a = other, *b = cur;
-        UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true));
+        UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true, (m == m_to && !ref) ? final_out : nullptr));
+        if (m == m_to && !ref && final_out) break;
         cur = a;
         other = b;
     }
@@ -394,8 +403,11 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
     for (int i = top; i >= 0; i--) {
         const int mi = level_iterations(i);
+        // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
+        const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0;
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr));
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr));
+        if (direct) return UGSM_OK;
         if (i > 0) {
             Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
             launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
