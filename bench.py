@@ -212,16 +212,22 @@ def main():
             achieved = BYTES_PER_PIXEL_ITER * dom["pixel_launches"] / (dom["total_ms"] * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            valu_busy = None
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(dom["name"])
+                    pj = json.load(open(tpath))
+                    traffic = pj.get(args.workload, {}).get(dom["name"])
+                    valu_busy = pj.get("valu_insts_per_simd_cycle_level0", {}).get(dom["name"])
                 except Exception:
                     traffic = None
             result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom["name"],
                                   "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
                                   "algorithmic_bytes_per_launch_avg": BYTES_PER_PIXEL_ITER * dom["pixel_launches"] / dom["launches"],
-                                  "note": "48 B per pixel-iteration x pixels per launch / HIP-event duration, slot 0, timed region"}
+                                  "valu_insts_per_simd_cycle_level0": valu_busy,
+                                  "note": "48 B per pixel-iteration x pixels per launch / HIP-event duration, slot 0, timed region; the kernel is "
+                                          "bound by VALU issue, not bytes: valu_insts_per_simd_cycle_level0 = SQ_INSTS_VALU / (SQ_BUSY_CU_CYCLES x 4) "
+                                          "from profiles/, times ~3.3 cycles per instruction of this mix = busy fraction (DESIGN.md section 6)"}
             # whole-pair figure: all algorithmic bytes of a pair / the pair's share of wall time
             result["whole_pair_algorithmic_GBps"] = (BYTES_PER_PIXEL_ITER * pi * value / n_gpus) / 1e9
         result["kernels"] = kernels

@@ -55,7 +55,25 @@ for k in sorted(rd, key=lambda k: -sum(rd[k]["TCC_EA0_RDREQ_sum"])):
         traffic[k.split("<")[0]] = (rb + w) / n
     lines.append(f"| {k} | {n} | {rb / n / 1e6:.2f} | {f / n / 1e6:.2f} | {w / n / 1e6:.2f} | {a} | {ratio} |")
 open(f"{out}/{tag}_hbm_traffic.md", "w").write("\n".join(lines) + "\n")
-json.dump({"full16mp": traffic,
+# VALU issue rate of the two hot kernels at level 0: SQ_INSTS_VALU (pass sq1) per SIMD cycle (SQ_BUSY_CU_CYCLES of pass sq2
+# x 4 SIMDs), largest grid of each kernel.  Times the mean issue cost of the mix (tools/valubench: 3.0 cycles for plain
+# binary32 operations up to 8.4 for v_rcp_f32; about 3.3 for these kernels) this is the busy fraction of the VALU.
+def _largest(agg, prefix, counter):
+    f = glob.glob(f"{base}/{agg}/**/*counter_collection.csv", recursive=True)[0]
+    rows = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ugsm::", "")
+        if name.startswith(prefix) and r["Counter_Name"] == counter:
+            rows[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
+    g = max(rows)
+    return sum(rows[g]) / len(rows[g])
+valu_busy = {}
+for kname, prefix in (("k_cost_split", "k_cost_split"), ("k_smooth_fused", "k_smooth_fused<112")):
+    try:
+        valu_busy[kname] = round(_largest("pmc_sq1", prefix, "SQ_INSTS_VALU") / (4.0 * _largest("pmc_sq2", prefix, "SQ_BUSY_CU_CYCLES")), 4)
+    except Exception:  # a pass without those counters
+        valu_busy[kname] = None
+json.dump({"full16mp": traffic, "valu_insts_per_simd_cycle_level0": valu_busy,
            "_note": "HBM bytes per launch (mean over the 218 launches of a 16 MP pair) of the dominant kernel: exact read bytes from "
                     f"the size-binned TCC_EA0_RDREQ counters + WRITE_SIZE; see profiles/{tag}_hbm_traffic.md"},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)

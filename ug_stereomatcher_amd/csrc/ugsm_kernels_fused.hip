@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void k_cost_fused(Img3 L, Img3 R, const float 
 //   role 1 (threads 256..511) = shifts (0,-1), (0,+1), pixels 2,3 of shift (0,0), the R'^2 row pass, parabola y
 // (the B column pass is shared by both).  The roles are wave-uniform (no divergence).  They meet once per tile:
 // each publishes its two pixels of Q(0,0), then the x / y parabola results (LDS exchanges in the dead sRow planes).
-// Where the time goes (SQ counters, profiles/): 70 % VALU-busy at 4 waves/SIMD, 1 460 VALU instructions per wave.
+// Where the time goes (SQ counters, profiles/): 1 880 VALU instructions per wave, 0.23 per SIMD cycle at 4 waves/SIMD,
+// about three quarters of the issue capacity at the measured ~3.3 cycles per instruction.
 // development only (tools/kbench.hip, ABL & 256): s_memtime stamps at the phase boundaries of wave 0 (role 0) and
 // wave 4 (role 1) of the first workgroups, 16 stamps each
 __device__ long long *g_cost_stamps = nullptr;
