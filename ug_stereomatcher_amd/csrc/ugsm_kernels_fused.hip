@@ -14,6 +14,7 @@
 // Citations: /root/reference/src/gpu_matcher/<file>:<line>.
 #include "ugsm_device.hpp"
 #include "ugsm_launch.hpp"
+#include <atomic>
 #include <type_traits>
 
 namespace ugsm {
@@ -1337,10 +1338,15 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 {
     constexpr int LW = STX + 20, LH = STY + 14;
     constexpr size_t bytes = 3 * (size_t)LH * LW * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: a process may hold contexts on several devices (the launch is made with the context's
+    // device current); std::atomic so that contexts driven from different host threads do not race on the mask
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        attr_set = true;
+        attr_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + STY - 1) / STY);
     hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles);
