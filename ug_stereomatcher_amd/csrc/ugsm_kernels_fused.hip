@@ -470,27 +470,22 @@ __device__ long long *g_cost_stamps = nullptr;
 #ifndef UGSM_SPLIT_WAVES
 #define UGSM_SPLIT_WAVES 4  // waves per SIMD the register allocation aims at (2 workgroups per CU)
 #endif
-template <int ABL, int WAVES = UGSM_SPLIT_WAVES>
-__global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
-                                                    float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles)
+// The body of k_cost_split.  INTERIOR: the tile and its halo of 3 lie inside the image, so the address clamps of P0, the
+// zero-padding and validity selects, the clamped B fetches of P3 and the store bounds are compiled out (a workgroup-uniform
+// choice made by the kernel below; about 95 % of the tiles of a 16 MP level).
+template <int ABL, bool INTERIOR>
+__device__ __forceinline__ void cost_split_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
+                                                float *__restrict__ nd3, const int W, const int H, const float thr, const int blend, const int x0,
+                                                const int y0, float *__restrict__ sR, float *__restrict__ sL, float *__restrict__ sRow,
+                                                float *__restrict__ sBrow, float *__restrict__ sB, float *__restrict__ sA)
 {
-    __shared__ __attribute__((aligned(16))) float sR[SR_H * SR_W];
-    __shared__ __attribute__((aligned(16))) float sL[SL_H * SL_W];
-    __shared__ __attribute__((aligned(16))) float sRow[5 * ROW_H * ROW_W];
-    __shared__ __attribute__((aligned(16))) float sBrow[SBROW_H * SB_W];
-    __shared__ __attribute__((aligned(16))) float sB[SB_H * SB_W];
-    __shared__ __attribute__((aligned(16))) float sA[TY * ROW_W];
-
     const int tid = threadIdx.x;
     const int role = tid >> 8, t = tid & 255;
-    int tile_x, tile_y;
-    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
-    const int x0 = tile_x * TX, y0 = tile_y * TY;
     const size_t n = (size_t)W * H;
     const int trow = t & 31, qx = t >> 5;  // 32 rows x 8 quad columns, lanes walk down the rows
     const int cx = qx * 4;
     const int gy = y0 + trow, gx0 = x0 + cx;
-    const bool live = trow < TY && gy < H && gx0 < W;
+    const bool live = INTERIOR ? (trow < TY) : (trow < TY && gy < H && gx0 < W);
     UGSM_STAMP(0);
 
     // ---- P0: all global reads of the tile up front (see k_cost_fused).  Every load is unconditional on a
@@ -513,8 +508,8 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         for (int u = 0; u < NR; u++) {  // (dx,dy) at the pixels whose warped fetch the tile needs
             const int it = min(tid + u * 512, IDX_H * IDX_W - 1);
             const int r = it / IDX_W, c = it - r * IDX_W;
-            gxh[u] = clampi(x0 + c - 3, 0, W - 1);
-            gyh[u] = clampi(y0 + r - 3, 0, H - 1);
+            gxh[u] = INTERIOR ? x0 + c - 3 : clampi(x0 + c - 3, 0, W - 1);
+            gyh[u] = INTERIOR ? y0 + r - 3 : clampi(y0 + r - 3, 0, H - 1);
             const unsigned off = ((unsigned)gyh[u] * (unsigned)W + (unsigned)gxh[u]) * 4u;
             ddx[u] = ld_at(Db[0], off);
             ddy[u] = ld_at(Db[1], off);
@@ -525,8 +520,9 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
             const int it = min(tid + u * 512, SL_H * (TX + 4) - 1);
             const int r = it / (TX + 4), c = it - r * (TX + 4);  // c: tile column + 2
             const int gxl = x0 + c - 2, gyl = y0 + r - 2;
-            const bool in = gxl >= 0 && gxl < W && gyl >= 0 && gyl < H;
-            const unsigned off = ((unsigned)clampi(gyl, 0, H - 1) * (unsigned)L.pitch + (unsigned)clampi(gxl, 0, W - 1)) * 4u;
+            const bool in = INTERIOR || (gxl >= 0 && gxl < W && gyl >= 0 && gyl < H);
+            const unsigned off = INTERIOR ? ((unsigned)gyl * (unsigned)L.pitch + (unsigned)gxl) * 4u
+                                          : ((unsigned)clampi(gyl, 0, H - 1) * (unsigned)L.pitch + (unsigned)clampi(gxl, 0, W - 1)) * 4u;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float t = ld_at(Lb[k], off);
@@ -552,7 +548,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
     for (int u = 0; u < NA; u++) {
         const int it = tid + u * 512;
         const int r = it / TX, c = it - r * TX;
-        const bool in = it < TX * TY && x0 + c < W && y0 + r < H;
+        const bool in = it < TX * TY && (INTERIOR || (x0 + c < W && y0 + r < H));
         const unsigned off = in ? ((unsigned)(y0 + r) * (unsigned)W + (unsigned)(x0 + c)) * 4u : 0u;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
@@ -715,17 +711,17 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
                 ld4(pb, bc); ld4(pb + 4, bc + 4); ld4(pb + 8, bc + 8);  // columns cx-4 .. cx+7, pixel i at [i+4]
                 colpass(0, N);
 #pragma unroll
-                for (int i = 0; i < 4; i++) b[i] = (gx0 + i == 0) ? bc[i + 4] : bc[i + 3];
+                for (int i = 0; i < 4; i++) b[i] = (!INTERIOR && gx0 + i == 0) ? bc[i + 4] : bc[i + 3];
                 accum(0, N, b);
                 colpass(1, N);
 #pragma unroll
-                for (int i = 0; i < 4; i++) b[i] = (gx0 + i >= W - 1) ? bc[i + 4] : bc[i + 5];
+                for (int i = 0; i < 4; i++) b[i] = (!INTERIOR && gx0 + i >= W - 1) ? bc[i + 4] : bc[i + 5];
                 accum(1, N, b);
                 half4(0, bc + 4);
             } else {
                 float bm[4], bu[4], bd[4];
                 ld4(pb + 4, bm); ld4(pb - SB_W + 4, bu); ld4(pb + SB_W + 4, bd);
-                const bool top = (gy == 0), bot = (gy == H - 1);
+                const bool top = !INTERIOR && (gy == 0), bot = !INTERIOR && (gy == H - 1);
                 colpass(2, N);
 #pragma unroll
                 for (int i = 0; i < 4; i++) b[i] = top ? bm[i] : bu[i];
@@ -765,7 +761,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         const int it = tid + u * 512;
         const int r = it / TX, c = it - r * TX;
         const int gxo = x0 + c, gyo = y0 + r;
-        if (it < TX * TY && gxo < W && gyo < H) {
+        if (it < TX * TY && (INTERIOR || (gxo < W && gyo < H))) {
             const unsigned off = ((unsigned)gyo * (unsigned)W + (unsigned)gxo) * 4u;
             const float ddx = sRow[(1 * ROW_H + r) * ROW_W + c], ddy = sRow[(2 * ROW_H + r) * ROW_W + c];
             float kap = sRow[(4 * ROW_H + r) * ROW_W + c] * sRow[(3 * ROW_H + r) * ROW_W + c];  // rho_y * rho_x
@@ -776,6 +772,27 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
         }
     }
     UGSM_STAMP(15);
+}
+
+template <int ABL, int WAVES = UGSM_SPLIT_WAVES>
+__global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+                                                    float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles)
+{
+    __shared__ __attribute__((aligned(16))) float sR[SR_H * SR_W];
+    __shared__ __attribute__((aligned(16))) float sL[SL_H * SL_W];
+    __shared__ __attribute__((aligned(16))) float sRow[5 * ROW_H * ROW_W];
+    __shared__ __attribute__((aligned(16))) float sBrow[SBROW_H * SB_W];
+    __shared__ __attribute__((aligned(16))) float sB[SB_H * SB_W];
+    __shared__ __attribute__((aligned(16))) float sA[TY * ROW_W];
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
+    const int x0 = tile_x * TX, y0 = tile_y * TY;
+#ifndef UGSM_COST_INTERIOR
+#define UGSM_COST_INTERIOR 1
+#endif
+    const bool interior = UGSM_COST_INTERIOR && !(ABL & 512) && x0 >= 3 && y0 >= 3 && x0 + TX + 3 <= W && y0 + TY + 3 <= H;
+    if (interior) cost_split_body<ABL, true>(L, R, A3, d3, nd3, W, H, thr, blend, x0, y0, sR, sL, sRow, sBrow, sB, sA);
+    else cost_split_body<ABL, false>(L, R, A3, d3, nd3, W, H, thr, blend, x0, y0, sR, sL, sRow, sBrow, sB, sA);
 }
 
 // The value the neighbouring lane holds in `v` (DPP wave shifts; lane 0 / lane 63 keep their own value).
