@@ -47,7 +47,8 @@ typedef struct ugsm_ctx ugsm_ctx;
  *   fovea_levels  <- foveatelevel = argv[2] or 7, MatchGPULib.cpp:259-264
  *   slots         <- pairs in flight (one HIP stream each); the reference has 1
  *   kernel_path   <- 0: fused gfx950 kernels (default); 1: one-stage-per-kernel
- *                    path kept for A/B parity checks (same results bit for bit) */
+ *                    path kept for A/B parity checks (same results bit for bit)
+ *   march_*       <- which levels run the marching form of the cost kernel (same results bit for bit) */
 typedef struct ugsm_config {
     int device;
     int levels;
@@ -55,7 +56,11 @@ typedef struct ugsm_config {
     int slots;
     int kernel_path;
     int profile_events; /* slot 0 brackets kernels with HIP events: 1 = the cost kernel only, 2 = every kernel class */
-    int reserved[6];
+    int march_min_pixels; /* levels of at least this many pixels run K-cost as the marching kernel (one wave per strip of
+                             columns, no LDS); 0 = default threshold, < 0 = never (the LDS-tiled kernel everywhere) */
+    int march_np;         /* tuning / tests: pixels per lane of the marching kernel (1 or 2; 0 = default) */
+    int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
+    int reserved[3];
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);

@@ -4,10 +4,12 @@
 // Times k_cost_fused and k_smooth_fused on one level-sized random problem with HIP events.
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
+#include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march.hip"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace ugsm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
@@ -52,6 +54,35 @@ int main(int argc, char **argv)
         for (int i = 0; i < reps; i++) launch_smooth_fused(st, d, o, W, H, 5, 0);
         for (int i = 0; i < reps; i++) launch_smooth_fused(st, d, o, W, H, 5, 1);
         CK(hipStreamSynchronize(st));
+        return 0;
+    }
+    if (argc > 4 && atoi(argv[4]) == 2) {  // marching K-cost against the LDS-tiled one: bit comparison + timing
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
+        for (int np = 1; np <= 2; np++) {
+            CK(hipMemset(o2, 0xff, 12 * n));
+            launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, 0);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < 3 * n; i++)
+                if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) { if (!bad) first = i; bad++; }
+            printf("march np=%d vs k_cost_split: %zu of %zu values differ%s\n", np, bad, 3 * n, bad ? "" : " (bit-exact)");
+            if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+        }
+        const int rows_list[] = {0, 24, 32, 48, 64, 96, 128};
+        for (int round = 0; round < 2; round++) {
+            SPLIT(0);
+            for (int np = 1; np <= 2; np++)
+                for (int rows : rows_list) {
+                    char nm[64]; snprintf(nm, sizeof nm, "k_cost_march np=%d rows=%d", np, rows);
+                    timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, rows); });
+                }
+        }
+        CK(hipGetLastError());
         return 0;
     }
     for (int round = 0; round < 2; round++) {  // interleaved rounds, one process (A/B rule)

@@ -1,0 +1,408 @@
+// ugsm_kernels_march.hip -- K-cost for the large levels as a marching (row-streaming) kernel.
+//
+// Same arithmetic as k_cost_split (ugsm_kernels_fused.hip) and the CPU oracle, bit for bit: one matcher iteration's
+// warp + 5-shift squared-NCC cost over 3 channels + parabola + confidence blend + disparity update
+// (matchlevel, /root/reference/src/gpu_matcher/MatchGPULib.cpp:1745-2250 and the MatchLib.cu kernels cited below).
+//
+// Layout: ONE WAVE owns a strip of 64*NP image columns (NP pixels per lane, lanes along the scanline) and marches
+// down the rows.  Nothing goes through LDS and there is no barrier:
+//   * horizontal neighbours (the +-1 shifts, the 5-tap row passes, B at x+-1) are the neighbouring lanes' registers,
+//     read by DPP wave shifts that the compiler folds into the consuming v_add/v_mul;
+//   * the 5-tap COLUMN passes are transposed-form FIR filters: a row's three tap products h*g0, h*g1, h*g2 are formed
+//     once and added into four running partial sums per image; because the reference adds its taps in row order
+//     j = -2..2 (MatchLib.cu:127-134, 1484-1487) the arrival order of the rows IS the reference's summation order,
+//     so the partial sums hold exactly the reference's intermediate values.  7 VALU per pixel and pass
+//     (3 products shared between the outputs they feed + 4 adds) instead of 9;
+//   * global loads run two rows ahead ((dx,dy)) / one row ahead (the warped gather of R, L, A) of the arithmetic.
+// Per pixel-iteration this is ~650 VALU lane-instructions against ~1080 in the LDS-tiled kernel, with the column
+// halo recomputed only 6 rows per strip (tile: 6 rows per 28) and 6 columns per 64*NP.
+//
+// Border semantics without cross-lane fix-ups: a lane whose pixel lies outside the image computes
+// the warp at the CLAMPED pixel, which is what a clamp-addressed fetch of R' returns (texture clamp, MatchLib.cu:56-60),
+// so R' is edge-replicated by construction; L is taken as zero outside (zero-padded smem convolution of the products,
+// SURVEY 9 U2/U3); only the five B fetches at clamped positions need a select, in the strips that touch the frame.
+//
+// FMAD (opt-in float contract): the reference binary is built with nvcc's default -fmad=true, which
+// contracts `sum += tap * k` into one FMA; FMAD = true evaluates the convolutions that way.
+#include "ugsm_exact.hpp"
+#include "ugsm_launch.hpp"
+
+namespace ugsm {
+
+typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;  // two floats, dword aligned (rows of odd width)
+typedef __attribute__((address_space(1))) const f2u gf2u_c;
+typedef __attribute__((address_space(1))) f2u gf2u;
+
+// value of the lane below / above (lane 0 / lane 63 read 0: those lanes hold strip halo whose results are dropped)
+__device__ __forceinline__ float shr1(float v)  // from lane - 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float shl1(float v)  // from lane + 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// the value of `v` at pixel column (own column j) + OFF, OFF = -1 or +1
+template <int NP, int OFF>
+__device__ __forceinline__ float nbr(const float (&v)[NP], const int j)
+{
+    static_assert(OFF == -1 || OFF == 1, "");
+    if constexpr (NP == 1) {
+        return OFF < 0 ? shr1(v[0]) : shl1(v[0]);
+    } else {
+        if (OFF < 0) return j == 0 ? shr1(v[1]) : v[0];
+        return j == 0 ? v[1] : shl1(v[0]);
+    }
+}
+
+// 5-tap row pass over the lane-distributed row p, taps added in the reference's order j = -2..2.
+// Products are >= +0 so the reference's leading "0 +" is exact (tap5p, ugsm_exact.hpp).
+template <int NP, bool FMAD>
+__device__ __forceinline__ void rowconv5(const float (&p)[NP], float (&out)[NP])
+{
+    if constexpr (NP == 2) {
+        if constexpr (!FMAD) {
+            const float a0A = p[0] * UGSM_G0, a1A = p[0] * UGSM_G1, a2A = p[0] * UGSM_G2;
+            const float a0B = p[1] * UGSM_G0, a1B = p[1] * UGSM_G1, a2B = p[1] * UGSM_G2;
+            const float t = a0A + a1B;  // taps -2, -1 of the NEXT lane's first pixel
+            out[0] = ((shr1(t) + a2A) + a1B) + shl1(a0A);
+            out[1] = (((shr1(a0B) + a1A) + a2B) + shl1(a1A)) + shl1(a0B);
+        } else {
+            const float t = __builtin_fmaf(p[1], UGSM_G1, p[0] * UGSM_G0);
+            out[0] = __builtin_fmaf(shl1(p[0]), UGSM_G0, __builtin_fmaf(p[1], UGSM_G1, __builtin_fmaf(p[0], UGSM_G2, shr1(t))));
+            out[1] = __builtin_fmaf(shl1(p[1]), UGSM_G0,
+                                    __builtin_fmaf(shl1(p[0]), UGSM_G1, __builtin_fmaf(p[1], UGSM_G2, __builtin_fmaf(p[0], UGSM_G1, shr1(p[1]) * UGSM_G0))));
+        }
+    } else {
+        if constexpr (!FMAD) {
+            const float a0 = p[0] * UGSM_G0, a1 = p[0] * UGSM_G1, a2 = p[0] * UGSM_G2;
+            const float t = shr1(a0) + a1;
+            const float m = shl1(a0);
+            out[0] = ((shr1(t) + a2) + shl1(a1)) + shl1(m);
+        } else {
+            const float t = __builtin_fmaf(p[0], UGSM_G1, shr1(p[0]) * UGSM_G0);
+            const float m = shl1(p[0]);
+            out[0] = __builtin_fmaf(shl1(m), UGSM_G0, __builtin_fmaf(m, UGSM_G1, __builtin_fmaf(p[0], UGSM_G2, shr1(t))));
+        }
+    }
+}
+
+// One step of the transposed-form 5-tap column pass: `h` is the row-pass value of the row that has just arrived;
+// s[0..3] hold the partial sums of the four output rows still open.  Returns the sum of the row that closes (two rows up).
+template <bool FMAD>
+__device__ __forceinline__ float colstep5(float (&s)[4], const float h)
+{
+    if constexpr (!FMAD) {
+        const float a0 = h * UGSM_G0, a1 = h * UGSM_G1, a2 = h * UGSM_G2;
+        const float out = s[3] + a0;
+        s[3] = s[2] + a1;
+        s[2] = s[1] + a2;
+        s[1] = s[0] + a1;
+        s[0] = a0;
+        return out;
+    } else {
+        const float out = __builtin_fmaf(h, UGSM_G0, s[3]);
+        s[3] = __builtin_fmaf(h, UGSM_G1, s[2]);
+        s[2] = __builtin_fmaf(h, UGSM_G2, s[1]);
+        s[1] = __builtin_fmaf(h, UGSM_G1, s[0]);
+        s[0] = h * UGSM_G0;
+        return out;
+    }
+}
+
+#ifndef MARCH_WAVES
+#define MARCH_WAVES(NP) ((NP) == 2 ? 2 : 3)
+#endif
+template <int NP>
+struct March {
+    static constexpr int COLS = 64 * NP;  // columns a wave holds
+    static constexpr int VX = COLS - 6;   // columns it produces (halo 3 on both sides)
+    static constexpr int ORG = (NP == 2) ? -1 : 0;  // first output column of strip 0 (-1 for NP = 2: lane 0's first pixel, three
+                                                    // columns further left, then sits on an even column and the pixel pairs
+                                                    // of a lane are 8-byte aligned when the row pitch is even)
+};
+
+// loads of one image row into the lane-distributed form; `row_base` is uniform, off[] the lanes' byte offsets
+template <int NP, bool EDGE>
+__device__ __forceinline__ void ld_row(gchar_c *row_base, const unsigned (&off)[NP], float (&o)[NP])
+{
+    if constexpr (NP == 2 && !EDGE) {
+        const f2u t = *(gf2u_c *)(row_base + off[0]);
+        o[0] = t.x;
+        o[1] = t.y;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; j++) o[j] = ld_at(row_base, off[j]);
+    }
+}
+
+template <int NP, bool EDGE, bool FMAD>
+__device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
+                                                float *__restrict__ nd3, const int W, const int H, const float thr, const int blend,
+                                                const int X0, const int xs, const int xe, const int ys, const int ye)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t n = (size_t)W * H;
+    gchar_c *const Lb[3] = {uniform_base(L.p), uniform_base(L.p + L.plane), uniform_base(L.p + 2 * L.plane)};
+    gchar_c *const Rb[3] = {uniform_base(R.p), uniform_base(R.p + R.plane), uniform_base(R.p + 2 * R.plane)};
+    gchar_c *const Ab[3] = {uniform_base(A3), uniform_base(A3 + n), uniform_base(A3 + 2 * n)};
+    gchar_c *const Db[3] = {uniform_base(d3), uniform_base(d3 + n), uniform_base(d3 + 2 * n)};
+    gchar_c *const Nb[3] = {uniform_base(nd3), uniform_base(nd3 + n), uniform_base(nd3 + 2 * n)};
+
+    // per-lane column constants
+    int px[NP];
+    unsigned coff[NP];  // byte offset of the (clamped) column inside a row
+    float xc[NP];       // warp x coordinate of the (clamped) pixel centre
+    bool cin[NP], stv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        px[j] = X0 + NP * lane + j;
+        const int pc = EDGE ? clampi(px[j], 0, W - 1) : px[j];
+        cin[j] = !EDGE || (px[j] >= 0 && px[j] < W);
+        coff[j] = (unsigned)pc * 4u;
+        xc[j] = (float)pc + 0.5f;
+        stv[j] = px[j] >= xs && px[j] < xe;
+    }
+    const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    (void)wm1; (void)hm1;
+    auto rowc = [&](int r) { return min(max(r, 0), H - 1); };  // rows are clamped with scalar ops in every strip
+
+    auto load_d = [&](const int r, float (&dx)[NP], float (&dy)[NP]) {
+        const unsigned ro = (unsigned)rowc(r) * pitchW;
+        ld_row<NP, EDGE>(Db[0] + ro, coff, dx);
+        ld_row<NP, EDGE>(Db[1] + ro, coff, dy);
+    };
+    // warpAbyB (MatchLib.cu:510-515): R'[x,y] = tex(R, x + 0.5 + dx, y + 0.5 + dy) at the clamped pixel
+    auto gather = [&](const int r, const float (&dx)[NP], const float (&dy)[NP], float (&o)[3][NP]) {
+        const float yc = (float)rowc(r) + 0.5f;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int sx = tex_index(xc[j] + dx[j], W);
+            const int sy = tex_index(yc + dy[j], H);
+            const unsigned off = (__umul24((unsigned)sy, (unsigned)R.pitch) + (unsigned)sx) * 4u;
+#pragma unroll
+            for (int k = 0; k < 3; k++) o[k][j] = ld_at(Rb[k], off);
+        }
+    };
+    auto load_L = [&](const int r, float (&o)[3][NP]) {
+        const unsigned ro = (unsigned)rowc(r) * pitchL;
+#pragma unroll
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Lb[k] + ro, coff, o[k]);
+    };
+    auto load_AO = [&](const int r, float (&a)[3][NP], float (&od)[3][NP]) {
+        const unsigned ro = (unsigned)rowc(r) * pitchW;
+#pragma unroll
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k] + ro, coff, a[k]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Db[k] + ro, coff, od[k]);
+    };
+
+    // ---- state carried down the rows --------------------------------------------------------------------------
+    float Rm1[3][NP], Rm2[3][NP];  // R'(r-1), R'(r-2)
+    float Bm1[3][NP], Bm2[3][NP];  // B(r-3), B(r-4)
+    float aB[3][NP][4];            // open partial sums of the B column pass
+    float aN[3][5][NP][4];         // open partial sums of the five product column passes
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            Rm1[k][j] = Rm2[k][j] = Bm1[k][j] = Bm2[k][j] = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                aB[k][j][u] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 5; s++) aN[k][s][j][u] = 0.0f;
+            }
+        }
+
+    // ---- prologue of the load pipeline ------------------------------------------------------------------------
+    int r = ys - 3;
+    const int r_end = ye + 2;  // last R' row any output of the strip needs
+    float dnx[NP], dny[NP];    // (dx,dy)(r+1)
+    float Rn[3][NP], Ln[3][NP], An[3][NP], On[3][NP];
+    {
+        float d0x[NP], d0y[NP];
+        load_d(r, d0x, d0y);
+        load_d(r + 1, dnx, dny);
+        load_L(r - 1, Ln);
+        load_AO(r - 3, An, On);
+        gather(r, d0x, d0y, Rn);
+    }
+
+    for (; r <= r_end; ++r) {
+        // ---- issue the next rows' loads ---------------------------------------------------------------------
+        float dfx[NP], dfy[NP];
+        load_d(r + 2, dfx, dfy);
+        float Rf[3][NP], Lf[3][NP], Af[3][NP], Of[3][NP];
+        gather(r + 1, dnx, dny, Rf);
+        load_L(r, Lf);
+        load_AO(r - 2, Af, Of);
+
+        // ---- arithmetic on R'(r), L(r-1), A(r-3) ------------------------------------------------------------
+        const int y = r - 1, o = r - 3;
+        const bool do_prod = r >= ys - 1;
+        const bool do_out = o >= ys;
+        const bool yin = !EDGE || (y >= 0 && y < H);
+        float Q[5][NP];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float rc[NP], sq[NP], hb[NP], bnew[NP];
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                rc[j] = Rn[k][j];
+                sq[j] = rc[j] * rc[j];  // Square, MatchLib.cu:569-570
+            }
+            rowconv5<NP, FMAD>(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
+#pragma unroll
+            for (int j = 0; j < NP; j++) bnew[j] = colstep5<FMAD>(aB[k][j], hb[j]);  // = B(r-2)
+            if (do_prod) {
+                float l[NP], p[5][NP], Nv[5][NP];
+#pragma unroll
+                for (int j = 0; j < NP; j++) l[j] = (cin[j] && yin) ? Ln[k][j] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < NP; j++) {  // CompareMove, MatchLib.cu:622-624
+                    p[0][j] = l[j] * nbr<NP, -1>(Rm1[k], j);  // shift (-1, 0)
+                    p[1][j] = l[j] * nbr<NP, +1>(Rm1[k], j);  // shift (+1, 0)
+                    p[2][j] = l[j] * Rm2[k][j];               // shift (0, -1)
+                    p[3][j] = l[j] * rc[j];                   // shift (0, +1)
+                    p[4][j] = l[j] * Rm1[k][j];               // shift (0, 0)
+                }
+#pragma unroll
+                for (int s = 0; s < 5; s++) {  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
+                    float h[NP];
+                    rowconv5<NP, FMAD>(p[s], h);
+#pragma unroll
+                    for (int j = 0; j < NP; j++) Nv[s][j] = colstep5<FMAD>(aN[k][s][j], h[j]);
+                }
+                if (do_out) {
+#pragma unroll
+                    for (int j = 0; j < NP; j++) {
+                        const float a = An[k][j], bc = Bm1[k][j];
+                        float bl = nbr<NP, -1>(Bm1[k], j), br = nbr<NP, +1>(Bm1[k], j), bu = Bm2[k][j], bd = bnew[j];
+                        if constexpr (EDGE) {  // B at the clamped position (MatchLib.cu:676-679)
+                            bl = (px[j] <= 0) ? bc : bl;
+                            br = (px[j] >= W - 1) ? bc : br;
+                            bu = (o <= 0) ? bc : bu;
+                            bd = (o >= H - 1) ? bc : bd;
+                        }
+                        const float q[5] = {ncc2_nn(Nv[0][j], a, bl), ncc2_nn(Nv[1][j], a, br), ncc2_nn(Nv[2][j], a, bu), ncc2_nn(Nv[3][j], a, bd),
+                                            ncc2_nn(Nv[4][j], a, bc)};
+#pragma unroll
+                        for (int s = 0; s < 5; s++) {  // MatchGPULib.cpp:2033-2070: q0 ; q1+q0 ; ((q0+q1)+q2)/3
+                            if (k == 0) Q[s][j] = q[s];
+                            else if (k == 1) Q[s][j] = q[s] + Q[s][j];
+                            else Q[s][j] = div3_nonneg(Q[s][j] + q[s]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                Bm2[k][j] = Bm1[k][j];
+                Bm1[k][j] = bnew[j];
+                Rm2[k][j] = Rm1[k][j];
+                Rm1[k][j] = rc[j];
+            }
+        }
+        if (do_out) {
+            // PolyDisparity x / y, corr product, update, confidence blend (MatchGPULib.cpp:2129-2250)
+            float ndx[NP], ndy[NP], nkp[NP];
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                float ddx, ddy, rx, ry;
+                poly_fast(Q[4][j], Q[0][j], Q[1][j], thr, ddx, rx);
+                poly_fast(Q[4][j], Q[2][j], Q[3][j], thr, ddy, ry);
+                float kap = ry * rx;
+                if (blend) kap = blend_conf(On[2][j], kap);
+                ndx[j] = On[0][j] + ddx;
+                ndy[j] = On[1][j] + ddy;
+                nkp[j] = kap;
+            }
+            const unsigned ro = (unsigned)o * pitchW;
+            if constexpr (NP == 2) {
+                if (stv[0] && stv[1]) {
+                    *(gf2u *)((gchar *)Nb[0] + ro + coff[0]) = f2u{ndx[0], ndx[1]};
+                    *(gf2u *)((gchar *)Nb[1] + ro + coff[0]) = f2u{ndy[0], ndy[1]};
+                    *(gf2u *)((gchar *)Nb[2] + ro + coff[0]) = f2u{nkp[0], nkp[1]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; j++)
+                        if (stv[j]) {
+                            st_at(Nb[0] + ro, coff[j], ndx[j]);
+                            st_at(Nb[1] + ro, coff[j], ndy[j]);
+                            st_at(Nb[2] + ro, coff[j], nkp[j]);
+                        }
+                }
+            } else {
+                if (stv[0]) {
+                    st_at(Nb[0] + ro, coff[0], ndx[0]);
+                    st_at(Nb[1] + ro, coff[0], ndy[0]);
+                    st_at(Nb[2] + ro, coff[0], nkp[0]);
+                }
+            }
+        }
+        // ---- rotate the load pipeline ---------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            dnx[j] = dfx[j];
+            dny[j] = dfy[j];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                Rn[k][j] = Rf[k][j];
+                Ln[k][j] = Lf[k][j];
+                An[k][j] = Af[k][j];
+                On[k][j] = Of[k][j];
+            }
+        }
+    }
+}
+
+// grid: one wave (64 threads) per strip of March<NP>::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
+template <int NP, bool FMAD>
+__global__ __launch_bounds__(64, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+                                                                      float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
+                                                                      int n_strips, int Hs)
+{
+    int sx, sy;
+    xcd_tile(n_strips, strips_x, sx, sy);
+    const int xs = sx * March<NP>::VX + March<NP>::ORG, ys = sy * Hs;
+    const int xe = min(xs + March<NP>::VX, W), ye = min(ys + Hs, H);
+    const int X0 = xs - 3;
+    // interior: every pixel a lane holds lies inside the image, and so do the product rows ys-2 .. ye+1 (L is zero outside)
+    // and the rows ys-1 .. ye of the B fetches
+    const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && ys >= 2 && ye <= H - 2;
+    if (interior) cost_march_body<NP, false, FMAD>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+    else cost_march_body<NP, true, FMAD>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+}
+
+template <int NP>
+static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
+                                int fmad, int rows)
+{
+    const int VX = March<NP>::VX;
+    const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
+    // strip height: as tall as possible (6 halo rows are recomputed per strip) while the grid still fills the wave slots
+    // the register allocation allows (256 CUs x 4 SIMDs x waves/SIMD)
+    const int slots = 256 * 4 * MARCH_WAVES(NP);
+    int Hs = rows;
+    if (Hs <= 0) {
+        const int sy = (slots / strips_x) > 0 ? (slots / strips_x) : 1;
+        Hs = (H + sy - 1) / sy;
+        if (Hs < 16) Hs = 16;
+    }
+    const int strips_y = (H + Hs - 1) / Hs;
+    const int n_strips = strips_x * strips_y;
+    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs);
+    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs);
+}
+
+void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
+                       int np, int rows)
+{
+    if (np == 1) launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows);
+    else launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows);
+}
+
+}  // namespace ugsm

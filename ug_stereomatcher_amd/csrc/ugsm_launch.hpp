@@ -33,6 +33,10 @@ void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t
 // One iteration's warp + cost + parabola + update, LDS-tiled.
 void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H,
                        float thr, int blend);
+// The same iteration as a marching kernel (ugsm_kernels_march.hip): one wave per strip of columns, no LDS.  np = pixels per
+// lane (1 or 2; 0 = default), rows = strip height (0 = automatic), fmad = the contracted float contract.
+void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
+                       int np, int rows);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled

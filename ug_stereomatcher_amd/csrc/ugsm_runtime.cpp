@@ -335,6 +335,16 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
     return UGSM_OK;
 }
 
+// K-cost as the marching kernel (ugsm_kernels_march.hip) or the LDS-tiled one: a strip of the marching kernel is one wave
+// working down >= 16 rows, so a level must be large enough to fill the chip with strips.
+constexpr int kMarchDefaultMinPixels = 1500000;
+bool use_march(const ugsm_config &cfg, int W, int H)
+{
+    if (cfg.march_min_pixels < 0) return false;
+    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchDefaultMinPixels;
+    return (long long)W * H >= thr;
+}
+
 // matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
 // on entry and on exit; other is scratch of the same size.
 // final_out (optional, fused path only): where the last iteration leaves its result instead of the ping-pong buffer
@@ -366,7 +376,8 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
             Timer t(ctx, &s, si, KC_COST, px);
-            launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
+            if (use_march(ctx->cfg, W, H)) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows);
+            else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
         float *a = other, *b = cur;
         UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true, (m == m_to && !ref) ? final_out : nullptr));
@@ -543,7 +554,10 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ugsm_config cfg;
     if (cfg_in) cfg = *cfg_in;
     else ugsm_default_config(&cfg);
-    if (const char *e = getenv("UGSM_KERNEL_PATH")) cfg.kernel_path = atoi(e);  // A/B switch for debugging
+    if (const char *e = getenv("UGSM_KERNEL_PATH")) cfg.kernel_path = atoi(e);  // A/B switches for debugging
+    if (const char *e = getenv("UGSM_MARCH_MIN_PIXELS")) cfg.march_min_pixels = atoi(e);
+    if (const char *e = getenv("UGSM_MARCH_NP")) cfg.march_np = atoi(e);
+    if (const char *e = getenv("UGSM_MARCH_ROWS")) cfg.march_rows = atoi(e);
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
         cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels)
         return UGSM_ERR_BAD_ARG;
