@@ -199,6 +199,11 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
 int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2,
                           const float *d_s, float *d_q0, float *d_q1, float *d_q2, int n);
 
+/* K-cost's range-guarded division (the compiler's binary32 division sequence without v_div_scale / v_div_fixup, used when
+ * every pyramid value of the pair is 0 or in [2^-12, 2^9]; csrc/ugsm_exact.hpp) on caller-supplied operands:
+ * q[i] must equal the IEEE binary32 quotient n[i] / d[i] bit for bit for operands that are 0 or in [2^-62, 2^37]. */
+int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n);
+
 /* ---- instrumentation ------------------------------------------------------------ */
 
 typedef struct ugsm_kernel_stat {

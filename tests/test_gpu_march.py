@@ -70,6 +70,25 @@ def test_march_large_disparities_top_level_and_zero_patches(lib, orc, np_lane):
             assert_bit_equal(got, exp, f"top={is_top} np={np_lane}")
 
 
+@pytest.mark.parametrize("np_lane", [1, 2])
+def test_march_wild_disparities(lib, orc, np_lane):
+    """NaN, +-Inf, huge and denormal disparities go through the branch-free texture index exactly like tex_index
+    (NaN -> 0, clamp otherwise)."""
+    rng = np.random.Generator(np.random.PCG64(79))
+    W, H = 150, 40
+    pl, pr = planes(orc, W, H, 4200)
+    d0 = np.stack([rng.normal(0, 5, (H, W)), rng.normal(0, 5, (H, W)), 0.2 + 0.8 * rng.random((H, W))]).astype(np.float32)
+    wild = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e10, -1e10, 2147483648.0, -2147483904.0, 1e-45, -1e-45, -0.5, -0.49999997],
+                    np.float32)
+    idx = rng.integers(0, H * W, 400)
+    d0[0].ravel()[idx[:200]] = wild[rng.integers(0, len(wild), 200)]
+    d0[1].ravel()[idx[200:]] = wild[rng.integers(0, len(wild), 200)]
+    exp, _ = orc.iterate_level(pl, pr, d0, 4, 0, False, 1, 1)
+    with lib.Context(levels=1, march_min_pixels=1, march_np=np_lane, march_rows=16) as c:
+        got = iterate(c, pl, pr, d0, 4, 0, False, 1, 1)
+    assert_bit_equal(got, exp, f"wild np={np_lane}")
+
+
 def test_march_equals_tiled_end_to_end(lib, orc, monkeypatch):
     """Whole matcher, every level through the marching kernel, against the oracle."""
     from ug_stereomatcher_amd import MatchGPULib, synth
@@ -82,3 +101,69 @@ def test_march_equals_tiled_end_to_end(lib, orc, monkeypatch):
         got = m.match(L, R, 0)
         m.close()
         assert_bit_equal(got, exp, f"320x240 full, np={np_lane}")
+
+
+def test_division_in_range_is_ieee(lib):
+    """K-cost's range-guarded division (csrc/ugsm_exact.hpp: the compiler's division sequence without v_div_scale /
+    v_div_fixup) equals the IEEE binary32 quotient for every operand pair it can meet: 0 or [2^-62, 2^37]."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    n = 1 << 22
+
+    def rand_pos(m, emin, emax):
+        mant = rng.integers(0, 1 << 23, m, dtype=np.uint32)
+        ex = rng.integers(emin + 127, emax + 127, m, dtype=np.uint32)
+        return ((ex << 23) | mant).view(np.float32)
+
+    num = rand_pos(n, -62, 37)
+    den = rand_pos(n, -62, 37)
+    q = n // 8
+    # pipeline-like: N^2 <= A*B, both around 1e3..1e9
+    den[:q] = (rng.uniform(1.0, 255.0, q) ** 4).astype(np.float32)
+    num[:q] = (den[:q] * rng.uniform(0.0, 1.001, q)).astype(np.float32)
+    # hard cases of a reciprocal-based quotient: all-ones mantissas, denominators just below / at powers of two, exact
+    # quotients, equal operands, the ends of the range
+    e = rng.integers(-62, 37, 8192)
+    den[q:q + 8192] = np.nextafter(np.float32(2.0) ** e.astype(np.float32), np.float32(0))
+    num[q:q + 4096] = np.nextafter(np.float32(2.0) ** rng.integers(-62, 37, 4096).astype(np.float32), np.float32(0))
+    num[q + 4096:q + 8192] = den[q + 4096:q + 8192]
+    den[2 * q:2 * q + 4096] = np.float32(2.0) ** rng.integers(-62, 37, 4096).astype(np.float32)
+    num[3 * q:3 * q + 4096] = (den[3 * q:3 * q + 4096] * np.float32(3.0))
+    num[4 * q:4 * q + 2048] = np.float32(2.0 ** -62)
+    den[4 * q:4 * q + 1024] = np.nextafter(np.float32(2.0 ** 37), np.float32(0))
+    num[4 * q + 2048:4 * q + 4096] = np.nextafter(np.float32(2.0 ** 37), np.float32(0))
+    den[4 * q + 2048:4 * q + 3072] = np.float32(2.0 ** -62)
+    # zeros: 0/d = +0, 0/0 = NaN (the all-zero 5x5 patch, SURVEY 9 U7)
+    num[5 * q:5 * q + 4096] = 0.0
+    den[5 * q + 2048:5 * q + 4096] = 0.0
+    with np.errstate(all="ignore"):
+        exp = (num / den).astype(np.float32)
+    with lib.Context(levels=1) as c:
+        pn, pd = c.to_device(num), c.to_device(den)
+        pq = c.alloc(4 * n)
+        try:
+            c.check(c.lib.ugsm_stage_div_probe(c.handle, pn, pd, pq, n))
+            got = c.to_host(pq, (n,))
+        finally:
+            for p in (pn, pd, pq):
+                c.free(p)
+    assert np.isnan(exp[5 * q + 2048:5 * q + 4096]).all() and (exp[5 * q:5 * q + 2048] == 0).all()
+    assert_bit_equal(got, exp, "range-guarded division")
+
+
+@pytest.mark.parametrize("np_lane", [1, 2])
+def test_march_values_outside_the_division_range_take_the_full_division(lib, orc, np_lane):
+    """A plane value outside range_ok (tiny, huge, negative) must switch the pair to the compiler's division; results
+    stay bit-exact either way.  The in-range case of the same images exercises the guarded division."""
+    rng = np.random.Generator(np.random.PCG64(80))
+    W, H = 140, 36
+    pl, pr = planes(orc, W, H, 4300)
+    d0 = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 2, (H, W)), 0.2 + 0.8 * rng.random((H, W))]).astype(np.float32)
+    for tag, edit in [("in range", None), ("tiny", 1e-7), ("huge", 3000.0), ("denormal", 1e-41)]:
+        L2, R2 = pl.copy(), pr.copy()
+        if edit is not None:
+            L2[1, 10:14, 20:60] = edit
+            R2[2, 20:22, 70:90] = edit
+        exp, _ = orc.iterate_level(L2, R2, d0, 4, 5, False, 1, 2)
+        with lib.Context(levels=1, march_min_pixels=1, march_np=np_lane, march_rows=16) as c:
+            got = iterate(c, L2, R2, d0, 4, 5, False, 1, 2)
+        assert_bit_equal(got, exp, f"{tag} np={np_lane}")

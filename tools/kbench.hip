@@ -22,7 +22,7 @@ int main(int argc, char **argv)
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (size_t i = 0; i < 3 * n; i++) { hL[i] = 1 + 254 * rnd(); hR[i] = 1 + 254 * rnd(); }
     for (size_t i = 0; i < n; i++) { int x = i % W, y = i / W; hd[i] = 30.0f * sinf(x * 0.002f) * cosf(y * 0.003f) + 0.3f * (rnd() - 0.5f); hd[n + i] = 0.75f * sinf(y * 0.002f) + 0.3f * (rnd() - 0.5f); hd[2 * n + i] = 0.3f + 0.7f * rnd(); }
-    if (argc > 5) {  // real data: 9 planes of W*H floats (L0 L1 L2 R0 R1 R2 dx dy conf), e.g. from tools/kbench_real.py
+    if (argc > 5 && atoi(argv[4]) < 2) {  // real data: 9 planes of W*H floats (L0 L1 L2 R0 R1 R2 dx dy conf), e.g. from tools/kbench_real.py
         FILE *f = fopen(argv[5], "rb");
         if (!f || fread(hL.data(), 4, 3 * n, f) != 3 * n || fread(hR.data(), 4, 3 * n, f) != 3 * n || fread(hd.data(), 4, 3 * n, f) != 3 * n) { printf("cannot read %s\n", argv[5]); return 1; }
         fclose(f);
@@ -33,6 +33,8 @@ int main(int argc, char **argv)
     CK(hipMemcpy(L, hL.data(), 12 * n, hipMemcpyHostToDevice)); CK(hipMemcpy(R, hR.data(), 12 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(d, hd.data(), 12 * n, hipMemcpyHostToDevice));
     hipStream_t st; CK(hipStreamCreate(&st));
+    unsigned *rb; CK(hipMalloc(&rb, 64)); CK(hipMemset(rb, 0, 64));  // range flag: inputs are in [1, 255]
+    const unsigned *rbs[2] = {nullptr, rb};
     Img3 iL{L, W, n}, iR{R, W, n};
     launch_sqblur_clamp(st, iL, W, H, A);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -56,6 +58,21 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 3) {  // counter runs of the marching K-cost: kbench W H reps 3 np rows
+        const int np = argc > 5 ? atoi(argv[5]) : 1, rows = argc > 6 ? atoi(argv[6]) : 0;
+        for (int i = 0; i < reps; i++) launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, np, rows, rb);
+        CK(hipStreamSynchronize(st));
+        return 0;
+    }
+    if (argc > 4 && atoi(argv[4]) == 4) {  // timing of the marching K-cost, both float contracts: kbench W H reps 4
+        for (int round = 0; round < 2; round++)
+            for (int fm = 0; fm < 4; fm++)
+                for (int rows : {0, 48, 96}) {
+                    char nm[64]; snprintf(nm, sizeof nm, "march np=1 fmad=%d fastdiv=%d rows=%d", fm & 1, fm >> 1, rows);
+                    timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, fm & 1, 1, rows, rbs[fm >> 1]); });
+                }
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 2) {  // marching K-cost against the LDS-tiled one: bit comparison + timing
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);
@@ -64,7 +81,7 @@ int main(int argc, char **argv)
         CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
         for (int np = 1; np <= 2; np++) {
             CK(hipMemset(o2, 0xff, 12 * n));
-            launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, 0);
+            launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, 0, rb);
             CK(hipStreamSynchronize(st));
             CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
             size_t bad = 0, first = 0;
@@ -79,7 +96,7 @@ int main(int argc, char **argv)
             for (int np = 1; np <= 2; np++)
                 for (int rows : rows_list) {
                     char nm[64]; snprintf(nm, sizeof nm, "k_cost_march np=%d rows=%d", np, rows);
-                    timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, rows); });
+                    timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, np, rows, rb); });
                 }
         }
         CK(hipGetLastError());
@@ -151,8 +168,8 @@ int main(int argc, char **argv)
     {
         const int W1 = (int)(W / 1.41421356), H1 = (int)(H / 1.41421356), W2 = W / 2, H2 = H / 2;
         for (int round = 0; round < 2; round++) {
-            timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f); });
-            timeit("blur_decimate 2", [&]() { launch_blur_decimate(st, L, W, H, o, W2, H2, 2.0f); });
+            timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f, nullptr); });
+            timeit("blur_decimate 2", [&]() { launch_blur_decimate(st, L, W, H, o, W2, H2, 2.0f, nullptr); });
             timeit("sqblur", [&]() { launch_sqblur_clamp(st, iL, W, H, o); });
         }
     }

@@ -1,21 +1,38 @@
 // valubench -- issue cost of the VALU instructions the fused kernels are made of, relative to v_fma_f32
 // (development tool).  One workgroup of 256 threads per CU x 4 (one..four waves per SIMD), each wave runs
-// ITER x 32 independent instructions of one kind; time per instruction per wave comes out in cycles
-// assuming the clock the chip reports.
+// ITER x 32 independent instructions of one kind.  Costs are reported in ACTUAL shader cycles: every wave stamps
+// s_memtime (shader clock) and s_memrealtime (constant 100 MHz) around its loop; cycles per wave-instruction per SIMD =
+// median over waves of (delta s_memtime) / (instructions x waves per SIMD), and the clock the chip held during the
+// loop = delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  The wall-clock
+// figure at the NOMINAL clock is printed beside it (round 1 quoted only that one, which overstates the cycle costs by
+// nominal / actual clock).
 //   hipcc -O3 --offload-arch=gfx950 tools/valubench.hip -o tools/valubench && ./tools/valubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
+__device__ long long *g_stamps = nullptr;  // per wave: delta s_memtime, delta s_memrealtime
+#define STAMP_BEGIN const long long t0__ = (long long)__builtin_amdgcn_s_memtime(), r0__ = (long long)__builtin_amdgcn_s_memrealtime();
+#define STAMP_END                                                                                       \
+    {                                                                                                   \
+        const long long t1__ = (long long)__builtin_amdgcn_s_memtime(), r1__ = (long long)__builtin_amdgcn_s_memrealtime(); \
+        if ((threadIdx.x & 63) == 0 && g_stamps) {                                                      \
+            const size_t w__ = (size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;               \
+            g_stamps[2 * w__] = t1__ - t0__;                                                            \
+            g_stamps[2 * w__ + 1] = r1__ - r0__;                                                        \
+        }                                                                                               \
+    }
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define KERNEL(name, decl, body, sink)                                                   \
     __global__ __launch_bounds__(256) void name(float *out, int iters)                  \
     {                                                                                    \
         decl;                                                                            \
+        STAMP_BEGIN                                                                      \
         for (int it = 0; it < iters; it++) {                                             \
             REP8(body) REP8(body) REP8(body) REP8(body)                                  \
         }                                                                                \
+        STAMP_END                                                                        \
         out[blockIdx.x * 256 + threadIdx.x] = sink;                                      \
     }
 
@@ -51,6 +68,20 @@
 #define B_RCP64(i) asm volatile("v_rcp_f64 %0, %0" : "+v"(a[i]));
 #define B_DPP(i) asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
 
+#define B_ADDDPP(i) asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+#define B_MULDPP(i) asm volatile("v_mul_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+#define B_MULLIT(i) asm volatile("v_mul_f32 %0, 0x3e779fea, %0" : "+v"(a[i]));
+#define B_FMA3(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+#define B_FMAC(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define B_CVTI(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+#define B_FLOOR(i) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i]));
+KERNEL(k_add_dpp, DECLF, B_ADDDPP, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_mul_dpp, DECLF, B_MULDPP, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_mul_literal, DECLF, B_MULLIT, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_fma_3src, DECLF, B_FMA3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_fmac, DECLF, B_FMAC, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_cvt_i32, DECLF, B_CVTI, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_floor, DECLF, B_FLOOR, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_fma, DECLF, B_FMA, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_mul, DECLF, B_MUL, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_add, DECLF, B_ADD, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
@@ -75,9 +106,11 @@ __global__ __launch_bounds__(256) void k_cnd_vccinit(float *out, int iters)
 {
     DECLF;
     asm volatile("s_mov_b64 vcc, exec" ::: "vcc");
+    STAMP_BEGIN
     for (int it = 0; it < iters; it++) {
         REP8(B_CND) REP8(B_CND) REP8(B_CND) REP8(B_CND)
     }
+    STAMP_END
     out[blockIdx.x * 256 + threadIdx.x] = a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7];
 }
 KERNEL(k_minimum3, DECLF, B_MINIMUM3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
@@ -93,25 +126,31 @@ __global__ __launch_bounds__(256) void k_cvt_f64_f32(float *out, int iters)
 {
     float a[8]; double d[8];
     for (int i = 0; i < 8; i++) a[i] = threadIdx.x + i;
+    STAMP_BEGIN
     for (int it = 0; it < iters; it++) {
 #define B(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(a[i]));
         REP8(B) REP8(B) REP8(B) REP8(B)
 #undef B
     }
+    STAMP_END
     out[blockIdx.x * 256 + threadIdx.x] = (float)(d[0] + d[1] + d[2] + d[3] + d[4] + d[5] + d[6] + d[7]);
 }
 __global__ __launch_bounds__(256) void k_cvt_f32_f64(float *out, int iters)
 {
     float a[8]; double d[8];
     for (int i = 0; i < 8; i++) d[i] = threadIdx.x + i;
+    STAMP_BEGIN
     for (int it = 0; it < iters; it++) {
 #define B(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
         REP8(B) REP8(B) REP8(B) REP8(B)
 #undef B
     }
+    STAMP_END
     out[blockIdx.x * 256 + threadIdx.x] = a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7];
 }
 
+#include <algorithm>
+#include <vector>
 int main()
 {
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
@@ -119,8 +158,11 @@ int main()
     const double ghz = pr.clockRate * 1e-6;
     printf("%s: %d CUs, %.2f GHz nominal\n", pr.name, cus, ghz);
     float *out; CK(hipMalloc(&out, sizeof(float) * 256 * cus * 8));
+    long long *stamps; CK(hipMalloc(&stamps, sizeof(long long) * 2 * 4 * cus * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int iters = 4096;
+    printf("%-16s %-12s %-22s %-12s %s\n", "kernel", "waves/SIMD", "cycles/wave-instr/SIMD", "clock GHz", "(wall time at the nominal clock)");
     auto run = [&](const char *name, void (*k)(float *, int), int wg_per_cu) {
         hipLaunchKernelGGL(k, dim3(cus * wg_per_cu), dim3(256), 0, 0, out, 64);
         CK(hipDeviceSynchronize());
@@ -128,12 +170,24 @@ int main()
         hipLaunchKernelGGL(k, dim3(cus * wg_per_cu), dim3(256), 0, 0, out, iters);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const int nw = cus * wg_per_cu * 4;
+        std::vector<long long> hs(2 * (size_t)nw);
+        CK(hipMemcpy(hs.data(), stamps, sizeof(long long) * 2 * nw, hipMemcpyDeviceToHost));
+        std::vector<double> cyc(nw), clk(nw);
+        for (int w = 0; w < nw; w++) {
+            cyc[w] = (double)hs[2 * w] / ((double)iters * 32 * wg_per_cu);
+            clk[w] = hs[2 * w + 1] > 0 ? (double)hs[2 * w] / (double)hs[2 * w + 1] * 0.1 : 0.0;
+        }
+        std::nth_element(cyc.begin(), cyc.begin() + nw / 2, cyc.end());
+        std::nth_element(clk.begin(), clk.begin() + nw / 2, clk.end());
         // per SIMD: wg_per_cu waves, each iters*32 instructions
-        const double cyc = ms * 1e-3 * ghz * 1e9 / ((double)iters * 32 * wg_per_cu);
-        printf("%-16s %d wave/SIMD  %6.2f cycles per wave-instruction (at nominal clock)\n", name, wg_per_cu, cyc);
+        const double nom = ms * 1e-3 * ghz * 1e9 / ((double)iters * 32 * wg_per_cu);
+        printf("%-16s %-12d %-22.2f %-12.2f (%.2f)\n", name, wg_per_cu, cyc[nw / 2], clk[nw / 2], nom);
     };
-#define RUN(k) run(#k, k, 1); run(#k, k, 4);
-    RUN(k_fma) RUN(k_mul) RUN(k_add) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma) RUN(k_rcp) RUN(k_dscale) RUN(k_dfmas) RUN(k_dfix) RUN(k_minimum3) RUN(k_min3) RUN(k_cnd) RUN(k_cnd_vccinit) RUN(k_cmp_cnd_vcc) RUN(k_cmp_cnd_sgpr) RUN(k_cnd64) RUN(k_cnd_nodep) RUN(k_max) RUN(k_med3) RUN(k_cmp_vcc) RUN(k_cmp_sgpr) RUN(k_mov) RUN(k_dpp)
+#define RUN(k) run(#k, k, 1); run(#k, k, 2); run(#k, k, 3); run(#k, k, 4);
+    RUN(k_fma) RUN(k_fma_3src) RUN(k_fmac) RUN(k_mul) RUN(k_mul_literal) RUN(k_add) RUN(k_add_dpp) RUN(k_mul_dpp) RUN(k_dpp) RUN(k_mov) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma)
+    RUN(k_rcp) RUN(k_dscale) RUN(k_dfmas) RUN(k_dfix) RUN(k_minimum3) RUN(k_min3) RUN(k_cmp_cnd_vcc) RUN(k_cmp_cnd_sgpr) RUN(k_cnd64) RUN(k_max) RUN(k_med3)
+    RUN(k_cmp_vcc) RUN(k_cmp_sgpr) RUN(k_floor) RUN(k_cvt_i32)
     RUN(k_fma64) RUN(k_mul64) RUN(k_add64) RUN(k_rcp64) RUN(k_cvt_f64_f32) RUN(k_cvt_f32_f64)
     return 0;
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_match_full",
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
-    "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_get_kernel_stats",
+    "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_get_kernel_stats",
     "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
 
@@ -102,6 +102,7 @@ def load():
     lib.ugsm_stage_smooth.argtypes = [vp, vp, i, i, i, i]
     lib.ugsm_stage_poly_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
     lib.ugsm_stage_div3_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
+    lib.ugsm_stage_div_probe.argtypes = [vp, vp, vp, vp, i]
     lib.ugsm_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), i]
     lib.ugsm_reset_kernel_stats.argtypes = [vp]
     lib.ugsm_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]

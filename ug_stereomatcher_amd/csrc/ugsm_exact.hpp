@@ -99,6 +99,39 @@ __device__ __forceinline__ float ncc2_nn(float n, float a, float b)
     if (v > 1.0f) v = 1.0f;
     return v;
 }
+// ---- range-guarded division ---------------------------------------------------------------------------------
+// hipcc expands a binary32 `n / d` to v_div_scale x2, v_rcp, six FMA/MUL, v_div_fmas, v_div_fixup (LowerFDIV32).  When
+// both operands are zero or lie in [2^-62, 2^37] -- no operand, reciprocal, quotient or remainder of the sequence leaves
+// the normal range -- v_div_scale returns its operand unscaled with VCC = 0, v_div_fmas is a plain FMA and
+// v_div_fixup passes the quotient through (its special cases are zero / Inf / NaN operands: 0/d gives +0 and 0/0 NaN
+// here as well, through rcp(0) = Inf and 0 * Inf = NaN).  The remaining eight instructions are these, operation for
+// operation, so the result is the same correctly rounded quotient.  15 divisions per pixel-iteration: ~26 issue
+// cycles each instead of ~41 (tools/valubench.hip).
+// The guarantee comes from the data: every pyramid value v is checked once, when it is produced, for
+// v == 0 or 2^-12 <= v <= 2^9 (range_ok below); then R'^2, L*R' lie in {0} U [2^-24, 2^18], their 5x5 Gaussian sums
+// (every tap >= 0.09) in {0} U [2^-31, 2^18.1], and N^2, A*B in {0} U [2^-62, 2^36.2].  A pair with any value outside
+// (a NaN, or the blurred fringe of an isolated bright pixel on black) takes the compiler's full sequence instead.
+// tests: test_division_in_range_is_ieee.
+__device__ __forceinline__ bool range_ok(const float v) { return v == 0.0f || (v >= 0x1p-12f && v <= 0x1p9f); }
+__device__ __forceinline__ float div_inrange(const float n, const float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = n * r;
+    const float e0 = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e0, r, q);
+    const float e1 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e1, r, q);
+}
+template <bool FAST>
+__device__ __forceinline__ float ncc2_t(const float n, const float a, const float b)
+{
+    float v = FAST ? div_inrange(n * n, a * b) : (n * n) / (a * b);
+    if (v > 1.0f) v = 1.0f;
+    return v;
+}
+
 // PolyDisparity (MatchLib.cu:805-836) with the first quotient in binary32 when that is provably the
 // same number: (-b1*0.5) is exact in f32 unless it underflows, and rounding a binary64 quotient of two
 // binary32 numbers to binary32 equals the correctly rounded binary32 quotient (53 >= 2*24+2, double

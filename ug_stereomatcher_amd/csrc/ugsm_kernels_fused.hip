@@ -1240,7 +1240,7 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
 constexpr int PTX = 64, PTY = 16, PRW = 2 * PTX + 8, PRH = 2 * PTY + 6;
 
 __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3,
-                                                             int W2, int H2, float sf)
+                                                             int W2, int H2, float sf, unsigned *__restrict__ range_bad)
 {
     __shared__ float sS[PRH * PRW];
     __shared__ float sT[PRH * PTX];
@@ -1281,18 +1281,22 @@ __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__rest
         }
     }
     __syncthreads();
-    // column pass at the sampled rows
+    // column pass at the sampled rows; every value written is checked against the range the guarded division of
+    // K-cost relies on (range_ok, ugsm_exact.hpp)
+    bool bad = false;
     if (ix < W2) {
         for (int ly = tid / PTX; ly < PTY; ly += 256 / PTX) {
             const int iy = oy0 + ly;
             if (iy < H2) {
                 const int cy = tex_index(((float)iy + 0.5f) * sf, H) - ry0;
                 const float *p = &sT[cy * PTX + lx];
-                dst3[(size_t)blockIdx.z * W2 * H2 + (size_t)iy * W2 + ix] =
-                    tap5(p[-2 * PTX], p[-PTX], p[0], p[PTX], p[2 * PTX]);
+                const float v = tap5(p[-2 * PTX], p[-PTX], p[0], p[PTX], p[2 * PTX]);
+                dst3[(size_t)blockIdx.z * W2 * H2 + (size_t)iy * W2 + ix] = v;
+                bad |= !range_ok(v);
             }
         }
     }
+    if (bad && range_bad) *range_bad = 1u;
 }
 
 // A = colconv_clamp(rowconv_clamp(L^2)) (Square + convolutionRows/ColumnsKernelT, MatchLib.cu:556-578,
@@ -1353,7 +1357,8 @@ __global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, fl
 constexpr int BTX = 64, BTY = 16, BRW = BTX + 4, BRH = BTY + 4, BC1 = 52, BR1 = 16, BC2 = 32, BR2 = 8;
 
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
-                                                  float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2)
+                                                  float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
+                                                  unsigned *__restrict__ range_bad)
 {
     __shared__ float sS[3][BRH * BRW];
     __shared__ float sT1[3][BRH * BC1];
@@ -1427,7 +1432,8 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
         }
     }
     __syncthreads();
-    // column pass at the sampled rows
+    // column pass at the sampled rows (level 0 holds the integers 0..255: always inside range_ok; levels 1 and 2 are checked)
+    bool bad = false;
     for (int it = tid; it < BR1 * BC1 + BR2 * BC2; it += 256) {
         const bool one = it < BR1 * BC1;
         const int l = one ? it : it - BR1 * BC1;
@@ -1445,28 +1451,32 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const float *p = (one ? &sT1[k][cy * BC1 + lx] : &sT2[k][cy * BC2 + lx]);
-                    dst[k * nd + at] = tap5(p[-2 * cw], p[-cw], p[0], p[cw], p[2 * cw]);
+                    const float v = tap5(p[-2 * cw], p[-cw], p[0], p[cw], p[2 * cw]);
+                    dst[k * nd + at] = v;
+                    bad |= !range_ok(v);
                 }
             }
         }
     }
+    if (bad && range_bad) *range_bad = 1u;
 }
 
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
-                     int H2)
+                     int H2, unsigned *range_bad)
 {
     hipLaunchKernelGGL(k_pyr_base, dim3((W + BTX - 1) / BTX, (H + BTY - 1) / BTY), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
-                       H2);
+                       H2, range_bad);
 }
 
-void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad)
 {
     if (sf > 2.0f || sf < 1.0f) {  // region bound assumes 1 <= sf <= 2 (the reference uses sqrt2 and 2)
         launch_blur_decimate_ref(st, src3, W, H, dst3, W2, H2, sf);
+        if (range_bad) launch_range_scan(st, dst3, 3 * (size_t)W2 * H2, range_bad);
         return;
     }
     dim3 grid((W2 + PTX - 1) / PTX, (H2 + PTY - 1) / PTY, 3);
-    hipLaunchKernelGGL(k_blur_decimate_tiled, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);
+    hipLaunchKernelGGL(k_blur_decimate_tiled, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad);
 }
 
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3)

@@ -123,21 +123,36 @@ struct March {
                                                     // of a lane are 8-byte aligned when the row pitch is even)
 };
 
-// loads of one image row into the lane-distributed form; `row_base` is uniform, off[] the lanes' byte offsets
+// loads of one image row into the lane-distributed form: uniform plane base + the lanes' 32-bit byte offsets
 template <int NP, bool EDGE>
-__device__ __forceinline__ void ld_row(gchar_c *row_base, const unsigned (&off)[NP], float (&o)[NP])
+__device__ __forceinline__ void ld_row(gchar_c *base, const unsigned (&off)[NP], float (&o)[NP])
 {
     if constexpr (NP == 2 && !EDGE) {
-        const f2u t = *(gf2u_c *)(row_base + off[0]);
+        const f2u t = *(gf2u_c *)(base + off[0]);
         o[0] = t.x;
         o[1] = t.y;
     } else {
 #pragma unroll
-        for (int j = 0; j < NP; j++) o[j] = ld_at(row_base, off[j]);
+        for (int j = 0; j < NP; j++) o[j] = ld_at(base, off[j]);
     }
 }
 
-template <int NP, bool EDGE, bool FMAD>
+// tex_index (ugsm_device.hpp) without branches: floor, clamp to [0, n-1] in float, convert.  v_med3_f32 returns
+// min3 of its operands when one of them is a NaN, and v_min_f32 ignores a quiet NaN, so NaN -> 0 as in tex_index;
+// +-Inf and values beyond the int range are clamped before the conversion.  (tests: test_march_wild_disparities)
+__device__ __forceinline__ int tex_index_nb(const float coord, const float nm1)
+{
+    return (int)__builtin_amdgcn_fmed3f(floorf(coord), 0.0f, nm1);
+}
+
+// what the load pipeline holds for one row r: (dx,dy)(r+1), the gathered R'(r), L(r-1), A(r-3) and the strip's own (dx,dy,conf)(r-3)
+template <int NP>
+struct MarchRow {
+    float dx[NP], dy[NP];
+    float R[3][NP], L[3][NP], A[3][NP], O[3][NP];
+};
+
+template <int NP, bool EDGE, bool FMAD, bool FAST>
 __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                 float *__restrict__ nd3, const int W, const int H, const float thr, const int blend,
                                                 const int X0, const int xs, const int xe, const int ys, const int ye)
@@ -166,37 +181,44 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     }
     const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    (void)wm1; (void)hm1;
     auto rowc = [&](int r) { return min(max(r, 0), H - 1); };  // rows are clamped with scalar ops in every strip
+    auto row_off = [&](const int r, const unsigned pitch, unsigned (&off)[NP]) {
+        const unsigned ro = (unsigned)rowc(r) * pitch;
+#pragma unroll
+        for (int j = 0; j < NP; j++) off[j] = ro + coff[j];
+    };
 
     auto load_d = [&](const int r, float (&dx)[NP], float (&dy)[NP]) {
-        const unsigned ro = (unsigned)rowc(r) * pitchW;
-        ld_row<NP, EDGE>(Db[0] + ro, coff, dx);
-        ld_row<NP, EDGE>(Db[1] + ro, coff, dy);
+        unsigned off[NP];
+        row_off(r, pitchW, off);
+        ld_row<NP, EDGE>(Db[0], off, dx);
+        ld_row<NP, EDGE>(Db[1], off, dy);
     };
     // warpAbyB (MatchLib.cu:510-515): R'[x,y] = tex(R, x + 0.5 + dx, y + 0.5 + dy) at the clamped pixel
     auto gather = [&](const int r, const float (&dx)[NP], const float (&dy)[NP], float (&o)[3][NP]) {
         const float yc = (float)rowc(r) + 0.5f;
 #pragma unroll
         for (int j = 0; j < NP; j++) {
-            const int sx = tex_index(xc[j] + dx[j], W);
-            const int sy = tex_index(yc + dy[j], H);
+            const int sx = tex_index_nb(xc[j] + dx[j], wm1);
+            const int sy = tex_index_nb(yc + dy[j], hm1);
             const unsigned off = (__umul24((unsigned)sy, (unsigned)R.pitch) + (unsigned)sx) * 4u;
 #pragma unroll
             for (int k = 0; k < 3; k++) o[k][j] = ld_at(Rb[k], off);
         }
     };
     auto load_L = [&](const int r, float (&o)[3][NP]) {
-        const unsigned ro = (unsigned)rowc(r) * pitchL;
+        unsigned off[NP];
+        row_off(r, pitchL, off);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Lb[k] + ro, coff, o[k]);
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Lb[k], off, o[k]);
     };
     auto load_AO = [&](const int r, float (&a)[3][NP], float (&od)[3][NP]) {
-        const unsigned ro = (unsigned)rowc(r) * pitchW;
+        unsigned off[NP];
+        row_off(r, pitchW, off);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k] + ro, coff, a[k]);
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k], off, a[k]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Db[k] + ro, coff, od[k]);
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Db[k], off, od[k]);
     };
 
     // ---- state carried down the rows --------------------------------------------------------------------------
@@ -217,33 +239,19 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
             }
         }
 
-    // ---- prologue of the load pipeline ------------------------------------------------------------------------
-    int r = ys - 3;
-    const int r_end = ye + 2;  // last R' row any output of the strip needs
-    float dnx[NP], dny[NP];    // (dx,dy)(r+1)
-    float Rn[3][NP], Ln[3][NP], An[3][NP], On[3][NP];
-    {
-        float d0x[NP], d0y[NP];
-        load_d(r, d0x, d0y);
-        load_d(r + 1, dnx, dny);
-        load_L(r - 1, Ln);
-        load_AO(r - 3, An, On);
-        gather(r, d0x, d0y, Rn);
-    }
-
-    for (; r <= r_end; ++r) {
-        // ---- issue the next rows' loads ---------------------------------------------------------------------
-        float dfx[NP], dfy[NP];
-        load_d(r + 2, dfx, dfy);
-        float Rf[3][NP], Lf[3][NP], Af[3][NP], Of[3][NP];
-        gather(r + 1, dnx, dny, Rf);
-        load_L(r, Lf);
-        load_AO(r - 2, Af, Of);
+    // One row step.  `cur` holds row r's loads (issued during the previous step); the next row's loads are issued into
+    // `nxt` before the arithmetic.  The two sets swap roles from step to step (the row loop is unrolled by two), so a
+    // loaded register is never copied: a copy would have to wait for its load and would end the prefetch.
+    auto step = [&](const int r, MarchRow<NP> &cur, MarchRow<NP> &nxt) {
+        load_d(r + 2, nxt.dx, nxt.dy);
+        gather(r + 1, cur.dx, cur.dy, nxt.R);
+        load_L(r, nxt.L);
+        load_AO(r - 2, nxt.A, nxt.O);
 
         // ---- arithmetic on R'(r), L(r-1), A(r-3) ------------------------------------------------------------
         const int y = r - 1, o = r - 3;
         const bool do_prod = r >= ys - 1;
-        const bool do_out = o >= ys;
+        const bool do_out = o >= ys && o < ye;  // (the row loop may run one step past the strip: two steps per trip)
         const bool yin = !EDGE || (y >= 0 && y < H);
         float Q[5][NP];
 #pragma unroll
@@ -251,7 +259,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
             float rc[NP], sq[NP], hb[NP], bnew[NP];
 #pragma unroll
             for (int j = 0; j < NP; j++) {
-                rc[j] = Rn[k][j];
+                rc[j] = cur.R[k][j];
                 sq[j] = rc[j] * rc[j];  // Square, MatchLib.cu:569-570
             }
             rowconv5<NP, FMAD>(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
@@ -260,7 +268,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
             if (do_prod) {
                 float l[NP], p[5][NP], Nv[5][NP];
 #pragma unroll
-                for (int j = 0; j < NP; j++) l[j] = (cin[j] && yin) ? Ln[k][j] : 0.0f;
+                for (int j = 0; j < NP; j++) l[j] = (cin[j] && yin) ? cur.L[k][j] : 0.0f;
 #pragma unroll
                 for (int j = 0; j < NP; j++) {  // CompareMove, MatchLib.cu:622-624
                     p[0][j] = l[j] * nbr<NP, -1>(Rm1[k], j);  // shift (-1, 0)
@@ -279,7 +287,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 if (do_out) {
 #pragma unroll
                     for (int j = 0; j < NP; j++) {
-                        const float a = An[k][j], bc = Bm1[k][j];
+                        const float a = cur.A[k][j], bc = Bm1[k][j];
                         float bl = nbr<NP, -1>(Bm1[k], j), br = nbr<NP, +1>(Bm1[k], j), bu = Bm2[k][j], bd = bnew[j];
                         if constexpr (EDGE) {  // B at the clamped position (MatchLib.cu:676-679)
                             bl = (px[j] <= 0) ? bc : bl;
@@ -287,8 +295,8 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                             bu = (o <= 0) ? bc : bu;
                             bd = (o >= H - 1) ? bc : bd;
                         }
-                        const float q[5] = {ncc2_nn(Nv[0][j], a, bl), ncc2_nn(Nv[1][j], a, br), ncc2_nn(Nv[2][j], a, bu), ncc2_nn(Nv[3][j], a, bd),
-                                            ncc2_nn(Nv[4][j], a, bc)};
+                        const float q[5] = {ncc2_t<FAST>(Nv[0][j], a, bl), ncc2_t<FAST>(Nv[1][j], a, br), ncc2_t<FAST>(Nv[2][j], a, bu),
+                                            ncc2_t<FAST>(Nv[3][j], a, bd), ncc2_t<FAST>(Nv[4][j], a, bc)};
 #pragma unroll
                         for (int s = 0; s < 5; s++) {  // MatchGPULib.cpp:2033-2070: q0 ; q1+q0 ; ((q0+q1)+q2)/3
                             if (k == 0) Q[s][j] = q[s];
@@ -315,47 +323,51 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 poly_fast(Q[4][j], Q[0][j], Q[1][j], thr, ddx, rx);
                 poly_fast(Q[4][j], Q[2][j], Q[3][j], thr, ddy, ry);
                 float kap = ry * rx;
-                if (blend) kap = blend_conf(On[2][j], kap);
-                ndx[j] = On[0][j] + ddx;
-                ndy[j] = On[1][j] + ddy;
+                if (blend) kap = blend_conf(cur.O[2][j], kap);
+                ndx[j] = cur.O[0][j] + ddx;
+                ndy[j] = cur.O[1][j] + ddy;
                 nkp[j] = kap;
             }
             const unsigned ro = (unsigned)o * pitchW;
             if constexpr (NP == 2) {
                 if (stv[0] && stv[1]) {
-                    *(gf2u *)((gchar *)Nb[0] + ro + coff[0]) = f2u{ndx[0], ndx[1]};
-                    *(gf2u *)((gchar *)Nb[1] + ro + coff[0]) = f2u{ndy[0], ndy[1]};
-                    *(gf2u *)((gchar *)Nb[2] + ro + coff[0]) = f2u{nkp[0], nkp[1]};
+                    *(gf2u *)((gchar *)Nb[0] + (ro + coff[0])) = f2u{ndx[0], ndx[1]};
+                    *(gf2u *)((gchar *)Nb[1] + (ro + coff[0])) = f2u{ndy[0], ndy[1]};
+                    *(gf2u *)((gchar *)Nb[2] + (ro + coff[0])) = f2u{nkp[0], nkp[1]};
                 } else {
 #pragma unroll
                     for (int j = 0; j < NP; j++)
                         if (stv[j]) {
-                            st_at(Nb[0] + ro, coff[j], ndx[j]);
-                            st_at(Nb[1] + ro, coff[j], ndy[j]);
-                            st_at(Nb[2] + ro, coff[j], nkp[j]);
+                            st_at(Nb[0], ro + coff[j], ndx[j]);
+                            st_at(Nb[1], ro + coff[j], ndy[j]);
+                            st_at(Nb[2], ro + coff[j], nkp[j]);
                         }
                 }
             } else {
                 if (stv[0]) {
-                    st_at(Nb[0] + ro, coff[0], ndx[0]);
-                    st_at(Nb[1] + ro, coff[0], ndy[0]);
-                    st_at(Nb[2] + ro, coff[0], nkp[0]);
+                    st_at(Nb[0], ro + coff[0], ndx[0]);
+                    st_at(Nb[1], ro + coff[0], ndy[0]);
+                    st_at(Nb[2], ro + coff[0], nkp[0]);
                 }
             }
         }
-        // ---- rotate the load pipeline ---------------------------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            dnx[j] = dfx[j];
-            dny[j] = dfy[j];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                Rn[k][j] = Rf[k][j];
-                Ln[k][j] = Lf[k][j];
-                An[k][j] = Af[k][j];
-                On[k][j] = Of[k][j];
-            }
-        }
+    };
+
+    // ---- prologue of the load pipeline, then the row loop (two steps per trip) ---------------------------------
+    int r = ys - 3;
+    const int r_end = ye + 2;  // last R' row any output of the strip needs
+    MarchRow<NP> P0, P1;
+    {
+        float d0x[NP], d0y[NP];
+        load_d(r, d0x, d0y);
+        load_d(r + 1, P0.dx, P0.dy);
+        load_L(r - 1, P0.L);
+        load_AO(r - 3, P0.A, P0.O);
+        gather(r, d0x, d0y, P0.R);
+    }
+    for (; r <= r_end; r += 2) {
+        step(r, P0, P1);
+        step(r + 1, P1, P0);
     }
 }
 
@@ -363,7 +375,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
 template <int NP, bool FMAD>
 __global__ __launch_bounds__(64, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
-                                                                      int n_strips, int Hs)
+                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad)
 {
     int sx, sy;
     xcd_tile(n_strips, strips_x, sx, sy);
@@ -373,13 +385,20 @@ __global__ __launch_bounds__(64, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3
     // interior: every pixel a lane holds lies inside the image, and so do the product rows ys-2 .. ye+1 (L is zero outside)
     // and the rows ys-1 .. ye of the B fetches
     const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && ys >= 2 && ye <= H - 2;
-    if (interior) cost_march_body<NP, false, FMAD>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
-    else cost_march_body<NP, true, FMAD>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+    // range-guarded division (ugsm_exact.hpp) when the pyramid builder found every value of the pair in range
+    const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
+    if (fast) {
+        if (interior) cost_march_body<NP, false, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        else cost_march_body<NP, true, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+    } else {
+        if (interior) cost_march_body<NP, false, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        else cost_march_body<NP, true, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+    }
 }
 
 template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
-                                int fmad, int rows)
+                                int fmad, int rows, const unsigned *range_bad)
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
@@ -394,15 +413,41 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     }
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs);
-    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs);
+    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
+    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
 }
 
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
-                       int np, int rows)
+                       int np, int rows, const unsigned *range_bad)
 {
-    if (np == 1) launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows);
-    else launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows);
+    if (np == 2) launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+    else launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+}
+
+// range_bad[0] = 1 if any of the `count` floats at p is outside range_ok (ugsm_exact.hpp); the caller zeroes the word first.
+// The pyramid kernels make this check as they write a level; this pass serves the stage-level test entry points, which
+// receive their planes ready-made.
+__global__ __launch_bounds__(256) void k_range_scan(const float *__restrict__ p, size_t count, unsigned *__restrict__ range_bad)
+{
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) bad |= !range_ok(p[i]);
+    if (bad) *range_bad = 1u;
+}
+void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad)
+{
+    const size_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(k_range_scan, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, p, count, range_bad);
+}
+
+// test hook: the range-guarded division on arbitrary operands
+__global__ void k_div_probe(const float *__restrict__ n, const float *__restrict__ d, float *__restrict__ q, int count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < count) q[i] = div_inrange(n[i], d[i]);
+}
+void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, int count)
+{
+    hipLaunchKernelGGL(k_div_probe, dim3((count + 255) / 256), dim3(256), 0, st, n, d, q, count);
 }
 
 }  // namespace ugsm

@@ -36,13 +36,17 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 // The same iteration as a marching kernel (ugsm_kernels_march.hip): one wave per strip of columns, no LDS.  np = pixels per
 // lane (1 or 2; 0 = default), rows = strip height (0 = automatic), fmad = the contracted float contract.
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
-                       int np, int rows);
+                       int np, int rows, const unsigned *range_bad);
+// range_bad (device word, may be null = unknown): 0 when every pyramid value of the pair passed range_ok (ugsm_exact.hpp),
+// which lets K-cost use the range-guarded division; launch_range_scan ORs the check of `count` floats into it.
+void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
-void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
+// (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad);
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
-                     int H2);
+                     int H2, unsigned *range_bad);
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3);
 // X, Y, Z planes from the full-resolution (dx, dy) and the two 3x4 projection matrices
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);
@@ -51,6 +55,7 @@ void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *
                               int upper_margin, float scale, const double *P1, const double *P2, float *xyz);
 void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, const float *fovH_, const float *fovV_,
                            const float *fovC_, int fovW, int fovH, int org_x, int org_y);
+void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, int count);
 void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n);
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);
 

@@ -47,10 +47,12 @@ struct Slot {
     size_t lvl_cap = 0;  // floats per 3-plane level buffer
     uint8_t *rgbL = nullptr, *rgbR = nullptr;
     size_t rgb_cap = 0;
+    unsigned *range_bad = nullptr;  // device word: 0 while every pyramid value of the pair in this slot passed range_ok (ugsm_exact.hpp)
     float *hout = nullptr;  // device staging for host-API outputs
     size_t hout_cap = 0;
     bool have_pyr = false;
     bool have_coarse = false;
+    bool range_known = false;  // range_bad describes the images the next run_level works on
     std::vector<EvRec> pending;
     std::vector<hipEvent_t> pool;
 };
@@ -274,7 +276,7 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     const bool base = !ref && levels >= 3;
     if (base) {
         Timer t(ctx, &s, si, KC_PYR, (double)s.W * s.H);
-        launch_pyr_base(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2]);
+        launch_pyr_base(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad);
     } else {
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
         launch_rgb_planes(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
@@ -286,13 +288,13 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
             float sf = (float)kScale;
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
-            else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
+            else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad);
         }
         if (i + 2 < levels && !(base && i == 0)) {
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
-            else launch_blur_decimate(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
+            else launch_blur_decimate(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad);
         }
     }
     HIPCHK(ctx, hipGetLastError());
@@ -376,7 +378,7 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
             Timer t(ctx, &s, si, KC_COST, px);
-            if (use_march(ctx->cfg, W, H)) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows);
+            if (use_march(ctx->cfg, W, H)) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
         float *a = other, *b = cur;
@@ -399,6 +401,9 @@ int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, cons
     if (!d_rgbL || !d_rgbR) return UGSM_ERR_BAD_ARG;
     if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
     UCHK(prepare_slot(ctx, s, W, H));
+    // the pyramid kernels of the fused path check every value they write (level 0 holds the integers 0..255)
+    s.range_known = ctx->cfg.kernel_path != 1 && s.range_bad != nullptr;
+    if (s.range_known) HIPCHK(ctx, hipMemsetAsync(s.range_bad, 0, sizeof(unsigned), s.st));
     UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
     UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR));
     s.have_pyr = true;
@@ -573,7 +578,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         snprintf(ctx->stats[k].name, sizeof ctx->stats[k].name, "%s", kClassName[cfg.kernel_path][k]);
     }
     for (Slot &s : ctx->slots) {
-        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&s.range_bad, 64) != hipSuccess) {
             ugsm_destroy(ctx);
             return UGSM_ERR_DEVICE;
         }
@@ -591,7 +596,7 @@ void ugsm_destroy(ugsm_ctx *ctx)
         harvest(ctx, s);
         for (hipEvent_t e : s.pool) (void)hipEventDestroy(e);
         for (void *p : {(void *)s.pyrL, (void *)s.pyrR, (void *)s.A, (void *)s.Rw, (void *)s.B, (void *)s.d0, (void *)s.d1,
-                        (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout})
+                        (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout, (void *)s.range_bad})
             if (p) (void)hipFree(p);
         if (s.st) (void)hipStreamDestroy(s.st);
     }
@@ -811,6 +816,13 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
     float *cur = s->d0, *other = s->d1;
     HIPCHK(ctx, hipMemcpyAsync(cur, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     const size_t n = (size_t)W * H;
+    // the planes arrive ready-made: check their range here (the pyramid kernels do it for the matcher proper)
+    s->range_known = ctx->cfg.kernel_path != 1;
+    if (s->range_known) {
+        HIPCHK(ctx, hipMemsetAsync(s->range_bad, 0, sizeof(unsigned), s->st));
+        launch_range_scan(s->st, d_L3, 3 * n, s->range_bad);
+        launch_range_scan(s->st, d_R3, 3 * n, s->range_bad);
+    }
     UCHK(run_level(ctx, *s, 0, Img3{d_L3, W, n}, Img3{d_R3, W, n}, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
     HIPCHK(ctx, hipMemcpyAsync(d_d3, cur, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     return ugsm_wait(ctx, 0);
@@ -945,6 +957,17 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
     if (!d_c || !d_l || !d_r || !d_thr || !d_delta || !d_corr || !d_third || n < 1) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     launch_poly_probe(s->st, d_c, d_l, d_r, d_thr, d_delta, d_corr, d_third, n);
+    HIPCHK(ctx, hipGetLastError());
+    return ugsm_wait(ctx, 0);
+}
+
+int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_n || !d_d || !d_q || n < 1) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    launch_div_probe(s->st, d_n, d_d, d_q, n);
     HIPCHK(ctx, hipGetLastError());
     return ugsm_wait(ctx, 0);
 }
