@@ -60,7 +60,9 @@ typedef struct ugsm_config {
                              columns, no LDS); 0 = default threshold, < 0 = never (the LDS-tiled kernel everywhere) */
     int march_np;         /* tuning / tests: pixels per lane of the marching kernel (1 or 2; 0 = default) */
     int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
-    int reserved[3];
+    int march_smooth;     /* 1: those levels also run K-smooth (five passes at a time) as a marching kernel; 0 (default): the
+                             LDS-tiled K-smooth everywhere -- the marching form is bit-identical but no faster */
+    int reserved[2];
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);

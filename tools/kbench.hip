@@ -64,6 +64,38 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 5) {  // marching K-smooth against the LDS-tiled one: bit comparison + timing
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        for (int box = 0; box < 2; box++) {
+            launch_smooth_fused(st, d, o, W, H, 5, box);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
+            for (int np = 1; np <= 2; np++) {
+                CK(hipMemset(o2, 0xff, 12 * n));
+                launch_smooth_march(st, d, o2, W, H, box, np, 0);
+                CK(hipStreamSynchronize(st));
+                CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+                size_t bad = 0, first = 0;
+                for (size_t i = 0; i < 3 * n; i++)
+                    if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) { if (!bad) first = i; bad++; }
+                printf("smooth march np=%d box=%d vs k_smooth_fused: %zu of %zu values differ%s\n", np, box, bad, 3 * n, bad ? "" : " (bit-exact)");
+                if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+            }
+        }
+        for (int round = 0; round < 2; round++)
+            for (int box = 0; box < 2; box++) {
+                char nm[64]; snprintf(nm, sizeof nm, "k_smooth_fused p5 box=%d", box);
+                timeit(nm, [&]() { launch_smooth_fused(st, d, o, W, H, 5, box); });
+                for (int np = 1; np <= 2; np++)
+                    for (int rows : {0, 32, 48, 64, 96, 128}) {
+                        snprintf(nm, sizeof nm, "k_smooth_march np=%d box=%d rows=%d", np, box, rows);
+                        timeit(nm, [&]() { launch_smooth_march(st, d, o2, W, H, box, np, rows); });
+                    }
+            }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 4) {  // timing of the marching K-cost, both float contracts: kbench W H reps 4
         for (int round = 0; round < 2; round++)
             for (int fm = 0; fm < 4; fm++)

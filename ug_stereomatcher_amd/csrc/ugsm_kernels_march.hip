@@ -26,6 +26,7 @@
 // contracts `sum += tap * k` into one FMA; FMAD = true evaluates the convolutions that way.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
+#include <type_traits>
 
 namespace ugsm {
 
@@ -422,6 +423,323 @@ void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 {
     if (np == 2) launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
     else launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+}
+
+// =========================================================================================
+// K-smooth for the large levels, marching form: PASSES confidence-weighted Jacobi passes (smoothKernel,
+// MatchLib.cu:1092-1145; MatchGPULib.cpp:2262-2292) and the 3x3 box (convolutionRows/ColumnsKernelTa, MatchLib.cu:1593-1697;
+// MatchGPULib.cpp:2361-2412) in one launch, the passes pipelined down the rows in registers: when input row t arrives, pass s
+// produces its row t-s from the three newest rows of pass s-1.  Same wave-per-strip layout as the marching K-cost: west / east
+// neighbours by DPP from the neighbouring lanes, north / south from the rows kept in registers (a ring of three rows per pass,
+// the row loop unrolled by three so that the ring turns without register copies), no LDS, no barrier.
+//   * A pixel's weighted terms v*kappa (v = dx, dy, kappa) are formed once, when its row is produced, and reused by the five
+//     stencils the pixel takes part in: 3 multiplications per pixel and pass instead of 15.  A ring row holds kappa and the
+//     three products.
+//   * The three quotients of a pixel share one binary64 reciprocal (div3_shared, ugsm_exact.hpp), with the literal
+//     division for denominators outside its range, as in the LDS-tiled kernel.
+//   * Borders (strips that touch the frame only): rows <= 0 and columns <= 0 pass through -- with clamped loads the lanes left
+//     of / above the image then hold copies of column 0 / row 0, which is also what the clamp-addressed box reads there; a
+//     lane right of the image copies the last column's result after every pass (the east neighbour of column W-1 is column
+//     W-1 itself, MatchLib.cu:1120), and a row below the image copies the last row.
+// =========================================================================================
+template <int NP, int OFF>
+__device__ __forceinline__ float nbr2(const float (&v)[NP], const int j)  // column (own column j) + OFF, |OFF| <= 2
+{
+    if constexpr (OFF == -1 || OFF == 1) return nbr<NP, OFF>(v, j);
+    else if constexpr (NP == 1) return OFF < 0 ? shr1(shr1(v[0])) : shl1(shl1(v[0]));
+    else return OFF < 0 ? shr1(v[j]) : shl1(v[j]);
+}
+
+template <int NP>
+struct SRow {
+    float k[NP];     // kappa of the row
+    float p[3][NP];  // dx*kappa, dy*kappa, kappa*kappa
+};
+
+template <int NP, int PASSES, bool BOX>
+struct SmoothMarch {
+    static constexpr int HALO = PASSES + (BOX ? 2 : 0);
+    static constexpr int COLS = 64 * NP;
+    static constexpr int VX = COLS - 2 * HALO - (NP == 2 ? 1 : 0);  // NP = 2: one spare column so that lane 0 can sit on an even column
+};
+
+template <int NP, int PASSES, bool BOX, bool EDGE>
+__device__ __forceinline__ void smooth_march_body(const float *__restrict__ s3, float *__restrict__ o3, const int W, const int H, const int X0,
+                                                  const int xs, const int xe, const int ys, const int ye)
+{
+    constexpr int HALO = SmoothMarch<NP, PASSES, BOX>::HALO;
+    const int lane = threadIdx.x & 63;
+    const size_t n = (size_t)W * H;
+    gchar_c *const Sb[3] = {uniform_base(s3), uniform_base(s3 + n), uniform_base(s3 + 2 * n)};
+    gchar_c *const Ob[3] = {uniform_base(o3), uniform_base(o3 + n), uniform_base(o3 + 2 * n)};
+    int px[NP];
+    unsigned coff[NP];
+    bool stv[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        px[j] = X0 + NP * lane + j;
+        coff[j] = (unsigned)(EDGE ? clampi(px[j], 0, W - 1) : px[j]) * 4u;
+        stv[j] = px[j] >= xs && px[j] < xe;
+    }
+    const unsigned pitchW = (unsigned)W * 4u;
+    auto load_row = [&](const int r, float (&v)[3][NP]) {
+        const unsigned ro = (unsigned)min(max(r, 0), H - 1) * pitchW;
+        unsigned off[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) off[j] = ro + coff[j];
+#pragma unroll
+        for (int f = 0; f < 3; f++) ld_row<NP, EDGE>(Sb[f], off, v[f]);
+    };
+    // the lane and slot that hold column W-1 (EDGE strips whose lanes reach past the image)
+    const int last_l = EDGE ? (W - 1 - X0) / NP : 0, last_j = EDGE ? (W - 1 - X0) - last_l * NP : 0;
+    const bool past_right = EDGE && X0 + 64 * NP > W;
+
+    // one pass for one row: N, C, S are rows r-1, r, r+1 of the previous pass; `out` receives (dx, dy, kappa) of row r
+    auto pass_row = [&](const SRow<NP> &N, const SRow<NP> &C, const SRow<NP> &S, const int r, float (&out)[3][NP]) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            // smoothKernel, MatchLib.cu:1108-1139: centre, west, east, north, south; the weight is the pre-pass confidence
+            float sumCorr = 0.0f;
+            sumCorr = sumCorr + C.k[j];
+            sumCorr = sumCorr + nbr<NP, -1>(C.k, j);
+            sumCorr = sumCorr + nbr<NP, +1>(C.k, j);
+            sumCorr = sumCorr + N.k[j];
+            sumCorr = sumCorr + S.k[j];
+            float acc[3];
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                float a = 0.0f;
+                a = C.p[f][j] + a;
+                a = nbr<NP, -1>(C.p[f], j) + a;
+                a = nbr<NP, +1>(C.p[f], j) + a;
+                a = N.p[f][j] + a;
+                a = S.p[f][j] + a;
+                acc[f] = a;
+            }
+            if (__builtin_expect(div3_shared_ok(sumCorr), 1)) {
+                div3_shared(acc[0], acc[1], acc[2], sumCorr, out[0][j], out[1][j], out[2][j]);
+            } else {
+#pragma unroll
+                for (int f = 0; f < 3; f++) out[f][j] = acc[f] / sumCorr;
+            }
+        }
+        (void)r;
+    };
+    // border rules of a pass's output row r (EDGE strips only); `in_r` = the INPUT row r (clamped), `prev` = this pass's row r-1
+    auto fix_edges = [&](const int r, const float (&in_r)[3][NP], const float (&prev)[3][NP], float (&out)[3][NP]) {
+        if (r >= H) {  // below the image: the last row's copy
+#pragma unroll
+            for (int f = 0; f < 3; f++)
+#pragma unroll
+                for (int j = 0; j < NP; j++) out[f][j] = prev[f][j];
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const bool keep = r <= 0 || px[j] <= 0;  // row 0 / column 0 are never touched (MatchLib.cu:1106), so they still hold the input
+#pragma unroll
+            for (int f = 0; f < 3; f++) out[f][j] = keep ? in_r[f][j] : out[f][j];
+        }
+        if (past_right) {
+#pragma unroll
+            for (int f = 0; f < 3; f++) {
+                const float sel = (NP == 2 && last_j == 1) ? out[f][NP - 1] : out[f][0];
+                const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sel), last_l));
+#pragma unroll
+                for (int j = 0; j < NP; j++) out[f][j] = px[j] >= W ? edge : out[f][j];
+            }
+        }
+    };
+    auto make_row = [&](const float (&v)[3][NP], SRow<NP> &R) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            R.k[j] = v[2][j];
+#pragma unroll
+            for (int f = 0; f < 3; f++) R.p[f][j] = v[f][j] * v[2][j];  // v*w of MatchLib.cu:1111-1131, rounded to binary32 as there
+        }
+    };
+
+    // ---- state -----------------------------------------------------------------------------------------------------
+    // The passes are SKEWED by two rows: at the step that brings input row t, pass s (1..PASSES) produces its row t - (2s-1) from
+    // rows its predecessor finished in EARLIER steps, so the PASSES stencil + division chains of a step are independent of one
+    // another (a wave then has work to issue while each chain waits out its latencies; with the passes chained inside a step a
+    // wave stalled on every division).  ring[s] holds the three newest rows of pass s (s = 0: the input) in slots that turn
+    // with the step's phase PH = (t - t0) % 3; the row loop is unrolled by three, so no register is ever copied.
+    SRow<NP> ring[PASSES > 0 ? PASSES : 1][3];
+    float in[3][3][NP];          // raw (dx, dy, kappa) of the input rows in flight: row t in slot (t - t0) % 3
+    float outP[3][3][NP];        // the last pass's rows (dx, dy, kappa): the row of step t in slot (t - t0) % 3
+    float prevP[PASSES > 0 ? PASSES : 1][3][NP];  // EDGE: every pass's previous row (rows below the image copy it)
+    float bacc[3][NP][4];        // open partial sums of the box's column pass
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+#pragma unroll
+            for (int s = 0; s < (PASSES > 0 ? PASSES : 1); s++) {
+                ring[s][u].k[j] = 0.0f;
+                prevP[s][u][j] = 0.0f;
+#pragma unroll
+                for (int f = 0; f < 3; f++) ring[s][u].p[f][j] = 0.0f;
+            }
+#pragma unroll
+            for (int f = 0; f < 3; f++) outP[u][f][j] = in[u][f][j] = 0.0f;
+        }
+#pragma unroll
+    for (int f = 0; f < 3; f++)
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) bacc[f][j][u] = 0.0f;
+
+    constexpr int DELAY = (PASSES > 0 ? 2 * PASSES : 1) + (BOX ? 2 : 0);  // output row = t - DELAY
+    const int t0 = ys - HALO;
+    const int t_end = ye - 1 + DELAY;
+    load_row(t0, in[0]);
+
+    auto step = [&](auto ph_tag, const int t) {
+        constexpr int PH = decltype(ph_tag)::value;
+        load_row(t + 1, in[(PH + 1) % 3]);  // a whole step ahead of its use
+        // the previous step's row of the last pass: through the box (rows, then the transposed column pass) or straight out
+        {
+            const float(&last)[3][NP] = outP[(PH + 2) % 3];
+            float res[3][NP];
+            if constexpr (BOX) {
+                // rows (Ta): sum = 0; sum += v[x-2]*0; += v[x-1]*a; += v[x]*a; += v[x+1]*a; += v[x+2]*0 (box5f); the same down the
+                // columns in transposed form: the rows arrive in the order the taps are added
+#pragma unroll
+                for (int f = 0; f < 3; f++)
+#pragma unroll
+                    for (int j = 0; j < NP; j++) {
+                        const float h = box5f(nbr2<NP, -2>(last[f], j), nbr2<NP, -1>(last[f], j), last[f][j], nbr2<NP, +1>(last[f], j), nbr2<NP, +2>(last[f], j));
+                        float(&b)[4] = bacc[f][j];
+                        const float hb = h * UGSM_BOX;
+                        res[f][j] = __builtin_fmaf(h, 0.0f, b[3]);
+                        b[3] = b[2] + hb;
+                        b[2] = b[1] + hb;
+                        b[1] = b[0] + hb;
+                        b[0] = __builtin_fmaf(h, 0.0f, 0.0f);
+                    }
+            } else {
+#pragma unroll
+                for (int f = 0; f < 3; f++)
+#pragma unroll
+                    for (int j = 0; j < NP; j++) res[f][j] = last[f][j];
+            }
+            const int o = t - DELAY;
+            if (o >= ys && o < ye) {
+                const unsigned ro = (unsigned)o * pitchW;
+                if constexpr (NP == 2) {
+                    if (stv[0] && stv[1]) {
+#pragma unroll
+                        for (int f = 0; f < 3; f++) *(gf2u *)((gchar *)Ob[f] + (ro + coff[0])) = f2u{res[f][0], res[f][1]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NP; j++)
+                            if (stv[j]) {
+#pragma unroll
+                                for (int f = 0; f < 3; f++) st_at(Ob[f], ro + coff[j], res[f][j]);
+                            }
+                    }
+                } else {
+                    if (stv[0]) {
+#pragma unroll
+                        for (int f = 0; f < 3; f++) st_at(Ob[f], ro + coff[0], res[f][0]);
+                    }
+                }
+            }
+        }
+        if constexpr (PASSES == 0) {
+#pragma unroll
+            for (int f = 0; f < 3; f++)
+#pragma unroll
+                for (int j = 0; j < NP; j++) outP[PH][f][j] = in[PH][f][j];
+        } else {
+            make_row(in[PH], ring[0][PH]);
+            // passes in DESCENDING order: pass s reads its predecessor's three rows before the predecessor (next in program
+            // order) overwrites the oldest of them with this step's row
+#pragma unroll
+            for (int s = PASSES; s >= 1; s--) {
+                const int r = t - (2 * s - 1);
+                // newest row of pass s-1 as of the previous step: slot PH for the input, (PH - 2(s-1)) mod 3 for a pass
+                constexpr int Z = 0;
+                const int sl_s = (s == 1) ? PH : ((PH - 2 * (s - 1)) % 3 + 3) % 3;
+                const int sl_c = (sl_s + 2) % 3, sl_n = (sl_s + 1) % 3;
+                (void)Z;
+                float cur[3][NP];
+                pass_row(ring[s - 1][sl_n], ring[s - 1][sl_c], ring[s - 1][sl_s], r, cur);
+                if constexpr (EDGE) {
+                    float in_r[3][NP];
+                    if (r <= 0 || X0 <= 0) load_row(r, in_r);  // (only the pass-through pixels use it)
+                    fix_edges(r, in_r, prevP[s - 1], cur);
+#pragma unroll
+                    for (int f = 0; f < 3; f++)
+#pragma unroll
+                        for (int j = 0; j < NP; j++) prevP[s - 1][f][j] = cur[f][j];
+                }
+                if (s < PASSES) {
+                    make_row(cur, ring[s][((PH - (2 * s - 1)) % 3 + 3) % 3]);  // = the slot of pass s's oldest row
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 3; f++)
+#pragma unroll
+                        for (int j = 0; j < NP; j++) outP[PH][f][j] = cur[f][j];
+                }
+            }
+        }
+    };
+    for (int t = t0; t <= t_end; t += 3) {
+        step(std::integral_constant<int, 0>{}, t);
+        step(std::integral_constant<int, 1>{}, t + 1);
+        step(std::integral_constant<int, 2>{}, t + 2);
+    }
+}
+
+#ifndef SMOOTH_MARCH_WAVES
+#define SMOOTH_MARCH_WAVES(NP) ((NP) == 2 ? 2 : 4)
+#endif
+template <int NP, int PASSES, bool BOX>
+__global__ __launch_bounds__(64, SMOOTH_MARCH_WAVES(NP)) void k_smooth_march(const float *__restrict__ s3, float *__restrict__ o3, int W, int H,
+                                                                              int strips_x, int n_strips, int Hs)
+{
+    using G = SmoothMarch<NP, PASSES, BOX>;
+    int sx, sy;
+    xcd_tile(n_strips, strips_x, sx, sy);
+    const int xs = sx * G::VX, ys = sy * Hs;
+    const int xe = min(xs + G::VX, W), ye = min(ys + Hs, H);
+    int X0 = xs - G::HALO;
+    if (NP == 2) X0 -= X0 & 1;  // (two's complement: also rounds a negative X0 down to even)
+    const bool interior = X0 >= 1 && X0 + G::COLS <= W && ys - G::HALO >= 1 && ye + G::HALO <= H;
+    if (interior) smooth_march_body<NP, PASSES, BOX, false>(s3, o3, W, H, X0, xs, xe, ys, ye);
+    else smooth_march_body<NP, PASSES, BOX, true>(s3, o3, W, H, X0, xs, xe, ys, ye);
+}
+
+template <int NP, int PASSES, bool BOX>
+static void launch_smooth_march_t(hipStream_t st, const float *s3, float *o3, int W, int H, int rows)
+{
+    using G = SmoothMarch<NP, PASSES, BOX>;
+    const int strips_x = (W + G::VX - 1) / G::VX;
+    const int slots = 256 * 4 * SMOOTH_MARCH_WAVES(NP);
+    int Hs = rows;
+    if (Hs <= 0) {
+        const int sy = (slots / strips_x) > 0 ? (slots / strips_x) : 1;
+        Hs = (H + sy - 1) / sy;
+        if (Hs < 24) Hs = 24;
+    }
+    const int strips_y = (H + Hs - 1) / Hs;
+    const int n_strips = strips_x * strips_y;
+    hipLaunchKernelGGL((k_smooth_march<NP, PASSES, BOX>), dim3(n_strips), dim3(64), 0, st, s3, o3, W, H, strips_x, n_strips, Hs);
+}
+
+// five passes (+ box) per launch; other pass counts belong to the LDS-tiled kernel (launch_smooth_fused)
+void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows)
+{
+    if (np == 2) {
+        if (do_box) launch_smooth_march_t<2, 5, true>(st, s3, o3, W, H, rows);
+        else launch_smooth_march_t<2, 5, false>(st, s3, o3, W, H, rows);
+    } else {
+        if (do_box) launch_smooth_march_t<1, 5, true>(st, s3, o3, W, H, rows);
+        else launch_smooth_march_t<1, 5, false>(st, s3, o3, W, H, rows);
+    }
 }
 
 // range_bad[0] = 1 if any of the `count` floats at p is outside range_ok (ugsm_exact.hpp); the caller zeroes the word first.

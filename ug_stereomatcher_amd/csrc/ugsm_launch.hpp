@@ -40,6 +40,8 @@ void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 // range_bad (device word, may be null = unknown): 0 when every pyramid value of the pair passed range_ok (ugsm_exact.hpp),
 // which lets K-cost use the range-guarded division; launch_range_scan ORs the check of `count` floats into it.
 void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad);
+// Five Jacobi passes (+ the box when do_box) as a marching kernel (ugsm_kernels_march.hip); np / rows as for launch_cost_march.
+void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled

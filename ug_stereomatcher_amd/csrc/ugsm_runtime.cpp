@@ -301,6 +301,16 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     return UGSM_OK;
 }
 
+// K-cost / K-smooth as the marching kernels (ugsm_kernels_march.hip) or the LDS-tiled ones: a strip of a marching kernel is one wave
+// working down >= 16 rows, so a level must be large enough to fill the chip with strips.
+constexpr int kMarchDefaultMinPixels = 900000;
+bool use_march(const ugsm_config &cfg, int W, int H)
+{
+    if (cfg.march_min_pixels < 0) return false;
+    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchDefaultMinPixels;
+    return (long long)W * H >= thr;
+}
+
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
 // result and `b` is scratch.
 // final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
@@ -325,26 +335,16 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             left -= p;
             if (p == 0 && !do_box) break;
             Timer t(ctx, &s, si, KC_SMOOTH, px);
-            if (left == 0 && final_out) {
-                launch_smooth_fused(s.st, a, final_out, W, H, p, do_box);
-                a = final_out;
-            } else {
-                launch_smooth_fused(s.st, a, b, W, H, p, do_box && left == 0);
-                std::swap(a, b);
-            }
+            const bool box_now = do_box && left == 0;
+            float *dst = (left == 0 && final_out) ? final_out : b;
+            // five passes at a time on a large level: the marching kernel; anything else: the LDS-tiled one
+            if (p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx->cfg, W, H)) launch_smooth_march(s.st, a, dst, W, H, box_now, ctx->cfg.march_np, ctx->cfg.march_rows);
+            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now);
+            if (dst == final_out) a = final_out;
+            else std::swap(a, b);
         } while (left > 0);
     }
     return UGSM_OK;
-}
-
-// K-cost as the marching kernel (ugsm_kernels_march.hip) or the LDS-tiled one: a strip of the marching kernel is one wave
-// working down >= 16 rows, so a level must be large enough to fill the chip with strips.
-constexpr int kMarchDefaultMinPixels = 1500000;
-bool use_march(const ugsm_config &cfg, int W, int H)
-{
-    if (cfg.march_min_pixels < 0) return false;
-    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchDefaultMinPixels;
-    return (long long)W * H >= thr;
 }
 
 // matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
@@ -563,6 +563,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (const char *e = getenv("UGSM_MARCH_MIN_PIXELS")) cfg.march_min_pixels = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_NP")) cfg.march_np = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_ROWS")) cfg.march_rows = atoi(e);
+    if (const char *e = getenv("UGSM_MARCH_SMOOTH")) cfg.march_smooth = atoi(e);
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
         cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels)
         return UGSM_ERR_BAD_ARG;
