@@ -6,23 +6,36 @@
 One "step" = one synthetic 16 MP (4928x3264) stereo pair through the full-resolution 14-level
 pyramid path (BASELINE.json configs[2], the configuration `metric` is quoted on), inputs already
 resident in HBM, `--slots` pairs in flight on separate HIP streams.  For N > 1 the driver launches
-one rank per GPU (torch.distributed.run); pairs are independent, so ranks share nothing on the data
-path ("weak" scaling, no collective); the barrier and the max-over-ranks reduction go over RCCL.
+one rank per GPU (torch.distributed.run); run without a launcher, `--gpus N` starts the ranks itself.
+Pairs are independent, so ranks share nothing on the data path ("weak" scaling, no collective); the
+barrier and the max-over-ranks reduction go over RCCL.
 
-Rank 0 prints ONE JSON line with, besides the contract fields,
-  roofline     -- dominant kernel (the per-iteration cost kernel): algorithmic bytes
-                  (48 B per pixel-iteration) / HIP-event duration of its launches,
-                  measured live on slot 0's stream during the timed region; HBM peak 8 TB/s.
-  cpu_baseline -- the CPU oracle (a port: the reference has no CPU matcher) timed on this host,
-                  rank 0 / N=1 only, on a bounded sample; reported, not a target.
-Other workloads (--workload 1080p | fovea16mp | fovea-shard) are parity/scaling cases, not the
-headline line.
+How the line is put together (rank 0 prints ONE JSON line):
+  value, ms_per_step  -- the timed region: W warm-up steps, then exactly K steps between two
+                  barrier + synchronize brackets, NO event recording (bracketing launches with HIP events
+                  costs the instrumented stream ~7 %).  value_repeats: the same K steps timed twice more.
+  roofline, kernels, single_pair -- a SEPARATE pass after the timed region: `--profile-pairs` pairs submitted
+                  one at a time on slot 0 with every launch bracketed by HIP events on that stream, so the
+                  durations are uncontended (what rocprofv3 --kernel-trace reports for the same kernels, since
+                  the profiler serialises launches).  roofline = the kernel with the largest total time
+                  (the per-iteration cost kernel of the large levels): algorithmic bytes (48 B per
+                  pixel-iteration, SURVEY.md 8d) / duration, over all its launches and for level 0 alone;
+                  HBM peak 8 TB/s.  kernels[] carries the same for every kernel (K-smooth: 24 B per pixel).
+  valu_roofline -- both hot kernels are bound by VALU issue, not bytes: the modelled VALU time of
+                  the level-0 launch (instruction counts of the kernel x per-instruction issue cost measured in
+                  actual cycles, profiles/r02_valu_model.json) against its measured duration.
+  pcie_inclusive -- the drop-in service call (ugsm_match_full: host buffers in and out), pageable and
+                  page-locked; never `value`.  device_copy_GBps: a 1 GiB device-to-device copy.
+  cpu_baseline -- the CPU oracle (a port: the reference has no CPU matcher) timed on this host, rank 0 /
+                  N=1 only, on a bounded sample (one 1920x1080 pair), 1 thread and all cores, median of 3.
+Other workloads (--workload 1080p | fovea16mp | fovea-shard) are parity/scaling cases, not the headline line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,7 +45,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL_ITER = 48.0  # L 12 + R 12 + (dx,dy,conf) in 12 + out 12
+BYTES_PER_PIXEL = {"k_cost": BYTES_PER_PIXEL_ITER, "k_smooth": 24.0, "k_box": 24.0, "k_warp": 36.0, "k_sqblur": 24.0, "k_seed": 24.0}
 REFERENCE_PAIRS_PER_S = {"full16mp": 0.1, "fovea16mp": 1.0 / 3.0}  # BASELINE.md section 1 (README.md:15-16)
+PROFILE_TAG = "r02"
 
 WORKLOADS = {
     "full16mp": dict(W=4928, H=3264, mode="full", desc="16MP (4928x3264) stereo pair, full-res 14-level pyramid"),
@@ -47,34 +62,86 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sample: str, threads: int, wl: dict):
-    """Times the CPU oracle (kind 'port') on a bounded sample; returns the JSON object."""
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask and the cgroup CPU quota, whichever is smaller."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline(wl: dict, runs: int = 3):
+    """The CPU oracle (kind 'port') on a bounded sample -- one 1920x1080 pair of the same generator, scaled to the
+    workload's unit by pixel-iterations -- with 1 thread and with every core of this host; median of `runs`."""
     from oracle import oracle as orc
     from ug_stereomatcher_amd import _lib, synth
     orc.build()
-    orc.set_num_threads(threads)
-    if sample == "full":
-        W, H = wl["W"], wl["H"]
-    else:
-        W, H = 1920, 1080
+    W, H = 1920, 1080
     L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 2)
-    log(f"cpu_baseline: oracle on one {W}x{H} pair, {threads} threads ...")
-    t0 = time.perf_counter()
-    if wl["mode"] == "full":
-        orc.match_full(L, R, 14)
-        pi_sample = _lib.pixel_iterations(W, H, 14, 0)
-        pi_unit = _lib.pixel_iterations(wl["W"], wl["H"], 14, 0)
-    else:
-        orc.match_foveated(L, R, 14, 7)
-        pi_sample = _lib.pixel_iterations(W, H, 14, 7)
-        pi_unit = _lib.pixel_iterations(wl["W"], wl["H"], 14, 7)
-    dt = time.perf_counter() - t0
-    # scaled to the metric's unit: pixel-iterations/s divided by the pixel-iterations of one workload pair
-    value = (pi_sample / dt) / pi_unit
-    return {"value": value, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"one {W}x{H} {wl['mode']}-mode pair ({pi_sample} pixel-iterations) in {dt:.2f} s, "
-                      f"scaled by pixel-iterations to the {wl['W']}x{wl['H']} workload ({pi_unit})",
-            "seconds": dt}
+    F = 0 if wl["mode"] == "full" else 7
+    pi_sample = _lib.pixel_iterations(W, H, 14, F)
+    pi_unit = _lib.pixel_iterations(wl["W"], wl["H"], 14, F)
+    # "all cores" = what this process may use, capped at the GPU box's CPU share of 16 per GPU (UGSM_CPU_THREADS overrides):
+    # an OpenMP team the size of the host's 256 hardware threads inside a 16-CPU share does not finish in minutes
+    ncpu = int(os.environ.get("UGSM_CPU_THREADS", min(usable_cpus(), 16)))
+
+    def leg(threads):
+        orc.set_num_threads(threads)
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            if F == 0:
+                orc.match_full(L, R, 14)
+            else:
+                orc.match_foveated(L, R, 14, F)
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        return {"threads": threads, "seconds_median": med, "seconds": ts, "value": (pi_sample / med) / pi_unit}
+
+    log(f"cpu_baseline: oracle on one {W}x{H} pair, {ncpu} threads x{runs} ...")
+    allc = leg(ncpu)
+    log(f"cpu_baseline: ... and 1 thread x{runs} ...")
+    one = leg(1)
+    return {"value": allc["value"], "unit": "pairs/s", "cores": ncpu, "kind": "port",
+            "sample": f"one {W}x{H} {wl['mode']}-mode pair ({pi_sample} pixel-iterations), median of {runs} runs, scaled by "
+                      f"pixel-iterations to the {wl['W']}x{wl['H']} workload ({pi_unit}); wall-clock bracket around the library "
+                      "call only, as UG_GPU_matcher.cpp:422-426",
+            "host_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": cpu_model(), "all_cores": allc, "one_thread": one}
+
+
+def spawn_ranks(args) -> int:
+    """`--gpus N` without a launcher: start one rank per GPU the way the driver does, from a process that has not touched
+    the GPU, and hand back the child's exit code."""
+    port = os.environ.get("MASTER_PORT", "29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    log("no launcher environment: starting", " ".join(cmd))
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -86,11 +153,15 @@ def main():
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU (HIP streams)")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="full", choices=["1080p", "full"], help="full = one pair of the workload itself (about 3-6 s at 16 MP)")
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--no-events", action="store_true", help="do not record HIP events on slot 0")
-    ap.add_argument("--all-events", action="store_true", help="bracket every kernel class, not only the dominant one (slower)")
+    ap.add_argument("--profile-pairs", type=int, default=3, help="pairs of the single-pair event pass after the timed region (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=2, help="extra timed repetitions of the K steps (value_repeats)")
+    ap.add_argument("--no-service", action="store_true", help="skip the PCIe-inclusive service-call leg")
+    ap.add_argument("--no-events", action="store_true", help="same as --profile-pairs 0 --no-service --repeats 0 (bare throughput line)")
     args = ap.parse_args()
+    if args.no_events:
+        args.profile_pairs, args.no_service, args.repeats = 0, True, 0
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1 on the way
     # (the RCCL version banner at communicator creation, driver notices) is sent to stderr instead
     sys.stdout.flush()
@@ -103,8 +174,8 @@ def main():
     from ug_stereomatcher_amd import _lib, dist as ud, synth
 
     rank, local_rank, world = ud.init()
-    if world != args.gpus and world > 1:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; reporting n_gpus={max(world, 1)}")
     n_gpus = max(world, 1)
     if rank == 0:
         ge.build_library()
@@ -120,15 +191,16 @@ def main():
     W, H, mode = wl["W"], wl["H"], wl["mode"]
     slots = max(1, args.slots)
     F = 7
-    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path,
-                       profile_events=0 if args.no_events else (2 if args.all_events else 1))
+    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0)
     fw, fh = _lib.fovea_dims(W, H, 14, F)
 
     # synthetic inputs: two distinct pairs per rank, resident in HBM before the timed region
     t0 = time.perf_counter()
-    pairs = []
+    pairs, host_pair = [], None
     for j in range(2):
         L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 2 + 16 * j + rank)
+        if j == 0:
+            host_pair = (L, R)
         pairs.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
     stride = 3 * W
     if rank == 0:
@@ -137,47 +209,45 @@ def main():
         outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(slots)]
     else:
         outs = [torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev) for _ in range(slots)]
-    state = torch.empty((3, fh, fw), dtype=torch.float32, device=dev)
+    # fovea-shard: one coarse-state buffer and one "fine phase has read it" event PER SLOT, so that the broadcast of a later
+    # step never overwrites a state an earlier step's fine phase has not copied yet, and the slots overlap
+    states = [torch.empty((3, fh, fw), dtype=torch.float32, device=dev) for _ in range(slots)]
     offsets = ud.fovea_window_offsets(n_gpus, W, H, fw, fh)
     my_off = offsets[rank % len(offsets)]
+    shard_drv = ud.UgsmShardDriver(ctx)
     torch.cuda.synchronize()
 
-    def submit(k):
-        s = k % slots
-        ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?
+    def submit(k, slot=None):
+        s = k % slots if slot is None else slot
+        ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?  (also: the slot's fine phase has consumed states[s])
         Lt, Rt = pairs[k % 2]
         if mode == "full":
             ctx.check(ctx.lib.ugsm_submit_full(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, outs[s].data_ptr()))
         elif mode == "fovea":
             ctx.check(ctx.lib.ugsm_submit_foveated(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, 0, 0,
                                                    outs[s].data_ptr(), None, None))
-        else:  # fovea-shard: pyramids everywhere, coarse on rank 0, one RCCL broadcast, fine per window
-            ctx.check(ctx.lib.ugsm_submit_pyramids(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride))
-            if rank == 0:
-                ctx.check(ctx.lib.ugsm_submit_fovea_coarse(ctx.handle, s, state.data_ptr()))
-                ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))
-            ud.broadcast_coarse_state(state, 0)
-            torch.cuda.synchronize()
-            ctx.check(ctx.lib.ugsm_submit_fovea_fine(ctx.handle, s, state.data_ptr(), my_off[0], my_off[1], outs[s].data_ptr()))
+        else:
+            ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s], rank)
 
     def run(n):
         for k in range(n):
             submit(k)
         ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
 
-    run(args.warmup)
-    ctx.reset_kernel_stats()
-    torch.cuda.synchronize()
-    ud.barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    ud.barrier()
-    dt = time.perf_counter() - t0
-    dt = ud.max_over_ranks(dt, dev)
+    def timed(n):
+        torch.cuda.synchronize()
+        ud.barrier()
+        t0 = time.perf_counter()
+        run(n)
+        torch.cuda.synchronize()
+        ud.barrier()
+        return ud.max_over_ranks(time.perf_counter() - t0, dev)
 
-    stats = ctx.kernel_stats()
-    value = n_gpus * args.steps / dt if mode != "fovea-shard" else args.steps / dt
+    run(args.warmup)
+    dt = timed(args.steps)
+    work = n_gpus if mode != "fovea-shard" else 1
+    value = work * args.steps / dt
+    repeats = [work * args.steps / timed(args.steps) for _ in range(max(0, args.repeats))]
     pi = _lib.pixel_iterations(W, H, 14, 0 if mode == "full" else F)
 
     result = {
@@ -195,54 +265,148 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["desc"], "pairs_in_flight_per_gpu": slots, "kernel_path": args.kernel_path,
                    "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}"},
+        "value_repeats": repeats,
+        "whole_pair_algorithmic_GBps": (8.913e9 if args.workload == "full16mp" else BYTES_PER_PIXEL_ITER * pi) * value / n_gpus / 1e9,
     }
-    if rank == 0:
-        # roofline of the dominant kernel from slot 0's HIP events (same stream as the launches)
-        dom = max((s for s in stats if s["name"].startswith("k_cost")), key=lambda s: s["total_ms"], default=None)
-        kernels = []
+
+    # ---- single-pair event pass: uncontended kernel durations (rank 0) ------------------------------------------------
+    if rank == 0 and args.profile_pairs > 0 and mode != "fovea-shard":
+        ctx.set_profile_events(2)
+        ctx.reset_kernel_stats()
+        t0 = time.perf_counter()
+        for k in range(args.profile_pairs):
+            submit(k, slot=0)
+            ctx.check(ctx.lib.ugsm_wait(ctx.handle, 0))
+        t_single = (time.perf_counter() - t0) / args.profile_pairs
+        ctx.set_profile_events(0)
+        stats = ctx.kernel_stats()
+        n_pairs = args.profile_pairs
+        by_name = {}
         for s in stats:
-            if s["launches"] == 0:
-                continue
-            bpp = {"k_cost": BYTES_PER_PIXEL_ITER, "k_smooth": 24.0, "k_box": 24.0, "k_warp": 36.0}.get(
-                next((p for p in ("k_cost", "k_smooth", "k_box", "k_warp") if s["name"].startswith(p)), ""), None)
-            kernels.append({"name": s["name"], "launches": s["launches"], "total_ms": s["total_ms"],
-                            "avg_us": 1e3 * s["total_ms"] / s["launches"],
-                            "GBps": (bpp * s["pixel_launches"] / (s["total_ms"] * 1e-3) / 1e9) if bpp and s["total_ms"] > 0 else None})
-        if dom and dom["total_ms"] > 0:
-            achieved = BYTES_PER_PIXEL_ITER * dom["pixel_launches"] / (dom["total_ms"] * 1e-3) / 1e9
-            traffic = None
+            e = by_name.setdefault(s["name"], {"launches": 0, "total_ms": 0.0, "pixel_launches": 0.0, "levels": {}})
+            e["launches"] += s["launches"]
+            e["total_ms"] += s["total_ms"]
+            e["pixel_launches"] += s["pixel_launches"]
+            e["levels"][s["level"]] = s
+        kernels = []
+        for name, e in sorted(by_name.items(), key=lambda kv: -kv[1]["total_ms"]):
+            bpp = next((v for k, v in BYTES_PER_PIXEL.items() if name.startswith(k)), None)
+            row = {"name": name, "launches_per_pair": e["launches"] / n_pairs, "ms_per_pair": e["total_ms"] / n_pairs,
+                   "avg_us": 1e3 * e["total_ms"] / e["launches"]}
+            if bpp:
+                row["bytes_per_pixel"] = bpp
+                row["GBps"] = bpp * e["pixel_launches"] / (e["total_ms"] * 1e-3) / 1e9
+                row["frac_of_hbm_peak"] = row["GBps"] / HBM_PEAK_GBS
+                l0 = e["levels"].get(0)
+                if l0 and l0["launches"]:
+                    row["level0"] = {"launches_per_pair": l0["launches"] / n_pairs, "avg_us": 1e3 * l0["total_ms"] / l0["launches"],
+                                     "GBps": bpp * l0["pixel_launches"] / (l0["total_ms"] * 1e-3) / 1e9}
+                    row["level0"]["frac_of_hbm_peak"] = row["level0"]["GBps"] / HBM_PEAK_GBS
+            kernels.append(row)
+        result["kernels"] = kernels
+        kernel_ms = sum(e["total_ms"] for e in by_name.values()) / n_pairs
+        result["single_pair"] = {"ms_per_pair_wall": 1e3 * t_single, "pairs_per_s": 1.0 / t_single, "kernel_ms_per_pair": kernel_ms,
+                                 "pairs": n_pairs, "note": "one pair in flight, every launch bracketed by HIP events on its stream"}
+        # the dominant kernel: the cost kernel that carries most of the pair's pixel-iterations (the marching kernel of the large
+        # levels; the LDS-tiled one only serves the latency-bound small levels)
+        dom = max((k for k in kernels if k["name"].startswith("k_cost")), key=lambda k: by_name[k["name"]]["pixel_launches"], default=None)
+        if dom:
+            e = by_name[dom["name"]]
+            traffic, prof = None, {}
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            valu_busy = None
             if os.path.exists(tpath):
                 try:
-                    pj = json.load(open(tpath))
-                    traffic = pj.get(args.workload, {}).get(dom["name"])
-                    valu_busy = pj.get("valu_insts_per_simd_cycle_level0", {}).get(dom["name"])
+                    prof = json.load(open(tpath))
+                    traffic = prof.get(args.workload, {}).get(dom["name"])
                 except Exception:
-                    traffic = None
-            result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom["name"],
-                                  "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
-                                  "algorithmic_bytes_per_launch_avg": BYTES_PER_PIXEL_ITER * dom["pixel_launches"] / dom["launches"],
-                                  "valu_insts_per_simd_cycle_level0": valu_busy,
-                                  "note": "48 B per pixel-iteration x pixels per launch / HIP-event duration, slot 0, timed region; the kernel is "
-                                          "bound by VALU issue, not bytes: valu_insts_per_simd_cycle_level0 = SQ_INSTS_VALU / (SQ_BUSY_CU_CYCLES x 4) "
-                                          "from profiles/, times ~3.3 cycles per instruction of this mix = busy fraction (DESIGN.md section 6)"}
-            # whole-pair figure: all algorithmic bytes of a pair / the pair's share of wall time
-            result["whole_pair_algorithmic_GBps"] = (BYTES_PER_PIXEL_ITER * pi * value / n_gpus) / 1e9
-        result["kernels"] = kernels
+                    prof = {}
+            result["roofline"] = {
+                "bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": dom["name"], "launches_per_pair": dom["launches_per_pair"], "avg_launch_us": dom["avg_us"],
+                "algorithmic_bytes_per_launch_avg": BYTES_PER_PIXEL_ITER * e["pixel_launches"] / e["launches"],
+                "level0": dom.get("level0"),
+                "traffic_source": (f"profiles/pmc_traffic.json ({prof.get('_tag', '?')}: PMC passes of tools/profile_round.sh, not measured in this run)"
+                                   if traffic is not None else None),
+                "note": "algorithmic bytes (48 B per pixel-iteration x pixels of the launch) / HIP-event duration on the launching stream, "
+                        "single-pair pass after the timed region (uncontended: agrees with rocprofv3 --kernel-trace --stats of this command, "
+                        "which serialises launches); the kernel is bound by VALU issue, see valu_roofline"}
+            vpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_valu_model.json")
+            if os.path.exists(vpath) and dom.get("level0") and args.workload == "full16mp":
+                try:
+                    vm = json.load(open(vpath))
+                    result["valu_roofline"] = valu_roofline(vm, by_name, n_pairs, W * H)
+                except Exception as ex:  # a stale model file must not take the line down
+                    result["valu_roofline"] = {"error": str(ex)}
+
+    # ---- device copy rate and the PCIe-inclusive service call (rank 0, N = 1) ------------------------------------------
+    if rank == 0 and n_gpus == 1 and not args.no_service:
+        a = torch.zeros(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        torch.add(a, 1.0, out=b)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            torch.add(a, 1.0, out=b)  # a streaming elementwise kernel: 1 GiB read + 1 GiB written per pass
+        e1.record()
+        torch.cuda.synchronize()
+        result["device_copy_GBps"] = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
+        del a, b
+        if mode == "full":
+            L, R = host_pair
+            out = np.empty((3, H, W), np.float32)
+
+            def call(Lh, Rh, oh):
+                ts = []
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    ctx.check(ctx.lib.ugsm_match_full(ctx.handle, Lh.ctypes.data, Rh.ctypes.data, W, H, stride,
+                                                      oh[0].ctypes.data, oh[1].ctypes.data, oh[2].ctypes.data))
+                    ts.append(time.perf_counter() - t0)
+                return sorted(ts[1:])[1]  # median of the last three
+            t_page = call(L, R, out)
+            pl, pr, po = ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W))
+            pl[...] = L
+            pr[...] = R
+            t_pin = call(pl, pr, po)
+            result["pcie_inclusive"] = {"pageable_ms_per_pair": 1e3 * t_page, "pageable_pairs_per_s": 1.0 / t_page,
+                                        "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
+                                        "note": "ugsm_match_full, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
+                                                "(193 MB); median of 3 calls"}
+
+    if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_threads, wl)
+                result["cpu_baseline"] = cpu_baseline(wl)
             except Exception as e:  # the baseline leg must never take the measurement down
-                result["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": args.cpu_threads, "kind": "port",
-                                          "sample": f"failed: {e}"}
+                result["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     ctx.close()
     import torch.distributed as td
     if td.is_initialized():
         td.destroy_process_group()
+
+
+def valu_roofline(vm: dict, by_name: dict, n_pairs: int, px0: int) -> dict:
+    """Modelled VALU time of the level-0 launches of the two hot kernels against their measured durations.
+    vm (profiles/rNN_valu_model.json, written by tools/valu_model.py from the kernels' ISA, the valubench cost table and the
+    in-kernel clock): per kernel, VALU issue cycles per wave per row step, and the geometry that turns pixels into row steps."""
+    out = {"source": vm.get("_source"), "clock_GHz": vm["clock_GHz"], "simds": vm["simds"], "kernels": []}
+    for name, m in vm["kernels"].items():
+        e = by_name.get(name)
+        l0 = e["levels"].get(0) if e else None
+        if not l0 or not l0["launches"]:
+            continue
+        measured_us = 1e3 * l0["total_ms"] / l0["launches"]
+        wave_steps = px0 / m["valid_pixels_per_wave_step"] * m["row_overhead"]
+        model_us = wave_steps * m["valu_cycles_per_wave_step"] / vm["simds"] / (vm["clock_GHz"] * 1e3)
+        out["kernels"].append({"name": name, "level0_measured_us": measured_us, "level0_valu_model_us": model_us,
+                               "frac": model_us / measured_us, "valu_cycles_per_wave_step": m["valu_cycles_per_wave_step"],
+                               "valu_instructions_per_wave_step": m["valu_instructions_per_wave_step"],
+                               "valid_pixels_per_wave_step": m["valid_pixels_per_wave_step"], "row_overhead": m["row_overhead"]})
+    out["note"] = ("frac = time the kernel's VALU instruction stream needs at the measured per-instruction issue costs (actual cycles, "
+                   "tools/valubench.hip) / measured duration; ~1 means the launch is VALU-issue bound")
+    return out
 
 
 if __name__ == "__main__":

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UGSM_ABI_VERSION 1
+#define UGSM_ABI_VERSION 2
 
 /* status codes */
 #define UGSM_OK                0
@@ -210,14 +210,21 @@ int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, floa
 
 typedef struct ugsm_kernel_stat {
     char name[48];
+    int level;              /* pyramid level the launches belong to; -1: none (stage entry points, copies) */
+    int reserved;
     long long launches;
     double total_ms;        /* sum of HIP-event durations (profile_events, slot 0) */
     double pixel_launches;  /* sum over launches of pixels processed */
 } ugsm_kernel_stat;
 
-/* Fills up to `cap` entries; returns the number of kernel classes. */
+/* One entry per (kernel, pyramid level) with at least one harvested launch (launches are harvested by ugsm_wait).
+ * Fills up to `cap` entries; returns the number of entries there are. */
 int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap);
 int ugsm_reset_kernel_stats(ugsm_ctx *ctx);
+/* Changes ugsm_config.profile_events of a live context (0 off, 1 cost kernels, 2 every kernel); takes effect for
+ * launches enqueued afterwards.  bench.py times its throughput region with events off and reads kernel durations
+ * from a separate single-pair pass. */
+int ugsm_set_profile_events(ugsm_ctx *ctx, int mode);
 
 /* Device-memory helpers so a C/C++ host (the ROS node) needs no HIP headers. */
 int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes);

@@ -89,3 +89,107 @@ def test_fovea_window_offsets():
     offs = ud.fovea_window_offsets(8, 4928, 3264, 615, 407)
     assert len(offs) == 8 and offs[0] == (0, 0) and len(set(offs)) == 8
     assert all(abs(x) <= 4928 // 2 and abs(y) <= 3264 // 2 for x, y in offs)
+
+
+# ---- the fovea-shard submit sequence, two ranks, two slots ---------------------------------------------
+
+class OracleShardDriver:
+    """The four calls UgsmShardDriver makes, answered by the CPU oracle's stage functions (test double: lives in tests/).
+    Work is deferred to wait() / the next use of the slot, like the asynchronous library, so that a state buffer shared
+    between slots -- the hazard the per-slot buffers remove -- would be caught."""
+
+    def __init__(self, orc, levels, F):
+        self.orc, self.levels, self.F = orc, levels, F
+        self.slot = {}
+
+    def submit_pyramids(self, slot, L, R, W, H, stride):
+        self._finish(slot)
+        o = self.orc
+        self.slot[slot] = dict(pl=o.pyramid(o.rgb_to_planes(L.numpy()), self.levels), pr=o.pyramid(o.rgb_to_planes(R.numpy()), self.levels),
+                               W=W, H=H, fine=None)
+
+    def submit_coarse(self, slot, state):
+        o, s = self.orc, self.slot[slot]
+        top = self.levels - 1
+        cur = np.zeros_like(s["pl"][top])
+        for i in range(top, self.F - 2, -1):
+            mi = o.iterations_for_level(i)
+            cur, _ = o.iterate_level(s["pl"][i], s["pr"][i], cur, mi, o.smooth_passes_for_level(i), i == top)
+            if i > self.F - 1:
+                cur = o.seed(cur, s["pl"][i - 1].shape[2], s["pl"][i - 1].shape[1])
+        state.copy_(torch.from_numpy(cur))
+
+    def wait(self, slot):
+        self._finish(slot)
+
+    def submit_fine(self, slot, state, off, out):
+        self.slot[slot]["fine"] = (state, off, out)  # reads `state` later, like the stream-ordered copy in the library
+
+    def _finish(self, slot):
+        s = self.slot.get(slot)
+        if not s or not s["fine"]:
+            return
+        state, off, out = s["fine"]
+        s["fine"] = None
+        o, F = self.orc, self.F
+        fw, fh, ox, oy, cx, cy = o.fovea_geometry(s["W"], s["H"], self.levels, F, off[0], off[1])
+        cur = state.numpy().copy()
+        out[:, F - 1] = torch.from_numpy(cur)
+        wup, hup = s["pl"][F - 2].shape[2], s["pl"][F - 2].shape[1]
+        for i in range(F - 2, -1, -1):
+            cur = o.seed_fovea(cur, wup, hup, cx[i], cy[i])
+            L3 = np.ascontiguousarray(s["pl"][i][:, oy[i]:oy[i] + fh, ox[i]:ox[i] + fw])
+            R3 = np.ascontiguousarray(s["pr"][i][:, oy[i]:oy[i] + fh, ox[i]:ox[i] + fw])
+            cur, _ = o.iterate_level(L3, R3, cur, o.iterations_for_level(i), o.smooth_passes_for_level(i), False)
+            out[:, i] = torch.from_numpy(cur)
+
+
+def _shard_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      UGSM_ORACLE_THREADS="2")
+    from oracle import oracle as orc
+    from ug_stereomatcher_amd import dist as ud, synth
+    ud.init(backend="gloo")
+    W, H, levels, F, slots, steps = 200, 150, 8, 4, 2, 3
+    fw, fh, *_ = orc.fovea_geometry(W, H, levels, F)
+    pairs = [tuple(torch.from_numpy(a) for a in synth.make_pair(W, H, 900 + j)[:2]) for j in range(2)]
+    offsets = [(0, 0), (37, -21)]
+    drv = OracleShardDriver(orc, levels, F)
+    states = [torch.zeros((3, fh, fw)) for _ in range(slots)]
+    outs = [torch.zeros((3, F, fh, fw)) for _ in range(slots)]
+    got = []
+    for k in range(steps):  # bench.py's submit(): slot free? then the step
+        s = k % slots
+        drv.wait(s)
+        if k >= slots:
+            got.append((k - slots, outs[s].clone()))
+        L, R = pairs[k % 2]
+        ud.fovea_shard_step(drv, s, L, R, W, H, 3 * W, states[s], offsets[rank], outs[s], rank)
+    for k in range(max(steps - slots, 0), steps):
+        drv.wait(k % slots)
+        got.append((k, outs[k % slots].clone()))
+    ok = True
+    for k, st in got:
+        L, R = pairs[k % 2]
+        exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[rank][0], offsets[rank][1])
+        ok = ok and bool((st.numpy().view(np.uint32) == exp.view(np.uint32)).all())
+    out_q.put((rank, ok, len(got)))
+    dist.destroy_process_group()
+
+
+def test_fovea_shard_sequence_world_size_2_two_slots():
+    """coarse on rank 0 -> one broadcast -> fine on every rank, three steps over two slots: rank 0's window (the centred fovea)
+    equals the one-shot foveated result bit for bit, and so does rank 1's off-centre window."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 3), (1, True, 3)]

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""VALU-issue model of the hot kernels (development tool; writes profiles/<tag>_valu_model.{json,md}).
+
+Both hot kernels are bound by VALU issue, not by bytes.  This tool makes that claim checkable:
+  1. it compiles the kernel sources to gfx950 assembly and finds each hot kernel's innermost loops;
+  2. it prices every VALU instruction of those loops with the issue cost measured by tools/valubench.hip in ACTUAL
+     shader cycles (cycles per wave-instruction per SIMD with four waves per SIMD, wall time x in-kernel clock);
+  3. it reports the instruction mix, the mean cost per VALU instruction and -- for the marching kernels, whose loop
+     trip is one image row per wave -- the VALU cycles per wave row step;
+  4. with the dynamic VALU instruction counts of the level-0 launches (SQ_INSTS_VALU, PMC pass of tools/profile_round.sh)
+     bench.py turns this into a modelled VALU time and compares it with the measured duration (`valu_roofline`).
+
+usage: valu_model.py <valubench.txt> <tag> [pmc_dir]
+"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ug_stereomatcher_amd", "csrc")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-x", "hip", "-S",
+         "--cuda-device-only"]
+
+# valubench kernel -> cost class
+BENCH_CLASS = {"k_fma": "fma32", "k_fmac": "fma32", "k_mul": "plain32", "k_add": "plain32", "k_mul_literal": "plain32", "k_mov": "plain32",
+               "k_add_dpp": "dpp", "k_mul_dpp": "dpp", "k_dpp": "dpp", "k_rcp": "trans32", "k_dscale": "div_scale32", "k_dfmas": "slow32",
+               "k_dfix": "slow32", "k_minimum3": "slow32", "k_min3": "slow32", "k_cnd64": "slow32", "k_max": "slow32", "k_med3": "slow32",
+               "k_cmp_vcc": "slow32", "k_cmp_sgpr": "slow32", "k_floor": "slow32", "k_cvt_i32": "slow32", "k_fma64": "f64", "k_mul64": "f64",
+               "k_add64": "f64", "k_rcp64": "trans64", "k_cvt_f64_f32": "f64", "k_cvt_f32_f64": "f64", "k_add_u32": "int",
+               "k_mad_u32_u24": "int3", "k_lshlrev_b32": "int", "k_add_lshl_u32": "int3", "k_med3_i32": "int3", "k_pkmul": "packed",
+               "k_pkadd": "packed", "k_pkfma": "packed"}
+
+
+def read_costs(path):
+    """cycles per wave-instruction per SIMD at 4 waves/SIMD: the wall-clock figure (quoted at the nominal 2.4 GHz) x measured clock / 2.4"""
+    acc = collections.defaultdict(list)
+    clocks = []
+    for line in open(path):
+        m = re.match(r"(k_\w+)\s+(\d)\s+([\d.]+)\s+([\d.]+)\s+\(([\d.]+)\)", line)
+        if m and m.group(2) == "4" and m.group(1) in BENCH_CLASS:
+            clk = float(m.group(4))
+            acc[BENCH_CLASS[m.group(1)]].append(float(m.group(5)) * clk / 2.4)
+            clocks.append(clk)
+    return {c: sum(v) / len(v) for c, v in acc.items()}, sum(clocks) / max(len(clocks), 1)
+
+
+def classify(op, text):
+    if "dpp" in text:
+        return "dpp"
+    if op.startswith("v_pk_"):
+        return "packed"
+    if op.endswith("_f64") or "_f64_" in op or op in ("v_ldexp_f64",):
+        return "trans64" if op.startswith("v_rcp_f64") or op.startswith("v_rsq_f64") else "f64"
+    if op.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_")):
+        return "trans32"
+    if op.startswith("v_div_scale_f32"):
+        return "div_scale32"
+    if op.startswith(("v_fma_f32", "v_fmac_f32")):
+        return "fma32"
+    if op.startswith(("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32")):
+        return "plain32"
+    if op.startswith(("v_mad_u32", "v_mad_i32", "v_add_lshl", "v_lshl_add", "v_add3", "v_med3_i32", "v_med3_u32", "v_lshl_or", "v_and_or", "v_bfe",
+                      "v_mul_lo", "v_mul_hi", "v_mad_u64")):
+        return "int3"
+    if op.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co", "v_addc", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32",
+                      "v_or_b32", "v_xor_b32", "v_mul_u32_u24", "v_mul_i32_i24", "v_add_i32", "v_sub_i32", "v_not_b32")):
+        return "int"
+    return "slow32"  # compares, selects, min/max/med3, floor, conversions, div_fmas/div_fixup, readlane ...
+
+
+def loops_of(asm_path, name_re):
+    """{kernel symbol: {loop header label: [instruction text]}} for innermost loops.  Basic blocks that hold a binary64
+    division (v_rcp_f64: the literal fallbacks of PolyDisparity's quotients, entered only by the lanes that need them and
+    skipped by s_cbranch_execz otherwise) are left out: they are not on the hot path."""
+    out = {}
+    cur = None
+    header = None
+    block = []
+
+    def flush():
+        if cur and header and block and not any("v_rcp_f64" in t for t in block):
+            out[cur][header] += block
+
+    for line in open(asm_path):
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            flush()
+            block = []
+            cur = m.group(1) if re.search(name_re, m.group(1)) else None
+            if cur:
+                out[cur] = collections.OrderedDict()
+            header = None
+            continue
+        if cur is None:
+            continue
+        if line.startswith(".Lfunc_end"):
+            flush()
+            block = []
+            cur = None
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):\s*;?\s*(.*)", line) or re.match(r"^; %bb\.(\d+):\s*;?\s*(.*)", line)
+        if m:
+            flush()
+            block = []
+            lab, com = m.group(1), m.group(2)
+            if "Inner Loop Header" in com:
+                header = lab
+                out[cur].setdefault(header, [])
+            else:
+                mm = re.search(r"in Loop: Header=(BB\d+_\d+)", com)
+                header = ".L" + mm.group(1) if mm and (".L" + mm.group(1)) in out[cur] else None
+            continue
+        t = line.strip()
+        if t and not t.startswith((";", ".")):
+            block.append(t)
+    flush()
+    return out
+
+
+def price(instrs, costs):
+    mix = collections.Counter()
+    other = collections.Counter()
+    for t in instrs:
+        op = t.split()[0]
+        if op.startswith("v_"):
+            mix[classify(op, t)] += 1
+        elif op.startswith("s_"):
+            other["salu"] += 1
+        elif op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+            other["vmem"] += 1
+        elif op.startswith("ds_"):
+            other["lds"] += 1
+    n = sum(mix.values())
+    cyc = sum(k * costs.get(c, costs["slow32"]) for c, k in mix.items())
+    return {"valu_instructions": n, "valu_cycles": cyc, "mean_cycles_per_valu": cyc / max(n, 1), "mix": dict(mix), "other": dict(other)}
+
+
+def main():
+    bench_txt, tag = sys.argv[1], sys.argv[2]
+    costs, clock = read_costs(bench_txt)
+    costs.setdefault("int", costs["plain32"])
+    costs.setdefault("int3", costs["slow32"])
+    costs.setdefault("packed", 2 * costs["plain32"])
+    tmp = "/tmp/ugsm_valu_model"
+    os.makedirs(tmp, exist_ok=True)
+    report = {"_source": f"tools/valu_model.py on {os.path.basename(bench_txt)}", "_tag": tag, "clock_GHz": round(clock, 3), "simds": 1024,
+              "cost_cycles_per_wave_instruction": {k: round(v, 2) for k, v in sorted(costs.items())}, "kernels": {}}
+    md = [f"# {tag}: VALU-issue model of the hot kernels\n",
+          f"Issue costs (actual shader cycles per wave-instruction per SIMD, four waves per SIMD; `{os.path.basename(bench_txt)}`; mean in-kernel "
+          f"clock {clock:.2f} GHz):\n", "| class | cycles | what is in it |", "|---|---|---|"]
+    what = {"plain32": "v_add/sub/mul_f32, v_mov_b32", "fma32": "v_fma_f32, v_fmac_f32", "dpp": "any VALU instruction with a DPP operand (wave_shr/shl)",
+            "trans32": "v_rcp_f32", "div_scale32": "v_div_scale_f32", "slow32": "v_cmp*, v_cndmask, v_min/max/med3, v_floor, v_cvt_*, v_div_fmas/fixup_f32",
+            "f64": "v_fma/mul/add_f64, v_cvt_f64_f32, v_cvt_f32_f64", "trans64": "v_rcp_f64", "int": "v_add_u32, shifts, logic", "int3": "v_mad_u32_u24, v_add_lshl_u32, v_med3_i32",
+            "packed": "v_pk_*_f32"}
+    for k, v in sorted(costs.items()):
+        md.append(f"| {k} | {v:.2f} | {what.get(k, '')} |")
+    jobs = [("ugsm_kernels_march.hip", r"k_cost_marchILi1ELb0", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
+            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0", "k_smooth_fused", None),
+            ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None)]
+    for src, name_re, short, geom in jobs:
+        asm = os.path.join(tmp, src.replace(".hip", ".s"))
+        if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(CSRC, src)):
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(CSRC, src), "-o", asm], stderr=subprocess.DEVNULL)
+        lp = loops_of(asm, name_re)
+        for sym, loops in lp.items():
+            if not loops:
+                continue
+            priced = {h: price(ins, costs) for h, ins in loops.items()}
+            entry = {"symbol": sym}
+            if geom:
+                # the row loops: four bodies (interior / frame strips x guarded / full division); the production case on in-range
+                # data is the interior body with the guarded division = the loop with no v_div_scale_f32 and the fewest selects
+                rows = {h: p for h, p in priced.items() if p["valu_instructions"] > 400}
+                pick = min(rows, key=lambda h: (rows[h]["mix"].get("div_scale32", 0), rows[h]["valu_instructions"]))
+                p = rows[pick]
+                entry.update({"loop": pick, "valu_instructions_per_wave_step": p["valu_instructions"] / geom["steps_per_trip"],
+                              "valu_cycles_per_wave_step": p["valu_cycles"] / geom["steps_per_trip"],
+                              "mean_cycles_per_valu": p["mean_cycles_per_valu"], "mix_per_trip": p["mix"], "other_per_trip": p["other"],
+                              "valid_pixels_per_wave_step": geom["valid_pixels_per_wave_step"]})
+            else:
+                tot = collections.Counter()
+                allins = []
+                for h, ins in loops.items():
+                    allins += ins
+                p = price(allins, costs)
+                entry.update({"loops": len(loops), "mean_cycles_per_valu": p["mean_cycles_per_valu"], "mix_static": p["mix"]})
+            report["kernels"][short] = entry
+            md.append(f"\n## {short}\n")
+            md.append("```\n" + json.dumps(entry, indent=1) + "\n```")
+    out = os.path.join(ROOT, "profiles")
+    json.dump(report, open(os.path.join(out, f"{tag}_valu_model.json"), "w"), indent=1)
+    open(os.path.join(out, f"{tag}_valu_model.md"), "w").write("\n".join(md) + "\n")
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()

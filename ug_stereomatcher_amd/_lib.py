@@ -31,7 +31,7 @@ EXPORTS = [
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_get_kernel_stats",
-    "ugsm_reset_kernel_stats", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
+    "ugsm_reset_kernel_stats", "ugsm_set_profile_events", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
 
 
@@ -48,8 +48,8 @@ class Config(C.Structure):
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_longlong), ("total_ms", C.c_double),
-                ("pixel_launches", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("level", C.c_int), ("reserved", C.c_int), ("launches", C.c_longlong),
+                ("total_ms", C.c_double), ("pixel_launches", C.c_double)]
 
 
 _lib = None
@@ -105,6 +105,7 @@ def load():
     lib.ugsm_stage_div_probe.argtypes = [vp, vp, vp, vp, i]
     lib.ugsm_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), i]
     lib.ugsm_reset_kernel_stats.argtypes = [vp]
+    lib.ugsm_set_profile_events.argtypes = [vp, i]
     lib.ugsm_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]
     lib.ugsm_dev_free.argtypes = [vp, vp]
     lib.ugsm_host_alloc.argtypes = [vp, C.POINTER(vp), C.c_longlong]
@@ -265,10 +266,15 @@ class Context:
         self.check(self.lib.ugsm_wait(self._h, slot))
 
     def kernel_stats(self):
-        arr = (KernelStat * 16)()
-        n = self.lib.ugsm_get_kernel_stats(self._h, arr, 16)
-        return [dict(name=arr[k].name.decode(), launches=int(arr[k].launches), total_ms=float(arr[k].total_ms),
-                     pixel_launches=float(arr[k].pixel_launches)) for k in range(min(n, 16))]
+        """One dict per (kernel, pyramid level) with harvested launches; level -1 = not tied to a level."""
+        cap = 512
+        arr = (KernelStat * cap)()
+        n = self.lib.ugsm_get_kernel_stats(self._h, arr, cap)
+        return [dict(name=arr[k].name.decode(), level=int(arr[k].level), launches=int(arr[k].launches), total_ms=float(arr[k].total_ms),
+                     pixel_launches=float(arr[k].pixel_launches)) for k in range(min(n, cap))]
+
+    def set_profile_events(self, mode: int):
+        self.check(self.lib.ugsm_set_profile_events(self._h, int(mode)))
 
     def reset_kernel_stats(self):
         self.check(self.lib.ugsm_reset_kernel_stats(self._h))

@@ -141,10 +141,17 @@ __device__ __forceinline__ void poly_fast(float c, float l, float r, float thr, 
     float b1 = (r - l) / 2.0f;
     float c1 = r - (c + b1);
     if (c1 < 0.0f) {
-        float dh;
-        if ((fabsf(b1) >= 0x1p-100f || b1 == 0.0f) && c1 <= -0x1p-100f) dh = (-b1 * 0.5f) / c1;
-        else dh = (float)(((double)(-b1) * 0.5) / (double)c1);
-        dh = fminf(thr, fmaxf(dh, -thr));
+        // The binary32 quotient for every lane; the binary64 route only when some lane of the wave needs it, behind a
+        // wave-uniform branch: written as `cond ? f32 : f64` the compiler evaluates BOTH divisions for every pixel and selects
+        // (the binary64 one costs ~80 issue cycles per parabola).
+        float dh = (-b1 * 0.5f) / c1;
+        const bool f32_ok = (fabsf(b1) >= 0x1p-100f || b1 == 0.0f) && c1 <= -0x1p-100f;
+        if (__builtin_amdgcn_ballot_w64(!f32_ok) != 0) {
+            asm volatile("; binary64 route of PolyDisparity's first quotient" ::: "memory");  // (keeps the block from being speculated)
+            if (!f32_ok) dh = (float)(((double)(-b1) * 0.5) / (double)c1);
+        }
+        // fmin(thr, fmax(dh, -thr)) as one v_med3_f32: dh is never a NaN here (b1, c1 finite, c1 < 0) and thr > 0
+        dh = __builtin_amdgcn_fmed3f(dh, -thr, thr);
         float cstar = (c1 * dh + b1) * dh + c;
         if (cstar > 1.0f) {
             float d = cstar - c;

@@ -25,13 +25,20 @@ namespace {
 
 constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
-enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COUNT };
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
-    {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc"},
-    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc"}};
+    {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_smooth_march",
+     "k_pyr_base"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-"}};
+constexpr int kNoLevel = UGSM_MAX_LEVELS;  // stats cell of launches that belong to no pyramid level
+struct StatCell {
+    long long launches = 0;
+    double total_ms = 0, pixel_launches = 0;
+};
 
 struct EvRec {
     int kclass;
+    int level;
     double pixels;
     hipEvent_t a, b;
 };
@@ -52,7 +59,8 @@ struct Slot {
     size_t hout_cap = 0;
     bool have_pyr = false;
     bool have_coarse = false;
-    bool range_known = false;  // range_bad describes the images the next run_level works on
+    bool range_known = false;
+    int cur_level = kNoLevel;  // pyramid level the launches being enqueued belong to (statistics only)  // range_bad describes the images the next run_level works on
     std::vector<EvRec> pending;
     std::vector<hipEvent_t> pool;
 };
@@ -63,7 +71,7 @@ struct ugsm_ctx {
     ugsm_config cfg;
     std::vector<Slot> slots;
     std::string err;
-    ugsm_kernel_stat stats[KC_COUNT];
+    StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
 };
 
 namespace {
@@ -228,9 +236,10 @@ struct Timer {
     {
         // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
         // has ~750 launches; bracketing all of them costs slot 0 about 20 %); 2: every kernel class
-        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && kclass == KC_COST));
+        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && (kclass == KC_COST || kclass == KC_COST_MARCH)));
         if (!on) return;
         rec.kclass = kclass;
+        rec.level = sl->cur_level;
         rec.pixels = pixels;
         for (hipEvent_t *e : {&rec.a, &rec.b}) {
             if (!s->pool.empty()) {
@@ -256,9 +265,10 @@ void harvest(ugsm_ctx *ctx, Slot &s)
     for (EvRec &r : s.pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
-            ctx->stats[r.kclass].launches += 1;
-            ctx->stats[r.kclass].total_ms += ms;
-            ctx->stats[r.kclass].pixel_launches += r.pixels;
+            StatCell &c = ctx->cells[r.kclass][r.level];
+            c.launches += 1;
+            c.total_ms += ms;
+            c.pixel_launches += r.pixels;
         }
         s.pool.push_back(r.a);
         s.pool.push_back(r.b);
@@ -274,8 +284,9 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     const bool ref = ctx->cfg.kernel_path == 1;
     // levels 0, 1, 2 in one pass over the rgb8 input (k_pyr_base); the one-stage-per-kernel path keeps the three launches
     const bool base = !ref && levels >= 3;
+    s.cur_level = 0;
     if (base) {
-        Timer t(ctx, &s, si, KC_PYR, (double)s.W * s.H);
+        Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H);
         launch_pyr_base(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad);
     } else {
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
@@ -285,18 +296,21 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
     for (int i = 0; i < levels; i++) {
         if (i == 0 && levels > 1 && !base) {
+            s.cur_level = 1;
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
             float sf = (float)kScale;
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
             else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad);
         }
         if (i + 2 < levels && !(base && i == 0)) {
+            s.cur_level = i + 2;
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
             if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
             else launch_blur_decimate(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad);
         }
     }
+    s.cur_level = kNoLevel;
     HIPCHK(ctx, hipGetLastError());
     return UGSM_OK;
 }
@@ -334,11 +348,12 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             int p = std::min(left, 5);
             left -= p;
             if (p == 0 && !do_box) break;
-            Timer t(ctx, &s, si, KC_SMOOTH, px);
+            const bool march = p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx->cfg, W, H);
+            Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : KC_SMOOTH, px);
             const bool box_now = do_box && left == 0;
             float *dst = (left == 0 && final_out) ? final_out : b;
-            // five passes at a time on a large level: the marching kernel; anything else: the LDS-tiled one
-            if (p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx->cfg, W, H)) launch_smooth_march(s.st, a, dst, W, H, box_now, ctx->cfg.march_np, ctx->cfg.march_rows);
+            // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
+            if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, ctx->cfg.march_np, ctx->cfg.march_rows);
             else launch_smooth_fused(s.st, a, dst, W, H, p, box_now);
             if (dst == final_out) a = final_out;
             else std::swap(a, b);
@@ -377,8 +392,9 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             Timer t(ctx, &s, si, KC_COST, px);
             launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
-            Timer t(ctx, &s, si, KC_COST, px);
-            if (use_march(ctx->cfg, W, H)) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            const bool march = use_march(ctx->cfg, W, H);
+            Timer t(ctx, &s, si, march ? KC_COST_MARCH : KC_COST, px);
+            if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
         float *a = other, *b = cur;
@@ -418,6 +434,7 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
     for (int i = top; i >= 0; i--) {
+        s.cur_level = i;
         const int mi = level_iterations(i);
         // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
         const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0;
@@ -443,6 +460,7 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
     for (int i = top; i >= F - 1; i--) {
+        s.cur_level = i;
         const int mi = level_iterations(i);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
                        level_smooth(i), i == top, 1, mi, cur, other, nullptr));
@@ -470,6 +488,7 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
     // stack row block F-1 = the whole level F-1 (UG_GPU_matcher.cpp:293-303)
     launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)(F - 1) * fn, (size_t)F * fn, g.fw);
     for (int i = F - 2; i >= 0; i--) {
+        s.cur_level = i;
         {   // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
             Timer t(ctx, &s, si, KC_SEED, (double)fn);
             launch_seed(s.st, cur, g.fw, g.fh, other, g.fw, g.fh, g.cx[i], g.cy[i]);
@@ -574,10 +593,6 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
     ctx->slots.resize(cfg.slots);
-    for (int k = 0; k < KC_COUNT; k++) {
-        memset(&ctx->stats[k], 0, sizeof(ugsm_kernel_stat));
-        snprintf(ctx->stats[k].name, sizeof ctx->stats[k].name, "%s", kClassName[cfg.kernel_path][k]);
-    }
     for (Slot &s : ctx->slots) {
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&s.range_bad, 64) != hipSuccess) {
             ugsm_destroy(ctx);
@@ -991,18 +1006,36 @@ int ugsm_get_kernel_stats(ugsm_ctx *ctx, ugsm_kernel_stat *out, int cap)
 {
     if (!ctx) return 0;
     int n = 0;
-    for (int k = 0; k < KC_COUNT && out && n < cap; k++) out[n++] = ctx->stats[k];
-    return KC_COUNT;
+    for (int k = 0; k < KC_COUNT; k++)
+        for (int l = 0; l <= UGSM_MAX_LEVELS; l++) {
+            const StatCell &c = ctx->cells[k][l];
+            if (c.launches == 0) continue;
+            if (out && n < cap) {
+                ugsm_kernel_stat &o = out[n];
+                memset(&o, 0, sizeof o);
+                snprintf(o.name, sizeof o.name, "%s", kClassName[ctx->cfg.kernel_path][k]);
+                o.level = l == kNoLevel ? -1 : l;
+                o.launches = c.launches;
+                o.total_ms = c.total_ms;
+                o.pixel_launches = c.pixel_launches;
+            }
+            n++;
+        }
+    return n;
 }
 
 int ugsm_reset_kernel_stats(ugsm_ctx *ctx)
 {
     if (!ctx) return UGSM_ERR_BAD_ARG;
-    for (int k = 0; k < KC_COUNT; k++) {
-        ctx->stats[k].launches = 0;
-        ctx->stats[k].total_ms = 0;
-        ctx->stats[k].pixel_launches = 0;
-    }
+    for (int k = 0; k < KC_COUNT; k++)
+        for (int l = 0; l <= UGSM_MAX_LEVELS; l++) ctx->cells[k][l] = StatCell();
+    return UGSM_OK;
+}
+
+int ugsm_set_profile_events(ugsm_ctx *ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return UGSM_ERR_BAD_ARG;
+    ctx->cfg.profile_events = mode;
     return UGSM_OK;
 }
 

@@ -128,3 +128,53 @@ def fovea_window_offsets(n_windows: int, W: int, H: int, fovW: int, fovH: int):
             if (ox, oy) != (0, 0):
                 offs.append((ox, oy))
     return offs[:n_windows]
+
+
+# ---- the fovea-shard step (bench.py --workload fovea-shard) ------------------------------------------
+
+class UgsmShardDriver:
+    """The four C-ABI calls of one fovea-shard step on a Context, addressed by slot.  Tensors are torch CUDA tensors;
+    tests drive fovea_shard_step with a double that has the same four methods (tests/test_dist_gloo.py)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def submit_pyramids(self, slot, L, R, W, H, stride):
+        c = self.ctx
+        c.check(c.lib.ugsm_submit_pyramids(c.handle, slot, L.data_ptr(), R.data_ptr(), W, H, stride))
+
+    def submit_coarse(self, slot, state):
+        c = self.ctx
+        c.check(c.lib.ugsm_submit_fovea_coarse(c.handle, slot, state.data_ptr()))
+
+    def wait(self, slot):
+        c = self.ctx
+        c.check(c.lib.ugsm_wait(c.handle, slot))
+
+    def submit_fine(self, slot, state, off, out):
+        c = self.ctx
+        c.check(c.lib.ugsm_submit_fovea_fine(c.handle, slot, state.data_ptr(), off[0], off[1], out.data_ptr()))
+
+
+def _collective_done(t: torch.Tensor):
+    """Host waits for the collective that was just enqueued on the current stream -- for it alone, not for the device:
+    the other slots' kernels keep running.  (gloo: the call has already completed.)"""
+    if t.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+        ev.synchronize()
+
+
+def fovea_shard_step(drv, slot: int, L, R, W: int, H: int, stride: int, state: torch.Tensor, off, out, rank: int, src: int = 0):
+    """One pair, one fovea window per rank: every rank builds the pyramids; rank `src` runs the coarse full-frame levels into
+    `state`; ONE broadcast of `state` (3 x fovH x fovW floats); every rank runs the fine levels of its window `off` into `out`.
+    `state` belongs to `slot`: the caller reuses a slot (and its state buffer) only after drv.wait(slot), i.e. after the fine
+    phase that reads the state has finished, so a later step's broadcast can never overwrite a state still in use; nothing
+    here synchronises the whole device, so the slots overlap."""
+    drv.submit_pyramids(slot, L, R, W, H, stride)
+    if rank == src:
+        drv.submit_coarse(slot, state)
+        drv.wait(slot)  # the state is complete before it is sent
+    broadcast_coarse_state(state, src)
+    _collective_done(state)
+    drv.submit_fine(slot, state, off, out)
