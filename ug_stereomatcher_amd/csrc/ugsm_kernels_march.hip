@@ -76,15 +76,21 @@ __device__ __forceinline__ void rowconv5(const float (&p)[NP], float (&out)[NP])
                                     __builtin_fmaf(shl1(p[0]), UGSM_G1, __builtin_fmaf(p[1], UGSM_G2, __builtin_fmaf(p[0], UGSM_G1, shr1(p[1]) * UGSM_G0))));
         }
     } else {
+        // one pixel per lane: the partial sum travels one lane to the right per tap (systolic), so every add takes its
+        // left operand through DPP and no separate lane move is needed; the finished sum of the window centred on column c
+        // arrives in lane c + 2 (March<1>::SKEW): everything downstream of a row pass lives two lanes right of its pixel
         if constexpr (!FMAD) {
             const float a0 = p[0] * UGSM_G0, a1 = p[0] * UGSM_G1, a2 = p[0] * UGSM_G2;
-            const float t = shr1(a0) + a1;
-            const float m = shl1(a0);
-            out[0] = ((shr1(t) + a2) + shl1(a1)) + shl1(m);
+            const float p2 = shr1(a0) + a1;
+            const float p3 = shr1(p2) + a2;
+            const float p4 = shr1(p3) + a1;
+            out[0] = shr1(p4) + a0;
         } else {
-            const float t = __builtin_fmaf(p[0], UGSM_G1, shr1(p[0]) * UGSM_G0);
-            const float m = shl1(p[0]);
-            out[0] = __builtin_fmaf(shl1(m), UGSM_G0, __builtin_fmaf(m, UGSM_G1, __builtin_fmaf(p[0], UGSM_G2, shr1(t))));
+            const float p1 = p[0] * UGSM_G0;
+            const float p2 = __builtin_fmaf(p[0], UGSM_G1, shr1(p1));
+            const float p3 = __builtin_fmaf(p[0], UGSM_G2, shr1(p2));
+            const float p4 = __builtin_fmaf(p[0], UGSM_G1, shr1(p3));
+            out[0] = __builtin_fmaf(p[0], UGSM_G0, shr1(p4));
         }
     }
 }
@@ -119,6 +125,7 @@ template <int NP>
 struct March {
     static constexpr int COLS = 64 * NP;  // columns a wave holds
     static constexpr int VX = COLS - 6;   // columns it produces (halo 3 on both sides)
+    static constexpr int SKEW = (NP == 1) ? 2 : 0;  // lanes between a pixel and the results of its row passes (rowconv5)
     static constexpr int ORG = (NP == 2) ? -1 : 0;  // first output column of strip 0 (-1 for NP = 2: lane 0's first pixel, three
                                                     // columns further left, then sits on an even column and the pixel pairs
                                                     // of a lane are 8-byte aligned when the row pitch is even)
@@ -166,27 +173,31 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     gchar_c *const Db[3] = {uniform_base(d3), uniform_base(d3 + n), uniform_base(d3 + 2 * n)};
     gchar_c *const Nb[3] = {uniform_base(nd3), uniform_base(nd3 + n), uniform_base(nd3 + 2 * n)};
 
-    // per-lane column constants
-    int px[NP];
-    unsigned coff[NP];  // byte offset of the (clamped) column inside a row
-    float xc[NP];       // warp x coordinate of the (clamped) pixel centre
+    // per-lane column constants.  px: the pixel whose R', L and products the lane holds; po = px - SKEW: the pixel whose row-pass
+    // results (N, B), A, own (dx,dy,conf) and output it holds
+    constexpr int SKEW = March<NP>::SKEW;
+    int px[NP], po[NP];
+    unsigned coff[NP], coffo[NP];  // byte offsets of the (clamped) columns px / po inside a row
+    float xc[NP];                  // warp x coordinate of the (clamped) pixel centre
     bool cin[NP], stv[NP];
 #pragma unroll
     for (int j = 0; j < NP; j++) {
         px[j] = X0 + NP * lane + j;
+        po[j] = px[j] - SKEW;
         const int pc = EDGE ? clampi(px[j], 0, W - 1) : px[j];
         cin[j] = !EDGE || (px[j] >= 0 && px[j] < W);
         coff[j] = (unsigned)pc * 4u;
+        coffo[j] = (unsigned)(EDGE || SKEW ? clampi(po[j], 0, W - 1) : po[j]) * 4u;
         xc[j] = (float)pc + 0.5f;
-        stv[j] = px[j] >= xs && px[j] < xe;
+        stv[j] = po[j] >= xs && po[j] < xe;
     }
     const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     auto rowc = [&](int r) { return min(max(r, 0), H - 1); };  // rows are clamped with scalar ops in every strip
-    auto row_off = [&](const int r, const unsigned pitch, unsigned (&off)[NP]) {
+    auto row_off = [&](const int r, const unsigned pitch, unsigned (&off)[NP], const bool skewed = false) {
         const unsigned ro = (unsigned)rowc(r) * pitch;
 #pragma unroll
-        for (int j = 0; j < NP; j++) off[j] = ro + coff[j];
+        for (int j = 0; j < NP; j++) off[j] = ro + (skewed ? coffo[j] : coff[j]);
     };
 
     auto load_d = [&](const int r, float (&dx)[NP], float (&dy)[NP]) {
@@ -215,7 +226,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     };
     auto load_AO = [&](const int r, float (&a)[3][NP], float (&od)[3][NP]) {
         unsigned off[NP];
-        row_off(r, pitchW, off);
+        row_off(r, pitchW, off, true);
 #pragma unroll
         for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k], off, a[k]);
 #pragma unroll
@@ -291,8 +302,8 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                         const float a = cur.A[k][j], bc = Bm1[k][j];
                         float bl = nbr<NP, -1>(Bm1[k], j), br = nbr<NP, +1>(Bm1[k], j), bu = Bm2[k][j], bd = bnew[j];
                         if constexpr (EDGE) {  // B at the clamped position (MatchLib.cu:676-679)
-                            bl = (px[j] <= 0) ? bc : bl;
-                            br = (px[j] >= W - 1) ? bc : br;
+                            bl = (po[j] <= 0) ? bc : bl;
+                            br = (po[j] >= W - 1) ? bc : br;
                             bu = (o <= 0) ? bc : bu;
                             bd = (o >= H - 1) ? bc : bd;
                         }
@@ -332,23 +343,23 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
             const unsigned ro = (unsigned)o * pitchW;
             if constexpr (NP == 2) {
                 if (stv[0] && stv[1]) {
-                    *(gf2u *)((gchar *)Nb[0] + (ro + coff[0])) = f2u{ndx[0], ndx[1]};
-                    *(gf2u *)((gchar *)Nb[1] + (ro + coff[0])) = f2u{ndy[0], ndy[1]};
-                    *(gf2u *)((gchar *)Nb[2] + (ro + coff[0])) = f2u{nkp[0], nkp[1]};
+                    *(gf2u *)((gchar *)Nb[0] + (ro + coffo[0])) = f2u{ndx[0], ndx[1]};
+                    *(gf2u *)((gchar *)Nb[1] + (ro + coffo[0])) = f2u{ndy[0], ndy[1]};
+                    *(gf2u *)((gchar *)Nb[2] + (ro + coffo[0])) = f2u{nkp[0], nkp[1]};
                 } else {
 #pragma unroll
                     for (int j = 0; j < NP; j++)
                         if (stv[j]) {
-                            st_at(Nb[0], ro + coff[j], ndx[j]);
-                            st_at(Nb[1], ro + coff[j], ndy[j]);
-                            st_at(Nb[2], ro + coff[j], nkp[j]);
+                            st_at(Nb[0], ro + coffo[j], ndx[j]);
+                            st_at(Nb[1], ro + coffo[j], ndy[j]);
+                            st_at(Nb[2], ro + coffo[j], nkp[j]);
                         }
                 }
             } else {
                 if (stv[0]) {
-                    st_at(Nb[0], ro + coff[0], ndx[0]);
-                    st_at(Nb[1], ro + coff[0], ndy[0]);
-                    st_at(Nb[2], ro + coff[0], nkp[0]);
+                    st_at(Nb[0], ro + coffo[0], ndx[0]);
+                    st_at(Nb[1], ro + coffo[0], ndy[0]);
+                    st_at(Nb[2], ro + coffo[0], nkp[0]);
                 }
             }
         }
