@@ -277,3 +277,107 @@ def test_reconstruct_full_known_answers(orc):
     assert (out[:, oy[0]:oy[0] + fh, ox[0]:ox[0] + fw] == 10.0).all()
     # ring of level-1 fovea (value 11) upsampled once, just outside the level-0 window
     assert out[1, oy[0] - 1, ox[0] + fw // 2] == np.float32(s * np.float32(11.0))
+
+
+# ---- hand-derived cases for the per-pixel kernels: expected values are computed here, operation by
+# operation in numpy float32 scalars, from the reference's formulas -- not by calling any restatement ------------------
+
+def _seq5(vals, taps):
+    """sum = 0; sum += v[k] * t[k] for k = 0..4, every product and partial sum rounded to float32"""
+    f = np.float32
+    s = f(0)
+    for v, t in zip(vals, taps):
+        s = f(s + f(f(v) * f(t)))
+    return s
+
+
+def test_move_correlation_known_answers(orc):
+    """MoveCorrelation, MatchLib.cu:681-687: clamp01((N*N) / (A * B)) with N = zero-padded, A and B = clamp-addressed 5x5
+    Gaussian sums (rows first, rounded, then columns).  Constant images make every term a product of tap sums."""
+    f = np.float32
+    g = orc.gauss_taps()
+    a, b = f(10), f(20)
+    H, W = 9, 12
+    L = np.full((3, H, W), a, f)
+    R = np.full((3, H, W), b, f)
+    d0 = np.zeros((3, H, W), f)
+    d0[2] = 0.5
+    _, dbg = orc.iterate_level(L, R, d0, 4, 5, False, 1, 1, want_dbg=True)
+
+    def two_pass(v, n_taps_row, n_taps_col):
+        # a constant image: the row pass sees `v` under the first n taps present, zero elsewhere (same for columns)
+        row = _seq5([v if k in n_taps_row else 0 for k in range(5)], g)
+        return _seq5([row if k in n_taps_col else 0 for k in range(5)], g)
+    full = range(5)
+    # interior pixel: every tap present in all three sums
+    N, A, B = two_pass(f(a * b), full, full), two_pass(f(a * a), full, full), two_pass(f(b * b), full, full)
+    q = f(f(N * N) / f(A * B))
+    q = f(1) if q > 1 else q
+    Q = f(f(f(q + q) + q) / f(3))  # the three channels are identical: ((q0 + q1) + q2) / 3.0f
+    for s in range(5):
+        assert dbg[s, 4, 6] == Q, (s, dbg[s, 4, 6], Q)
+    # corner (0,0), shift (0,0): the zero-padded N has only taps 2..4 (pixels 0..2) in both directions, the clamp-addressed
+    # A and B still see all five taps (edge replicated)
+    Nc = two_pass(f(a * b), range(2, 5), range(2, 5))
+    qc = f(f(Nc * Nc) / f(A * B))
+    Qc = f(f(f(qc + qc) + qc) / f(3))
+    assert dbg[4, 0, 0] == Qc and Qc < Q
+
+
+def test_true_confidence_blends_old_075_new_025(orc):
+    """TrueConfidence (MatchLib.cu:1003-1007) through its binding (calculateTrueConfidence, MatchLib.cu:1016-1038, called at
+    MatchGPULib.cpp:2243 with dispy = the new correlation product, a_Src = the previous confidence): 0.75 * OLD + 0.25 * NEW in
+    double.  Identical constant images give l = c = r, hence c1 = 0 -> (delta, rho) = (0, 0.4) for x and y, NEW = 0.4 * 0.4."""
+    f = np.float32
+    L = np.full((3, 8, 10), 7, f)
+    d0 = np.zeros((3, 8, 10), f)
+    d0[2] = 0.2
+    _, dbg = orc.iterate_level(L, L.copy(), d0, 4, 5, False, 1, 1, want_dbg=True)
+    new = f(f(0.4) * f(0.4))
+    exp = f(0.75 * float(f(0.2)) + 0.25 * float(new))
+    swapped = f(0.75 * float(new) + 0.25 * float(f(0.2)))
+    assert exp != swapped
+    assert (dbg[7] == exp).all() and (dbg[5] == 0).all() and (dbg[6] == 0).all()
+    # the coarsest level's first iteration has no old confidence to blend (MatchGPULib.cpp:2223)
+    _, dbg = orc.iterate_level(L, L.copy(), d0, 22, 5, True, 1, 1, want_dbg=True)
+    assert (dbg[7] == new).all()
+
+
+def test_smooth_kernel_weights_and_order(orc):
+    """smoothKernel, MatchLib.cu:1108-1139: sumDisp = v*w + sumDisp over centre, west, east, north, south, sumCorr likewise,
+    east / south clamped at the last column / row, result sumDisp / sumCorr; every plane weighted by the confidence plane."""
+    f = np.float32
+    v = np.array([[1.5, -2.25, 4.0], [0.5, 3.0, -1.0], [2.0, 8.0, 0.125]], f)
+    w = np.array([[0.9, 0.1, 0.4], [0.3, 0.7, 0.2], [0.6, 0.05, 0.8]], f)
+    out = orc.smooth_pass(np.stack([v, v * f(2), w]))
+
+    def at(y, x):
+        yy, xx = min(y + 1, 2), min(x + 1, 2)
+        nb = [(y, x), (y, x - 1), (y, xx), (y - 1, x), (yy, x)]
+        sd, sc, sk = f(0), f(0), f(0)
+        for (j, i) in nb:
+            sd = f(f(v[j, i] * w[j, i]) + sd)
+            sk = f(f(w[j, i] * w[j, i]) + sk)
+            sc = f(sc + w[j, i])
+        return f(sd / sc), f(sk / sc)
+    for (y, x) in [(1, 1), (2, 2), (1, 2), (2, 1)]:
+        ev, ek = at(y, x)
+        assert out[0, y, x] == ev and out[2, y, x] == ek, (y, x)
+    assert (out[:, 0, :] == np.stack([v, v * f(2), w])[:, 0, :]).all() and (out[:, :, 0] == np.stack([v, v * f(2), w])[:, :, 0]).all()
+
+
+def test_foveated_seed_crop_known_answers(orc):
+    """foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655: the fovea-sized field is upsampled to the parent level's size
+    (Wup x Hup) with subsampleDispKernel -- dst = SCALE * src[floor((i + .5f) * (float)(1/SCALE))] -- and the fovea window at
+    origin (l, u) is cut out (:1612-1615, :1642-1644)."""
+    f = np.float32
+    fw, fh, Wup, Hup = 11, 7, 15, 10
+    src = (np.arange(3 * fh * fw, dtype=f).reshape(3, fh, fw) * f(0.37) - f(5)).astype(f)
+    l, u = Wup // 2 - fw // 2, Hup // 2 - fh // 2
+    out = orc.seed_fovea(src, Wup, Hup, l, u)
+    sf = f(1.0 / 1.41421356)
+    for (y, x) in [(0, 0), (3, 5), (fh - 1, fw - 1), (2, 9)]:
+        sy = min(int(np.floor(f(f(u + y) + f(0.5)) * sf)), fh - 1)
+        sx = min(int(np.floor(f(f(l + x) + f(0.5)) * sf)), fw - 1)
+        for c in range(3):
+            assert out[c, y, x] == f(1.41421356 * float(src[c, sy, sx])), (c, y, x)
