@@ -16,7 +16,10 @@
 #include <ug_stereomatcher/GetDisparitiesGPU.h>
 #include <ug_stereomatcher/foveatedstack.h>
 
+#include <cstring>
+#include <map>
 #include <memory>
+#include <string>
 
 #include "MatchGPULib_ugsm.hpp"
 

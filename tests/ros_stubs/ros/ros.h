@@ -1,0 +1,21 @@
+#pragma once
+#include <map>
+#include <string>
+#include <boost/stub.h>
+#define ROS_WARN(...) ((void)0)
+#define ROS_INFO(...) ((void)0)
+#define ROS_ERROR(...) ((void)0)
+namespace ros {
+struct Publisher { template <class M> void publish(const M &) const; };
+struct ServiceServer {};
+struct WallDuration { double toSec() const; };
+struct WallTime { static WallTime now(); WallDuration operator-(const WallTime &) const; };
+struct NodeHandle {
+    template <class M> Publisher advertise(const std::string &topic, unsigned queue);
+    template <class T, class Req, class Res> ServiceServer advertiseService(const std::string &name, bool (T::*)(Req &, Res &), T *obj);
+    bool getParam(const std::string &key, int &v) const;
+};
+void init(int &argc, char **argv, const std::string &name);
+bool ok();
+void spin();
+}

@@ -1,0 +1,3 @@
+#pragma once
+#include <sensor_msgs/Image.h>
+namespace stereo_msgs { struct DisparityImage { std_msgs::Header header; sensor_msgs::Image image; float f, T, min_disparity, max_disparity, delta_d; }; }

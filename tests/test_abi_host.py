@@ -103,3 +103,20 @@ def test_fovea_mapping_matches_oracle(orc):
             assert _lib.fovea_mapping(W, H, src) == orc.fovea_mapping(W, H, src)
         for dest in (1, 3):
             assert _lib.fovea_mapping(W, H, 0, dest) == orc.fovea_mapping(W, H, 0, dest)
+
+
+def test_ros_node_source_compiles_against_declaration_stubs():
+    """ros/UG_GPU_matcher_ugsm.cpp (the catkin node over the shim) has never met ROS in this image.  This is a SYNTAX /
+    INTERFACE check only: g++ -fsyntax-only against declaration-only stand-ins (tests/ros_stubs/, see its README) for the ROS,
+    cv_bridge, image_transport, message_filters, OpenCV and boost headers it includes -- it catches typos, wrong member names
+    and drift against ros/MatchGPULib_ugsm.hpp and include/ugsm.h; it does not build, link or run a node."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        import pytest
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Itests/ros_stubs", "-Iros", "-Iinclude", "ros/UG_GPU_matcher_ugsm.cpp"],
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

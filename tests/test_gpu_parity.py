@@ -336,6 +336,23 @@ def test_service_boundary_on_gpu(lib, ctx, orc):
     assert_bit_equal(rsp.dispC.image.to_array(), exp[2], "dispC")
 
 
+def test_config0_640x480_three_levels_through_the_service_on_gpu(lib, ctx, orc):
+    """BASELINE.json configs[0] on the HIP side: the 640x480 synthetic pair (generator seed of config 0), 3-level pyramid,
+    through GPUMatcher.disparitySrv with the real library behind it, against the CPU oracle."""
+    from ug_stereomatcher_amd import service as svc, synth
+    L, R, _, _ = synth.make_pair(640, 480, synth.BASE_SEED + 0)
+    hdrL, hdrR = svc.Header(7, 1.5, "left"), svc.Header(7, 1.5, "right")
+    req = svc.GetDisparitiesGPURequest(svc.Image.from_array(L.reshape(480, -1), "rgb8", hdrL), svc.Image.from_array(R.reshape(480, -1), "rgb8", hdrR))
+    req.imL.width = req.imR.width = 640
+    node = svc.GPUMatcher(params={}, levels=3, kernel_path=ctx.cfg.kernel_path)
+    rsp = svc.GetDisparitiesGPUResponse()
+    assert node.disparitySrv(req, rsp) is True
+    exp = orc.match_full(L, R, 3)
+    for img, plane, hdr, what in ((rsp.dispH, exp[0], hdrL, "dispH"), (rsp.dispV, exp[1], hdrR, "dispV"), (rsp.dispC, exp[2], hdrL, "dispC")):
+        assert img.image.encoding == "32FC1" and (img.image.height, img.image.width) == (480, 640) and img.header is hdr
+        assert_bit_equal(img.image.to_array(), plane, what)
+
+
 def test_error_codes(lib, ctx):
     c = ctx
     out = np.empty((3, 48, 64), np.float32)

@@ -13,8 +13,8 @@
 namespace ugsm {
 
 // MatchGPULib.cpp:761-774 -- {0.0816475, 0.218507, 0.303281, ...} / their f32 sum.
-// Bit patterns 0x3db90e25, 0x3e779fea, 0x3eabd904 (checked at context creation
-// against the host computation).
+// Bit patterns 0x3db90e25, 0x3e779fea, 0x3eabd904; ugsm_create recomputes them the reference's way
+// and refuses to start (UGSM_ERR_STATE) if these literals ever disagree.
 #define UGSM_G0 0.09035900980234146f
 #define UGSM_G1 0.24182096123695374f
 #define UGSM_G2 0.3356400728225708f

@@ -7,6 +7,7 @@
 // HIP stream ("slot") so the launch-bound coarse levels of one pair overlap the
 // bandwidth/VALU-bound fine levels of another.
 #include "../../include/ugsm.h"
+#include "ugsm_device.hpp"
 #include "ugsm_launch.hpp"
 
 #include <hip/hip_runtime.h>
@@ -99,6 +100,7 @@ int level_dims(int W, int H, int levels, int *w, int *h)
 {
     if (W < 1 || H < 1 || levels < 1 || levels > UGSM_MAX_LEVELS) return UGSM_ERR_BAD_ARG;
     if ((long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;  // the kernels address a plane by 32-bit byte offsets
+    if (H > 65535) return UGSM_ERR_BAD_ARG;  // several launchers put the image row on grid.y (HIP: at most 65535)
     w[0] = W;
     h[0] = H;
     for (int i = 0; i < levels - 1; i++) {  // MatchGPULib.cpp:1224-1228
@@ -186,13 +188,23 @@ int grow(ugsm_ctx *ctx, T *&p, size_t &cap, size_t need)
 int ensure_level_bufs(ugsm_ctx *ctx, Slot &s, size_t lvl)
 {
     if (lvl <= s.lvl_cap) return UGSM_OK;
-    size_t c;
-    c = s.lvl_cap; UCHK(grow(ctx, s.A, c, lvl));
-    c = s.lvl_cap; UCHK(grow(ctx, s.d0, c, lvl));
-    c = s.lvl_cap; UCHK(grow(ctx, s.d1, c, lvl));
-    if (ctx->cfg.kernel_path == 1) {
-        c = s.lvl_cap; UCHK(grow(ctx, s.Rw, c, lvl));
-        c = s.lvl_cap; UCHK(grow(ctx, s.B, c, lvl));
+    // all-or-nothing: a failure part-way (out of memory) leaves every buffer freed and the capacity at zero, never a
+    // capacity that some buffer does not have
+    const size_t old = s.lvl_cap;
+    s.lvl_cap = 0;
+    int st = UGSM_OK;
+    float **bufs[5] = {&s.A, &s.d0, &s.d1, &s.Rw, &s.B};
+    const int nb = ctx->cfg.kernel_path == 1 ? 5 : 3;
+    for (int k = 0; k < nb && st == UGSM_OK; k++) {
+        size_t c = old;
+        st = grow(ctx, *bufs[k], c, lvl);
+    }
+    if (st != UGSM_OK) {
+        for (int k = 0; k < nb; k++) {
+            if (*bufs[k]) (void)hipFree(*bufs[k]);
+            *bufs[k] = nullptr;
+        }
+        return st;
     }
     s.lvl_cap = lvl;
     return UGSM_OK;
@@ -583,6 +595,14 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (const char *e = getenv("UGSM_MARCH_NP")) cfg.march_np = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_ROWS")) cfg.march_rows = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_SMOOTH")) cfg.march_smooth = atoi(e);
+    {   // the kernels carry the Gaussian taps as literals (ugsm_device.hpp); they must be the numbers the reference computes at
+        // start-up: five float literals divided by their float sum (MatchGPULib.cpp:761-774)
+        const float lit[5] = {0.0816475f, 0.218507f, 0.303281f, 0.218507f, 0.0816475f};
+        volatile float sum = 0.0f;
+        for (float v : lit) sum = sum + v;
+        const float g[3] = {lit[0] / sum, lit[1] / sum, lit[2] / sum}, k[3] = {UGSM_G0, UGSM_G1, UGSM_G2};
+        if (memcmp(g, k, sizeof g) != 0) return UGSM_ERR_STATE;
+    }
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
         cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels)
         return UGSM_ERR_BAD_ARG;
