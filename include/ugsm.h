@@ -62,7 +62,11 @@ typedef struct ugsm_config {
     int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
     int march_smooth;     /* 1: those levels also run K-smooth (five passes at a time) as a marching kernel; 0 (default): the
                              LDS-tiled K-smooth everywhere -- the marching form is bit-identical but no faster */
-    int reserved[2];
+    float early_exit_threshold; /* SURVEY 8f row f-4, OFF at 0 (default): when > 0, a level stops iterating as soon as the
+                             confidence-weighted mean change of dx and of dy between two iterations is below it
+                             (differenceIterations / weightedDifference, MatchGPULib.cpp:1323-1437 -- dead code in the
+                             reference, whose results this option therefore leaves; one host round trip per iteration) */
+    int reserved[1];
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);
@@ -200,6 +204,13 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
  * q_f[i] must equal the IEEE binary32 quotient a_f[i] / s[i] bit for bit. */
 int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2,
                           const float *d_s, float *d_q0, float *d_q1, float *d_q2, int n);
+
+/* Row f-4: weightedDifference (MatchGPULib.cpp:1336-1437) of two device (dx, dy, conf) fields, weights = the new field's
+ * conf: out2[0] = dx, out2[1] = dy (host).  Fixed-order binary64 sums, identical to the CPU restatement. */
+int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const float *d_old3, int W, int H, float *out2);
+/* Iterations each level of the last call on `slot` actually ran (early_exit_threshold > 0 can stop a level early);
+ * per_level[UGSM_MAX_LEVELS], -1 for levels not run.  ugsm_stage_iterate records its count at index 0. */
+int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level);
 
 /* K-cost's range-guarded division (the compiler's binary32 division sequence without v_div_scale / v_div_fixup, used when
  * every pyramid value of the pair is 0 or in [2^-12, 2^9]; csrc/ugsm_exact.hpp) on caller-supplied operands:

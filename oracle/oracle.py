@@ -273,3 +273,12 @@ def reconstruct_full(stack3: np.ndarray, W: int, H: int, levels: int = 14, off_x
     if rc:
         raise RuntimeError(f"orc_reconstruct_full rc={rc}")
     return out
+
+
+def weighted_difference(new3: np.ndarray, old3: np.ndarray):
+    """Row f-4 (MatchGPULib.cpp:1323-1437): (difH, difV) = sum(|new - old| * conf_new) / sum(conf_new)."""
+    _, H, W = new3.shape
+    out = np.zeros(2, np.float32)
+    lib().orc_weighted_difference(_fp(np.ascontiguousarray(new3, np.float32)), _fp(np.ascontiguousarray(old3, np.float32)), W, H, _fp(out))
+    return float(out[0]), float(out[1])
+

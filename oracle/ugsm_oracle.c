@@ -849,3 +849,43 @@ int orc_reconstruct_full(const float *stack3, int W, int H, int levels, int F, i
     }
     return 0;
 }
+
+/* ---- convergence measure of the reference's (never called) early exit -------------------------
+ * MatchGPULib.cpp:1323-1437 (differenceIterations / weightedDifference) with kernels 17, 18 (MatchLib.cu:1174-1373):
+ * theDif = sum(|D - OldD| * conf) / sum(conf); the iteration would stop when theDif of both disparities is below a threshold.
+ * The per-pixel term is the reference's, in float (MatchLib.cu:1194-1199: abs(a - b), then times conf).  Its sum is NOT
+ * defined by the reference: reduceGPU is called with the block count in place of the block size (:1363-1400) and the order of
+ * a tree reduction is an implementation detail.  Defined interpretation of this build: binary64
+ * sums in a fixed order -- per row, 64 column classes x = l (mod 64) each summed left to right, the classes added l = 0..63;
+ * the rows likewise in 64 row classes -- and theDif = (float)(S / C). */
+void orc_weighted_difference(const float *newd3, const float *oldd3, int W, int H, float out2[2])
+{
+    const size_t n = (size_t)W * H;
+    const float *conf = newd3 + 2 * n;
+    double ts[2][64], tc[64];
+    for (int l = 0; l < 64; l++) ts[0][l] = ts[1][l] = tc[l] = 0.0;
+    for (int y = 0; y < H; y++) {
+        double ps[2][64], pc[64];
+        for (int l = 0; l < 64; l++) ps[0][l] = ps[1][l] = pc[l] = 0.0;
+        for (int x = 0; x < W; x++) {
+            const size_t at = (size_t)y * W + x;
+            const float c = conf[at];
+            for (int k = 0; k < 2; k++) {
+                float t = fabsf(newd3[k * n + at] - oldd3[k * n + at]);
+                t = t * c;
+                ps[k][x & 63] += (double)t;
+            }
+            pc[x & 63] += (double)c;
+        }
+        double rs[2] = {0.0, 0.0}, rc = 0.0;
+        for (int l = 0; l < 64; l++) { rs[0] += ps[0][l]; rs[1] += ps[1][l]; rc += pc[l]; }
+        ts[0][y & 63] += rs[0];
+        ts[1][y & 63] += rs[1];
+        tc[y & 63] += rc;
+    }
+    double S[2] = {0.0, 0.0}, C = 0.0;
+    for (int l = 0; l < 64; l++) { S[0] += ts[0][l]; S[1] += ts[1][l]; C += tc[l]; }
+    out2[0] = (float)(S[0] / C);
+    out2[1] = (float)(S[1] / C);
+}
+

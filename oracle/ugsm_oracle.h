@@ -110,6 +110,10 @@ void orc_triangulate_fovea(const float *stackx, const float *stacky, int fovW, i
 /* SURVEY 8f row f-3 -- MatchGPULib.cpp:2589-2701 + MatchLib.cu:435-462.  stack3: 3 x F x fovH x fovW; out3: 3 x H x W. */
 int orc_reconstruct_full(const float *stack3, int W, int H, int levels, int F, int off_x, int off_y, float *out3);
 
+/* SURVEY 8f row f-4 -- MatchGPULib.cpp:1323-1437: confidence-weighted mean absolute change of dx (out2[0]) and dy (out2[1])
+ * between two (dx, dy, conf) fields, weights = the new field's conf; fixed-order binary64 sums (see the .c file). */
+void orc_weighted_difference(const float *newd3, const float *oldd3, int W, int H, float out2[2]);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -761,3 +761,58 @@ def test_page_locked_host_buffers_give_the_same_result(lib):
     finally:
         ctx.close()
     assert_bit_equal(got, ref, "page-locked vs pageable host buffers")
+
+
+# ---- convergence measure and the opt-in early exit -------------------------------------------------
+
+def test_weighted_difference_matches_oracle(lib, orc):
+    rng = np.random.Generator(np.random.PCG64(61))
+    with lib.Context(levels=1) as c:
+        for (W, H) in [(300, 97), (64, 64), (65, 1), (1, 70), (1000, 130)]:
+            new = np.stack([rng.normal(0, 5, (H, W)), rng.normal(0, 2, (H, W)), 0.05 + rng.random((H, W))]).astype(np.float32)
+            old = (new + rng.normal(0, 0.1, new.shape)).astype(np.float32)
+            pn, po = c.to_device(new), c.to_device(old)
+            out = (C.c_float * 2)()
+            try:
+                c.check(c.lib.ugsm_stage_weighted_difference(c.handle, pn, po, W, H, out))
+            finally:
+                c.free(pn)
+                c.free(po)
+            eh, ev = orc.weighted_difference(new, old)
+            assert (np.float32(out[0]).tobytes(), np.float32(out[1]).tobytes()) == (np.float32(eh).tobytes(), np.float32(ev).tobytes()), (W, H)
+            # and it is the plain formula up to summation order
+            ref = float((np.abs(new[0] - old[0]) * new[2]).astype(np.float64).sum() / new[2].astype(np.float64).sum())
+            assert abs(out[0] - ref) <= 1e-6 * abs(ref)
+
+
+def test_early_exit_stops_where_the_oracle_loop_stops(lib, orc):
+    """early_exit_threshold > 0: the level's iteration loop ends once both weighted differences are below it.  Emulated with the
+    oracle iteration by iteration; OFF (the default) leaves the reference's fixed iteration count."""
+    from ug_stereomatcher_amd import synth
+    L, R, _, _ = synth.make_pair(160, 120, 5100)
+    pl, pr = orc.rgb_to_planes(L), orc.rgb_to_planes(R)
+    rng = np.random.Generator(np.random.PCG64(62))
+    d0 = np.stack([rng.normal(2, 0.5, (120, 160)), rng.normal(0, 0.3, (120, 160)), 0.3 + 0.6 * rng.random((120, 160))]).astype(np.float32)
+    mi, S = 12, 5
+    for eps in (0.05, 0.2, 1e9, 1e-9):
+        d, ran = d0, 0
+        for m in range(1, mi + 1):
+            nd, _ = orc.iterate_level(pl, pr, d, mi, S, False, m, m)
+            ran = m
+            dh, dv = orc.weighted_difference(nd, d)
+            d = nd
+            if m < mi and dh < eps and dv < eps:
+                break
+        with lib.Context(levels=1, early_exit_threshold=eps) as c:
+            pL, pR, pd = c.to_device(pl), c.to_device(pr), c.to_device(d0)
+            try:
+                c.check(c.lib.ugsm_stage_iterate(c.handle, pL, pR, pd, 160, 120, mi, S, 0, 1, mi, None))
+                got = c.to_host(pd, (3, 120, 160))
+                its = (C.c_int * 32)()
+                c.check(c.lib.ugsm_last_iterations(c.handle, 0, its))
+            finally:
+                for p in (pL, pR, pd):
+                    c.free(p)
+        assert its[0] == ran, (eps, its[0], ran)
+        assert_bit_equal(got, d, f"early exit eps={eps}")
+    assert ran == mi  # eps = 1e-9 never triggers

@@ -381,3 +381,18 @@ def test_foveated_seed_crop_known_answers(orc):
         sx = min(int(np.floor(f(f(l + x) + f(0.5)) * sf)), fw - 1)
         for c in range(3):
             assert out[c, y, x] == f(1.41421356 * float(src[c, sy, sx])), (c, y, x)
+
+
+def test_weighted_difference_is_the_weighted_mean_absolute_change(orc):
+    """Row f-4, weightedDifference (MatchGPULib.cpp:1336-1437): sum(|D - OldD| * conf) / sum(conf) per disparity plane."""
+    f = np.float32
+    new = np.zeros((3, 4, 5), f)
+    old = np.zeros((3, 4, 5), f)
+    new[2] = 0.5
+    new[0, 1, 2], old[0, 1, 2] = 3.0, 1.0   # |2| * 0.5
+    new[1, 3, 4], old[1, 3, 4] = -1.0, 0.5  # |-1.5| * 0.5
+    dh, dv = orc.weighted_difference(new, old)
+    assert dh == f(1.0 / 10.0) and dv == f(0.75 / 10.0)
+    new[2, 0, 0] = 2.0  # weights are the NEW field's confidence
+    dh2, _ = orc.weighted_difference(new, old)
+    assert dh2 == f(1.0 / 11.5)

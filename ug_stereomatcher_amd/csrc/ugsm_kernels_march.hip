@@ -768,6 +768,64 @@ void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *r
     hipLaunchKernelGGL(k_range_scan, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, p, count, range_bad);
 }
 
+// =========================================================================================
+// the convergence measure of the reference's (never called) early exit -- weightedDifference,
+// MatchGPULib.cpp:1336-1437 with kernels 17 / 18 (MatchLib.cu:1174-1373): sum(|D - OldD| * conf) / sum(conf) for dx and dy.
+// The reference's reduction has no defined order (and is called with the block count as the block size); this build's
+// definition (oracle/ugsm_oracle.c: orc_weighted_difference) is a fixed order of binary64 sums that maps onto one wave per
+// row: lane l adds its columns x = l (mod 64) left to right, lane 0 adds the 64 lane sums in lane order; a second, single-wave
+// kernel adds the rows the same way.  Deterministic, and bit-identical to the CPU restatement.
+// =========================================================================================
+__global__ __launch_bounds__(64) void k_wdiff_rows(const float *__restrict__ newd3, const float *__restrict__ oldd3, int W, int H,
+                                                  double *__restrict__ rowsum)
+{
+    __shared__ double sp[3][64];
+    const int y = blockIdx.x, l = threadIdx.x;
+    const size_t n = (size_t)W * H;
+    double ph = 0.0, pv = 0.0, pc = 0.0;
+    for (int x = l; x < W; x += 64) {
+        const size_t at = (size_t)y * W + x;
+        const float c = newd3[2 * n + at];
+        float th = fabsf(newd3[at] - oldd3[at]);        // kernel 17, MatchLib.cu:1194-1199: abs(a - b) ...
+        float tv = fabsf(newd3[n + at] - oldd3[n + at]);
+        th = th * c;                                    // ... times conf, in float
+        tv = tv * c;
+        ph += (double)th;
+        pv += (double)tv;
+        pc += (double)c;
+    }
+    sp[0][l] = ph;
+    sp[1][l] = pv;
+    sp[2][l] = pc;
+    __syncthreads();
+    if (l < 3) {
+        double r = 0.0;
+        for (int i = 0; i < 64; i++) r += sp[l][i];
+        rowsum[(size_t)y * 3 + l] = r;
+    }
+}
+__global__ __launch_bounds__(64) void k_wdiff_total(const double *__restrict__ rowsum, int H, double *__restrict__ out3)
+{
+    __shared__ double sp[3][64];
+    const int l = threadIdx.x;
+    double p[3] = {0.0, 0.0, 0.0};
+    for (int y = l; y < H; y += 64)
+        for (int k = 0; k < 3; k++) p[k] += rowsum[(size_t)y * 3 + k];
+    for (int k = 0; k < 3; k++) sp[k][l] = p[k];
+    __syncthreads();
+    if (l < 3) {
+        double r = 0.0;
+        for (int i = 0; i < 64; i++) r += sp[l][i];
+        out3[l] = r;
+    }
+}
+// out3 (device): S_dx, S_dy, C; rowsum: 3 * H doubles of scratch
+void launch_weighted_difference(hipStream_t st, const float *newd3, const float *oldd3, int W, int H, double *rowsum, double *out3)
+{
+    hipLaunchKernelGGL(k_wdiff_rows, dim3(H), dim3(64), 0, st, newd3, oldd3, W, H, rowsum);
+    hipLaunchKernelGGL(k_wdiff_total, dim3(1), dim3(64), 0, st, rowsum, H, out3);
+}
+
 // test hook: the range-guarded division on arbitrary operands
 __global__ void k_div_probe(const float *__restrict__ n, const float *__restrict__ d, float *__restrict__ q, int count)
 {

@@ -57,6 +57,8 @@ void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *
                               int upper_margin, float scale, const double *P1, const double *P2, float *xyz);
 void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, const float *fovH_, const float *fovV_,
                            const float *fovC_, int fovW, int fovH, int org_x, int org_y);
+// S_dx, S_dy, C of weightedDifference (MatchGPULib.cpp:1336-1437) into out3; rowsum = 3*H doubles of scratch
+void launch_weighted_difference(hipStream_t st, const float *newd3, const float *oldd3, int W, int H, double *rowsum, double *out3);
 void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, int count);
 void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n);
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);

@@ -55,6 +55,12 @@ struct Slot {
     size_t lvl_cap = 0;  // floats per 3-plane level buffer
     uint8_t *rgbL = nullptr, *rgbR = nullptr;
     size_t rgb_cap = 0;
+    float *d2 = nullptr;            // third (dx,dy,conf) buffer: only with early_exit_threshold > 0 (the previous iteration's field must survive)
+    size_t d2_cap = 0;
+    double *wd_rows = nullptr;      // row f-4 scratch: 3 doubles per row + 3 totals
+    size_t wd_cap = 0;
+    double *wd_host = nullptr;      // page-locked, 3 doubles
+    int iters_run[UGSM_MAX_LEVELS];
     unsigned *range_bad = nullptr;  // device word: 0 while every pyramid value of the pair in this slot passed range_ok (ugsm_exact.hpp)
     float *hout = nullptr;  // device staging for host-API outputs
     size_t hout_cap = 0;
@@ -225,6 +231,7 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H)
     s.W = W;
     s.H = H;
     s.levels = levels;
+    for (int i = 0; i < UGSM_MAX_LEVELS; i++) s.iters_run[i] = -1;
     s.have_pyr = false;
     s.have_coarse = false;
     if (tot > s.pyr_cap) {
@@ -374,6 +381,27 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
     return UGSM_OK;
 }
 
+// Row f-4 (MatchGPULib.cpp:1323-1437): S_dx / C and S_dy / C of two device fields, synchronously (one host round trip).
+int weighted_difference(ugsm_ctx *ctx, Slot &s, const float *newd3, const float *oldd3, int W, int H, float out2[2])
+{
+    const size_t need = 3 * (size_t)H + 3;
+    if (need > s.wd_cap) {
+        if (s.wd_rows) HIPCHK(ctx, hipFree(s.wd_rows));
+        s.wd_rows = nullptr;
+        s.wd_cap = 0;
+        HIPCHK(ctx, hipMalloc((void **)&s.wd_rows, need * sizeof(double)));
+        s.wd_cap = need;
+    }
+    if (!s.wd_host) HIPCHK(ctx, hipHostMalloc((void **)&s.wd_host, 3 * sizeof(double), hipHostMallocDefault));
+    double *tot = s.wd_rows + 3 * (size_t)H;
+    launch_weighted_difference(s.st, newd3, oldd3, W, H, s.wd_rows, tot);
+    HIPCHK(ctx, hipMemcpyAsync(s.wd_host, tot, 3 * sizeof(double), hipMemcpyDeviceToHost, s.st));
+    HIPCHK(ctx, hipStreamSynchronize(s.st));
+    out2[0] = (float)(s.wd_host[0] / s.wd_host[2]);
+    out2[1] = (float)(s.wd_host[1] / s.wd_host[2]);
+    return UGSM_OK;
+}
+
 // matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
 // on entry and on exit; other is scratch of the same size.
 // final_out (optional, fused path only): where the last iteration leaves its result instead of the ping-pong buffer
@@ -385,6 +413,18 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
     const double px = (double)W * H;
     std::vector<float> thr((size_t)std::max(mi, 1));
     threshold_schedule(mi, thr.data());
+    // row f-4, opt-in: stop the level when the confidence-weighted mean change of dx and dy falls below the threshold.  The
+    // previous iteration's field has to survive the smoothing ping-pong, hence a third buffer.
+    const float eps = ctx->cfg.early_exit_threshold;
+    const bool early = eps > 0.0f;
+    float *third = nullptr;
+    if (early) {
+        const size_t lvl = 3 * (size_t)W * H;
+        UCHK(grow(ctx, s.d2, s.d2_cap, std::max(lvl, s.lvl_cap)));
+        third = s.d2;
+        final_out = nullptr;
+    }
+    int ran = 0;
     {   // A = G_clamp * L^2 does not depend on the iteration: once per level.
         Timer t(ctx, &s, si, KC_SQBLUR, px);
         if (ref) launch_sqblur_clamp_ref(s.st, L, W, H, s.A);
@@ -409,12 +449,26 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
+        ran = m;
+        if (early) {
+            float *a = other, *b = third;  // cur (the field before this iteration) stays untouched
+            UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true, nullptr));
+            float dif[2] = {0.0f, 0.0f};
+            if (m < m_to) UCHK(weighted_difference(ctx, s, a, cur, W, H, dif));
+            float *old = cur;
+            cur = a;  // the new field; b and the old field are the scratch pair of the next iteration
+            other = b;
+            third = old;
+            if (m < m_to && dif[0] < eps && dif[1] < eps) break;  // differenceIterations: both below the threshold
+            continue;
+        }
         float *a = other, *b = cur;
         UCHK(enqueue_smooth(ctx, s, si, a, b, W, H, S, true, (m == m_to && !ref) ? final_out : nullptr));
         if (m == m_to && !ref && final_out) break;
         cur = a;
         other = b;
     }
+    s.iters_run[s.cur_level == kNoLevel ? 0 : s.cur_level] = ran;
     HIPCHK(ctx, hipGetLastError());
     return UGSM_OK;
 }
@@ -449,7 +503,7 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
         s.cur_level = i;
         const int mi = level_iterations(i);
         // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
-        const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0;
+        const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0 && !(ctx->cfg.early_exit_threshold > 0.0f);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
                        level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr));
         if (direct) return UGSM_OK;
@@ -632,8 +686,9 @@ void ugsm_destroy(ugsm_ctx *ctx)
         harvest(ctx, s);
         for (hipEvent_t e : s.pool) (void)hipEventDestroy(e);
         for (void *p : {(void *)s.pyrL, (void *)s.pyrR, (void *)s.A, (void *)s.Rw, (void *)s.B, (void *)s.d0, (void *)s.d1,
-                        (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout, (void *)s.range_bad})
+                        (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout, (void *)s.range_bad, (void *)s.d2, (void *)s.wd_rows})
             if (p) (void)hipFree(p);
+        if (s.wd_host) (void)hipHostFree(s.wd_host);
         if (s.st) (void)hipStreamDestroy(s.st);
     }
     delete ctx;
@@ -995,6 +1050,24 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
     launch_poly_probe(s->st, d_c, d_l, d_r, d_thr, d_delta, d_corr, d_third, n);
     HIPCHK(ctx, hipGetLastError());
     return ugsm_wait(ctx, 0);
+}
+
+int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const float *d_old3, int W, int H, float *out2)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_new3 || !d_old3 || !out2 || W < 1 || H < 1 || H > 65535 || (long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    return weighted_difference(ctx, *s, d_new3, d_old3, W, H, out2);
+}
+
+int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!per_level) return UGSM_ERR_BAD_ARG;
+    for (int i = 0; i < UGSM_MAX_LEVELS; i++) per_level[i] = s->iters_run[i];
+    return UGSM_OK;
 }
 
 int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n)
