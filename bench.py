@@ -388,24 +388,31 @@ def main():
 
 
 def valu_roofline(vm: dict, by_name: dict, n_pairs: int, px0: int) -> dict:
-    """Modelled VALU time of the level-0 launches of the two hot kernels against their measured durations.
-    vm (profiles/rNN_valu_model.json, written by tools/valu_model.py from the kernels' ISA, the valubench cost table and the
-    in-kernel clock): per kernel, VALU issue cycles per wave per row step, and the geometry that turns pixels into row steps."""
+    """Modelled VALU time of the level-0 launches of the hot kernels against their measured durations.
+    vm = profiles/rNN_valu_model.json (tools/valu_model.py): per kernel the mean issue cost of a VALU instruction of its hot
+    loops (ISA mix x tools/valubench.hip costs in actual cycles) and the in-kernel clock; profiles/pmc_traffic.json holds
+    SQ_INSTS_VALU of the level-0 launch (PMC pass).  model = instructions x mean cost / (SIMDs x clock)."""
     out = {"source": vm.get("_source"), "clock_GHz": vm["clock_GHz"], "simds": vm["simds"], "kernels": []}
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        insts, clocks = pj.get("valu_insts_level0", {}), pj.get("clock_GHz_level0", {})
+    except Exception:
+        insts, clocks = {}, {}
     for name, m in vm["kernels"].items():
         e = by_name.get(name)
         l0 = e["levels"].get(0) if e else None
-        if not l0 or not l0["launches"]:
+        if not l0 or not l0["launches"] or name not in insts:
             continue
         measured_us = 1e3 * l0["total_ms"] / l0["launches"]
-        wave_steps = px0 / m["valid_pixels_per_wave_step"] * m["row_overhead"]
-        model_us = wave_steps * m["valu_cycles_per_wave_step"] / vm["simds"] / (vm["clock_GHz"] * 1e3)
-        out["kernels"].append({"name": name, "level0_measured_us": measured_us, "level0_valu_model_us": model_us,
-                               "frac": model_us / measured_us, "valu_cycles_per_wave_step": m["valu_cycles_per_wave_step"],
-                               "valu_instructions_per_wave_step": m["valu_instructions_per_wave_step"],
-                               "valid_pixels_per_wave_step": m["valid_pixels_per_wave_step"], "row_overhead": m["row_overhead"]})
-    out["note"] = ("frac = time the kernel's VALU instruction stream needs at the measured per-instruction issue costs (actual cycles, "
-                   "tools/valubench.hip) / measured duration; ~1 means the launch is VALU-issue bound")
+        clk = clocks.get(name) if isinstance(clocks.get(name), (int, float)) else vm["clock_GHz"]  # the clock held during that launch
+        model_us = insts[name] * m["mean_cycles_per_valu"] / vm["simds"] / (clk * 1e3)
+        out["kernels"].append({"name": name, "level0_measured_us": measured_us, "level0_valu_model_us": model_us, "frac": model_us / measured_us,
+                               "clock_GHz": clk,
+                               "valu_instructions_level0": insts[name], "mean_cycles_per_valu": m["mean_cycles_per_valu"],
+                               "valu_lane_instructions_per_pixel": insts[name] * 64.0 / px0})
+    out["note"] = ("frac = time the launch's VALU instruction stream needs at the measured per-instruction issue costs (actual cycles, four waves "
+                   "per SIMD) / measured duration; near 1 = VALU-issue bound.  Instruction counts and costs come from profiles/ (PMC pass and "
+                   "valubench of this round), the duration is measured in this run")
     return out
 
 

@@ -17,7 +17,8 @@ out = os.path.join(ROOT, "profiles")
 shutil.copy(glob.glob(base + "/trace/**/*kernel_stats.csv", recursive=True)[0], f"{out}/{tag}_kernel_stats.csv")
 for f in ("bench_default.json", "bench_under_rocprof.json"):
     shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
-for f in ("kbench_16mp.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json", "bench_fovea16mp.json"):
+for f in ("kbench_16mp.txt", "kbench_smooth_16mp.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json",
+          "bench_fovea16mp.json"):
     if os.path.exists(f"{base}/{f}"):
         shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 
@@ -40,7 +41,7 @@ lines = [f"# {tag}: HBM traffic per kernel (PMC, separate passes; `bench.py --st
          "agree.  Write bytes = WRITE_SIZE x 1024.  Algorithmic = 48 B x pixels of the launch (SURVEY.md 8d).\n",
          "| kernel | launches | read MB/launch | 2 x FETCH_SIZE MB/launch | write MB/launch | algorithmic MB/launch | traffic / algorithmic |",
          "|---|---|---|---|---|---|---|"]
-traffic = {}
+traffic, traffic_n = {}, {}
 for k in sorted(rd, key=lambda k: -sum(rd[k]["TCC_EA0_RDREQ_sum"])):
     c = rd[k]
     n = len(c["TCC_EA0_RDREQ_sum"])
@@ -49,11 +50,14 @@ for k in sorted(rd, key=lambda k: -sum(rd[k]["TCC_EA0_RDREQ_sum"])):
     f = sum(fe[k]["FETCH_SIZE"]) * 1024 * 2
     w = sum(wr[k]["WRITE_SIZE"]) * 1024
     a = ratio = ""
-    if k.startswith("k_cost"):
-        algb = 48.0 * pi * 5 / n
-        a, ratio = f"{algb / 1e6:.2f}", f"{(rb + w) / n / algb:.2f}"
-        traffic[k.split("<")[0]] = (rb + w) / n
+    if k.startswith("k_cost") or k.startswith("k_smooth"):
+        traffic[k.split("<")[0]] = traffic.get(k.split("<")[0], 0.0) + (rb + w)
+        traffic_n[k.split("<")[0]] = traffic_n.get(k.split("<")[0], 0) + n
     lines.append(f"| {k} | {n} | {rb / n / 1e6:.2f} | {f / n / 1e6:.2f} | {w / n / 1e6:.2f} | {a} | {ratio} |")
+traffic = {k: v / traffic_n[k] for k, v in traffic.items()}
+lines.append("")
+lines.append("Mean HBM bytes per launch over all launches of a pair (what `roofline.traffic` in the bench line quotes): "
+             + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in sorted(traffic.items())))
 open(f"{out}/{tag}_hbm_traffic.md", "w").write("\n".join(lines) + "\n")
 # VALU issue rate of the two hot kernels at level 0: SQ_INSTS_VALU (pass sq1) per SIMD cycle (SQ_BUSY_CU_CYCLES of pass sq2
 # x 4 SIMDs), largest grid of each kernel.  Times the mean issue cost of the mix (tools/valubench: 3.0 cycles for plain
@@ -68,21 +72,45 @@ def _largest(agg, prefix, counter):
     g = max(rows)
     return sum(rows[g]) / len(rows[g])
 valu_busy = {}
-for kname, prefix in (("k_cost_split", "k_cost_split"), ("k_smooth_fused", "k_smooth_fused<112")):
+valu_insts = {}
+for kname, prefix in (("k_cost_march", "k_cost_march"), ("k_cost_split", "k_cost_split"), ("k_smooth_fused", "k_smooth_fused<112")):
     try:
-        valu_busy[kname] = round(_largest("pmc_sq1", prefix, "SQ_INSTS_VALU") / (4.0 * _largest("pmc_sq2", prefix, "SQ_BUSY_CU_CYCLES")), 4)
+        valu_insts[kname] = _largest("pmc_sq1", prefix, "SQ_INSTS_VALU")
+        valu_busy[kname] = round(valu_insts[kname] / (4.0 * _largest("pmc_sq2", prefix, "SQ_BUSY_CU_CYCLES")), 4)
     except Exception:  # a pass without those counters
         valu_busy[kname] = None
-json.dump({"full16mp": traffic, "valu_insts_per_simd_cycle_level0": valu_busy,
+# the clock the chip held during the level-0 launches: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration of the same dispatch
+# (MI355X_MICROARCH.md, DVFS give-back)
+clock = {}
+try:
+    f = glob.glob(f"{base}/pmc_sq2/**/*counter_collection.csv", recursive=True)[0]
+    t = glob.glob(f"{base}/pmc_sq2/**/*kernel_trace.csv", recursive=True)[0]
+    dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(t))}
+    rows = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] in dur:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ugsm::", "").split("<")[0]
+            rows[name][int(r["Grid_Size"])].append(float(r["Counter_Value"]) / 8.0 / dur[r["Dispatch_Id"]])
+    for name, g in rows.items():
+        if name in ("k_cost_march", "k_smooth_fused", "k_cost_split"):
+            v = g[max(g)]
+            clock[name] = round(sum(v) / len(v), 3)
+except Exception as ex:  # a pass without the counter
+    clock = {"error": str(ex)}
+json.dump({"_tag": tag, "full16mp": traffic, "clock_GHz_level0": clock, "valu_insts_per_simd_cycle_level0": valu_busy, "valu_insts_level0": valu_insts,
            "_note": "HBM bytes per launch (mean over the 218 launches of a 16 MP pair) of the dominant kernel: exact read bytes from "
-                    f"the size-binned TCC_EA0_RDREQ counters + WRITE_SIZE; see profiles/{tag}_hbm_traffic.md"},
+                    f"the size-binned TCC_EA0_RDREQ counters + WRITE_SIZE; see profiles/{tag}_hbm_traffic.md.  valu_insts_level0: "
+                    "SQ_INSTS_VALU of the largest grid of each kernel (the level-0 launch), mean per dispatch"},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)
 an = os.path.join(out, "analyze_trace.py")
 subprocess.check_call([sys.executable, an, base + "/trace", "--out", f"{out}/{tag}_trace_summary.md"], stdout=subprocess.DEVNULL)
 with open(f"{out}/{tag}_pmc_summary.md", "w") as fo:
-    fo.write(f"# {tag}: SQ counters (two separate PMC passes, single slot, 5 pairs; mean per dispatch)\n")
-    for d in ("pmc_sq1", "pmc_sq2"):
+    fo.write(f"# {tag}: SQ counters (separate PMC passes, single slot, 5 pairs; mean per dispatch)\n")
+    for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
         txt = subprocess.check_output([sys.executable, an, base + "/" + d]).decode()
         keep = [l for l in txt.split("\n") if l.startswith("- k_cost") or l.startswith("- k_smooth")]
         fo.write(f"\n## {d}\n" + "\n".join(keep[:14]) + "\n")
+vb = f"{out}/{tag}_valubench.txt"
+if os.path.exists(vb):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "valu_model.py"), vb, tag], stdout=subprocess.DEVNULL)
 print("\n".join(lines))

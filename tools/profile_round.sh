@@ -1,30 +1,32 @@
 #!/bin/bash
 # Collects everything profiles/make_summaries.py needs, in ONE gpurun call:
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r01'
-#   python profiles/make_summaries.py gpurun_out/prof_r01 r01
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
+#   python profiles/make_summaries.py gpurun_out/prof_r02 r02
 # Counter passes are separate rocprofv3 runs with at most 8 counters each (--kernel-trace only beside --pmc), each
 # behind its own timeout; a line is printed after every step so that the call never looks hung.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 step() { echo "[profile_round] $* ($(date +%T))"; }
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; step "bench default: $(cut -c1-120 $O/bench_default.json)"
-python bench.py --slots 1 --no-cpu-baseline > $O/bench_slots1.json 2>> $O/bench_default.err; step "bench slots1"
-python bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench_default.err; step "bench 1080p"
-python bench.py --workload fovea16mp --no-cpu-baseline > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp"
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; step "bench default: $(cut -c1-160 $O/bench_default.json)"
+python bench.py --slots 1 --no-cpu-baseline --no-service > $O/bench_slots1.json 2>> $O/bench_default.err; step "bench slots1"
+python bench.py --workload 1080p --no-cpu-baseline --no-service > $O/bench_1080p.json 2>> $O/bench_default.err; step "bench 1080p"
+python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
+# the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
 pmc() { name=$1; shift; timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 pmc pmc_write WRITE_SIZE
 pmc pmc_fetch FETCH_SIZE
 pmc pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS
 pmc pmc_sq2 GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
+pmc pmc_sq3 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64
 cd $R
-timeout -k 10 200 ./tools/kbench 4928 3264 10 > $O/kbench_16mp.txt 2>&1; step "kbench"
+timeout -k 10 200 ./tools/kbench 4928 3264 10 2 > $O/kbench_16mp.txt 2>&1; step "kbench (marching vs tiled K-cost)"
+timeout -k 10 200 ./tools/kbench 4928 3264 10 5 > $O/kbench_smooth_16mp.txt 2>&1; step "kbench (marching vs tiled K-smooth)"
 timeout -k 10 100 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"
-timeout -k 10 100 ./tools/ldsbench > $O/ldsbench.txt 2>&1; step "ldsbench"
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
 ls $O
