@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -58,6 +59,30 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         return 0;
     }
+#ifdef UGSM_MARCH_STAMP
+    if (argc > 4 && atoi(argv[4]) == 6) {  // in-kernel clock of the marching K-cost under sustained launches: kbench_stamp W H reps 6
+        const int nb = 8192;
+        long long *dst; CK(hipMalloc(&dst, sizeof(long long) * 2 * nb)); CK(hipMemset(dst, 0, sizeof(long long) * 2 * nb));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_march_stamps), &dst, sizeof(dst)));
+        const auto t_start = std::chrono::steady_clock::now();
+        int launches = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() < 2.5) {  // >= 2 s of back-to-back launches
+            for (int i = 0; i < 50; i++) launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb);
+            CK(hipStreamSynchronize(st));
+            launches += 50;
+        }
+        std::vector<long long> hs(2 * nb);
+        CK(hipMemcpy(hs.data(), dst, sizeof(long long) * 2 * nb, hipMemcpyDeviceToHost));
+        std::vector<double> clk, cyc;
+        for (int b = 0; b < nb; b++) if (hs[2 * b + 1] > 0) { clk.push_back((double)hs[2 * b] / (double)hs[2 * b + 1] * 0.1); cyc.push_back((double)hs[2 * b]); }
+        std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
+        printf("k_cost_march np=1 %dx%d after %d back-to-back launches: in-kernel clock median %.3f GHz (p10 %.3f, p90 %.3f) over %zu waves; "
+               "wave lifetime cycles p10 %.0f, median %.0f, p90 %.0f, p99 %.0f, max %.0f\n", W, H, launches, clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], clk.size(),
+               cyc[cyc.size() / 10], cyc[cyc.size() / 2], cyc[cyc.size() * 9 / 10], cyc[cyc.size() * 99 / 100], cyc.back());
+        timeit("k_cost_march np=1 (stamped build)", [&]() { launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb); });
+        return 0;
+    }
+#endif
     if (argc > 4 && atoi(argv[4]) == 3) {  // counter runs of the marching K-cost: kbench W H reps 3 np rows
         const int np = argc > 5 ? atoi(argv[5]) : 1, rows = argc > 6 ? atoi(argv[6]) : 0;
         for (int i = 0; i < reps; i++) launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, np, rows, rb);

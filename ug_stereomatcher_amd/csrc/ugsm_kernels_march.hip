@@ -383,14 +383,36 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     }
 }
 
+// A workgroup is MARCH_WPB independent waves (they never synchronise): single-wave workgroups are admitted only 8 per CU
+// (2 waves per SIMD; measured: wave lifetime 2/3 of the launch at a nominal 3 waves per SIMD), four-wave workgroups reach the
+// occupancy the register allocation allows.
+constexpr int MARCH_WPB = 4;
+// strip of this wave: blocks are dealt to the XCDs as contiguous bands of strips (xcd_tile), a block's waves take consecutive strips
+__device__ __forceinline__ bool march_strip(const int n_strips, const int strips_x, int &sx, int &sy)
+{
+    const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
+    int bx, by;
+    xcd_tile(n_blocks, n_blocks, bx, by);  // (one row of blocks: bx = the remapped block index)
+    const int strip = bx * MARCH_WPB + (int)(threadIdx.x >> 6);
+    if (strip >= n_strips) return false;
+    sy = strip / strips_x;
+    sx = strip - sy * strips_x;
+    return true;
+}
+#ifdef UGSM_MARCH_STAMP
+__device__ long long *g_march_stamps = nullptr;  // per workgroup: delta s_memtime, delta s_memrealtime (never read by the kernel)
+#endif
 // grid: one wave (64 threads) per strip of March<NP>::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
 template <int NP, bool FMAD>
-__global__ __launch_bounds__(64, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+__global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
                                                                       int n_strips, int Hs, const unsigned *__restrict__ range_bad)
 {
+#ifdef UGSM_MARCH_STAMP  // diagnostic build only (tools/kbench_stamp): in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
+    const long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     int sx, sy;
-    xcd_tile(n_strips, strips_x, sx, sy);
+    if (!march_strip(n_strips, strips_x, sx, sy)) return;
     const int xs = sx * March<NP>::VX + March<NP>::ORG, ys = sy * Hs;
     const int xe = min(xs + March<NP>::VX, W), ye = min(ys + Hs, H);
     const int X0 = xs - 3;
@@ -406,6 +428,13 @@ __global__ __launch_bounds__(64, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3
         if (interior) cost_march_body<NP, false, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
         else cost_march_body<NP, true, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
     }
+#ifdef UGSM_MARCH_STAMP
+    if (g_march_stamps && (threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * MARCH_WPB + (threadIdx.x >> 6);
+        g_march_stamps[2 * w] = (long long)__builtin_amdgcn_s_memtime() - st_t0;
+        g_march_stamps[2 * w + 1] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
 }
 
 template <int NP>
@@ -425,8 +454,9 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     }
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
-    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_strips), dim3(64), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
+    const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
+    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
+    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
 }
 
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
@@ -709,12 +739,12 @@ __device__ __forceinline__ void smooth_march_body(const float *__restrict__ s3, 
 #define SMOOTH_MARCH_WAVES(NP) ((NP) == 2 ? 2 : 4)
 #endif
 template <int NP, int PASSES, bool BOX>
-__global__ __launch_bounds__(64, SMOOTH_MARCH_WAVES(NP)) void k_smooth_march(const float *__restrict__ s3, float *__restrict__ o3, int W, int H,
+__global__ __launch_bounds__(64 * MARCH_WPB, SMOOTH_MARCH_WAVES(NP)) void k_smooth_march(const float *__restrict__ s3, float *__restrict__ o3, int W, int H,
                                                                               int strips_x, int n_strips, int Hs)
 {
     using G = SmoothMarch<NP, PASSES, BOX>;
     int sx, sy;
-    xcd_tile(n_strips, strips_x, sx, sy);
+    if (!march_strip(n_strips, strips_x, sx, sy)) return;
     const int xs = sx * G::VX, ys = sy * Hs;
     const int xe = min(xs + G::VX, W), ye = min(ys + Hs, H);
     int X0 = xs - G::HALO;
@@ -738,7 +768,8 @@ static void launch_smooth_march_t(hipStream_t st, const float *s3, float *o3, in
     }
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    hipLaunchKernelGGL((k_smooth_march<NP, PASSES, BOX>), dim3(n_strips), dim3(64), 0, st, s3, o3, W, H, strips_x, n_strips, Hs);
+    hipLaunchKernelGGL((k_smooth_march<NP, PASSES, BOX>), dim3((n_strips + MARCH_WPB - 1) / MARCH_WPB), dim3(64 * MARCH_WPB), 0, st, s3, o3, W, H,
+                       strips_x, n_strips, Hs);
 }
 
 // five passes (+ box) per launch; other pass counts belong to the LDS-tiled kernel (launch_smooth_fused)
