@@ -353,17 +353,17 @@ def main():
         del a, b
         if mode == "full":
             L, R = host_pair
-            out = np.empty((3, H, W), np.float32)
 
             def call(Lh, Rh, oh):
                 ts = []
                 for _ in range(4):
+                    o = oh if oh is not None else np.empty((3, H, W), np.float32)  # fresh, untouched result planes per call
                     t0 = time.perf_counter()
                     ctx.check(ctx.lib.ugsm_match_full(ctx.handle, Lh.ctypes.data, Rh.ctypes.data, W, H, stride,
-                                                      oh[0].ctypes.data, oh[1].ctypes.data, oh[2].ctypes.data))
+                                                      o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
                     ts.append(time.perf_counter() - t0)
                 return sorted(ts[1:])[1]  # median of the last three
-            t_page = call(L, R, out)
+            t_page = call(L, R, None)
             pl, pr, po = ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W))
             pl[...] = L
             pr[...] = R
@@ -371,7 +371,8 @@ def main():
             result["pcie_inclusive"] = {"pageable_ms_per_pair": 1e3 * t_page, "pageable_pairs_per_s": 1.0 / t_page,
                                         "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
                                         "note": "ugsm_match_full, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
-                                                "(193 MB); median of 3 calls"}
+                                                "(193 MB); median of 3 calls; pageable = fresh result planes for every call, as the reference "
+                                                "node allocates them (UG_GPU_matcher.cpp:414-418); the caller's free() is not in the call"}
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace ugsm;
@@ -64,6 +65,9 @@ struct Slot {
     unsigned *range_bad = nullptr;  // device word: 0 while every pyramid value of the pair in this slot passed range_ok (ugsm_exact.hpp)
     float *hout = nullptr;  // device staging for host-API outputs
     size_t hout_cap = 0;
+    float *hpin = nullptr;  // page-locked host staging for host-API outputs that land in pageable caller memory
+    size_t hpin_cap = 0;
+    hipEvent_t out_ev[3] = {nullptr, nullptr, nullptr};
     bool have_pyr = false;
     bool have_coarse = false;
     bool range_known = false;
@@ -601,6 +605,89 @@ int stage_in(ugsm_ctx *ctx, Slot &s, const uint8_t *rgbL, const uint8_t *rgbR, i
     return UGSM_OK;
 }
 
+// Result planes into caller memory.  Page-locked destinations (ugsm_host_alloc, or memory the caller registered) take the
+// device-to-host copies directly.  Pageable ones go through a page-locked staging buffer and a team of host threads: the
+// reference node allocates fresh result planes for every call (UG_GPU_matcher.cpp:414-418), and the first touch of 193 MB of
+// fresh pages by the single copy thread of a pageable hipMemcpy costs more than the whole match (30.7 ms against 16.6 ms per
+// 16 MP pair); spread over the team, and with plane k+1's transfer running under plane k's copy, it costs ~2 ms.
+bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'd pointer is "invalid value" to the runtime: clear the sticky error
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+void team_copy(void *dst, const void *src, size_t bytes)
+{
+    static const unsigned team = [] {
+        const char *e = getenv("UGSM_COPY_THREADS");
+        unsigned n = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1u, n);
+    }();
+    if (team == 1 || bytes < (1u << 22)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t chunk = ((bytes / team) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < team; t++) {
+        const size_t off = t * chunk;
+        if (off >= bytes) break;
+        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, std::min(chunk, bytes - off)); });
+    }
+    memcpy(dst, src, std::min(chunk, bytes));
+    for (std::thread &t : th) t.join();
+}
+
+// First touch of the caller's (possibly fresh) result pages by the host team WHILE the GPU is still matching: every page of
+// dst[0..2] gets one byte written (the planes are overwritten in full afterwards), so the page faults are off the critical path.
+void prefault_planes(float *const dst[3], size_t plane_floats)
+{
+    if (is_pinned(dst[0]) && is_pinned(dst[1]) && is_pinned(dst[2])) return;
+    const size_t pb = plane_floats * sizeof(float);
+    const unsigned team = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < team; t++)
+        th.emplace_back([=] {
+            for (int k = 0; k < 3; k++) {
+                volatile char *p = (volatile char *)dst[k];
+                const size_t lo = pb * t / team, hi = pb * (t + 1) / team;
+                for (size_t o = (lo + 4095) & ~(size_t)4095; o < hi; o += 4096) p[o] = 0;
+                if (t == 0 && pb) p[0] = 0;
+            }
+        });
+    for (std::thread &t : th) t.join();
+}
+
+int copy_out_planes(ugsm_ctx *ctx, Slot &s, const float *d_src, size_t plane_floats, float *const dst[3])
+{
+    const size_t pb = plane_floats * sizeof(float);
+    if (is_pinned(dst[0]) && is_pinned(dst[1]) && is_pinned(dst[2])) {
+        for (int k = 0; k < 3; k++) HIPCHK(ctx, hipMemcpyAsync(dst[k], d_src + k * plane_floats, pb, hipMemcpyDeviceToHost, s.st));
+        return UGSM_OK;
+    }
+    if (3 * plane_floats > s.hpin_cap) {
+        if (s.hpin) HIPCHK(ctx, hipHostFree(s.hpin));
+        s.hpin = nullptr;
+        s.hpin_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void **)&s.hpin, 3 * pb, hipHostMallocDefault));
+        s.hpin_cap = 3 * plane_floats;
+    }
+    for (int k = 0; k < 3; k++) {
+        if (!s.out_ev[k]) HIPCHK(ctx, hipEventCreateWithFlags(&s.out_ev[k], hipEventDisableTiming));
+        HIPCHK(ctx, hipMemcpyAsync(s.hpin + k * plane_floats, d_src + k * plane_floats, pb, hipMemcpyDeviceToHost, s.st));
+        HIPCHK(ctx, hipEventRecord(s.out_ev[k], s.st));
+    }
+    for (int k = 0; k < 3; k++) {
+        HIPCHK(ctx, hipEventSynchronize(s.out_ev[k]));
+        team_copy(dst[k], s.hpin + k * plane_floats, pb);
+    }
+    return UGSM_OK;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -689,6 +776,9 @@ void ugsm_destroy(ugsm_ctx *ctx)
                         (void *)s.rgbL, (void *)s.rgbR, (void *)s.hout, (void *)s.range_bad, (void *)s.d2, (void *)s.wd_rows})
             if (p) (void)hipFree(p);
         if (s.wd_host) (void)hipHostFree(s.wd_host);
+        if (s.hpin) (void)hipHostFree(s.hpin);
+        for (hipEvent_t e : s.out_ev)
+            if (e) (void)hipEventDestroy(e);
         if (s.st) (void)hipStreamDestroy(s.st);
     }
     delete ctx;
@@ -814,9 +904,9 @@ int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int
     UCHK(grow(ctx, s->hout, s->hout_cap, 3 * n));
     UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
     UCHK(enqueue_full(ctx, *s, 0, s->hout));
-    HIPCHK(ctx, hipMemcpyAsync(dispH, s->hout, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(ctx, hipMemcpyAsync(dispV, s->hout + n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(ctx, hipMemcpyAsync(dispC, s->hout + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    float *const dst[3] = {dispH, dispV, dispC};
+    prefault_planes(dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
+    UCHK(copy_out_planes(ctx, *s, s->hout, n, dst));
     return ugsm_wait(ctx, 0);
 }
 
@@ -870,9 +960,9 @@ int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *
     UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
     UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, nullptr, nullptr));
     UCHK(ugsm_reconstruct_full(ctx, 0, d_stack, d_stack + stackn, d_stack + 2 * stackn, W, H, off_x, off_y, d_full));
-    HIPCHK(ctx, hipMemcpyAsync(outH, d_full, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(ctx, hipMemcpyAsync(outV, d_full + n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    HIPCHK(ctx, hipMemcpyAsync(outC, d_full + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    float *const dst[3] = {outH, outV, outC};
+    prefault_planes(dst, n);
+    UCHK(copy_out_planes(ctx, *s, d_full, n, dst));
     return ugsm_wait(ctx, 0);
 }
 
