@@ -170,6 +170,22 @@ def test_march_values_outside_the_division_range_take_the_full_division(lib, orc
         assert_bit_equal(got, exp, f"{tag} np={np_lane}")
 
 
+def test_march_on_fovea_views(lib, orc, monkeypatch):
+    """Foveated mode hands the cost kernel (pointer, pitch) views into the pyramid levels (pitch != width); production never
+    runs the marching kernel there (the fovea is below its size threshold), forced on here, against the fixture."""
+    from conftest import load_golden
+    from ug_stereomatcher_amd import MatchGPULib
+    g = load_golden("fovea_320x240_l9_f4.npz")
+    monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
+    monkeypatch.setenv("UGSM_MARCH_SMOOTH", "1")
+    for np_lane in (1, 2):
+        monkeypatch.setenv("UGSM_MARCH_NP", str(np_lane))
+        m = MatchGPULib(3, ["node", "x", str(int(g["F"]))], levels=int(g["levels"]))
+        st = m.matchStack(g["L"], g["R"])
+        m.close()
+        assert_bit_equal(np.ascontiguousarray(np.asarray(st).transpose(1, 0, 2, 3)), g["stack"], f"fovea stack np={np_lane}")
+
+
 # ---- K-smooth, marching form -----------------------------------------------------------------------
 
 def smooth_ref(orc, d, passes, box):
