@@ -340,16 +340,19 @@ def main():
 
     # ---- device copy rate and the PCIe-inclusive service call (rank 0, N = 1) ------------------------------------------
     if rank == 0 and n_gpus == 1 and not args.no_service:
+        torch.cuda.synchronize()
         a = torch.zeros(1 << 28, dtype=torch.float32, device=dev)
         b = torch.empty_like(a)
-        torch.add(a, 1.0, out=b)
+        for _ in range(3):
+            torch.add(a, 1.0, out=b)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(4):
+        for _ in range(8):
             torch.add(a, 1.0, out=b)  # a streaming elementwise kernel: 1 GiB read + 1 GiB written per pass
         e1.record()
         torch.cuda.synchronize()
-        result["device_copy_GBps"] = 4 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
+        result["device_copy_GBps"] = 8 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9  # read + write
         del a, b
         if mode == "full":
             L, R = host_pair
