@@ -169,14 +169,15 @@ __device__ __forceinline__ void poly_fast(float c, float l, float r, float thr, 
     }
 }
 
-// The value the neighbouring lane holds in `v` (DPP wave shifts; lane 0 / lane 63 keep their own value).
+// The value the neighbouring lane holds in `v` (DPP wave shifts; lane 0 / lane 63 read 0: with bound_ctrl and no `old` operand the
+// compiler needs no copy in front of the DPP move and can fold it into the consuming instruction).
 __device__ __forceinline__ float lane_below(float v)  // from lane - 1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_above(float v)  // from lane + 1
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
 // smoothKernel divides the three weighted sums of a pixel by the same sumCorr (MatchLib.cu:1131-1139).
