@@ -14,16 +14,16 @@
 //     so the partial sums hold exactly the reference's intermediate values.  7 VALU per pixel and pass
 //     (3 products shared between the outputs they feed + 4 adds) instead of 9;
 //   * global loads run two rows ahead ((dx,dy)) / one row ahead (the warped gather of R, L, A) of the arithmetic.
-// Per pixel-iteration this is ~650 VALU lane-instructions against ~1080 in the LDS-tiled kernel, with the column
-// halo recomputed only 6 rows per strip (tile: 6 rows per 28) and 6 columns per 64*NP.
+// Per pixel-iteration this is ~720 VALU lane-instructions against ~1080 in the LDS-tiled kernel (SQ_INSTS_VALU, profiles/),
+// with the halo recomputed only 6 rows per strip (tile: 6 rows per 28) and 6 columns per 64*NP.
 //
 // Border semantics without cross-lane fix-ups: a lane whose pixel lies outside the image computes
 // the warp at the CLAMPED pixel, which is what a clamp-addressed fetch of R' returns (texture clamp, MatchLib.cu:56-60),
 // so R' is edge-replicated by construction; L is taken as zero outside (zero-padded smem convolution of the products,
 // SURVEY 9 U2/U3); only the five B fetches at clamped positions need a select, in the strips that touch the frame.
 //
-// FMAD (opt-in float contract): the reference binary is built with nvcc's default -fmad=true, which
-// contracts `sum += tap * k` into one FMA; FMAD = true evaluates the convolutions that way.
+// FMAD (development switch, not reachable through the C-ABI): evaluates the convolutions as FMA chains, the
+// way nvcc's default -fmad=true may contract `sum += tap * k`.  Measured slower than the literal form; no parity claim.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
 #include <type_traits>
@@ -803,7 +803,7 @@ void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *r
 // the convergence measure of the reference's (never called) early exit -- weightedDifference,
 // MatchGPULib.cpp:1336-1437 with kernels 17 / 18 (MatchLib.cu:1174-1373): sum(|D - OldD| * conf) / sum(conf) for dx and dy.
 // The reference's reduction has no defined order (and is called with the block count as the block size); this build's
-// definition (oracle/ugsm_oracle.c: orc_weighted_difference) is a fixed order of binary64 sums that maps onto one wave per
+// definition (the CPU restatement used by the tests mirrors it) is a fixed order of binary64 sums that maps onto one wave per
 // row: lane l adds its columns x = l (mod 64) left to right, lane 0 adds the 64 lane sums in lane order; a second, single-wave
 // kernel adds the rows the same way.  Deterministic, and bit-identical to the CPU restatement.
 // =========================================================================================
