@@ -816,3 +816,33 @@ def test_early_exit_stops_where_the_oracle_loop_stops(lib, orc):
         assert its[0] == ran, (eps, its[0], ran)
         assert_bit_equal(got, d, f"early exit eps={eps}")
     assert ran == mi  # eps = 1e-9 never triggers
+
+
+def test_early_exit_through_the_whole_matcher(lib, orc):
+    """The opt-in early exit across levels (the three field buffers rotate from level to level): the full matcher with a
+    threshold that stops most levels early, against the same loop driven level by level, iteration by iteration, through the
+    oracle."""
+    from ug_stereomatcher_amd import synth
+    W, H, levels, eps = 200, 150, 8, 0.25
+    L, R, _, _ = synth.make_pair(W, H, 5200)
+    pl, pr = orc.pyramid(orc.rgb_to_planes(L), levels), orc.pyramid(orc.rgb_to_planes(R), levels)
+    cur = np.zeros_like(pl[levels - 1])
+    ran = [-1] * levels
+    for i in range(levels - 1, -1, -1):
+        mi, S = orc.iterations_for_level(i), orc.smooth_passes_for_level(i)
+        for m in range(1, mi + 1):
+            nd, _ = orc.iterate_level(pl[i], pr[i], cur, mi, S, i == levels - 1, m, m)
+            dh, dv = orc.weighted_difference(nd, cur)
+            cur, ran[i] = nd, m
+            if m < mi and dh < eps and dv < eps:
+                break
+        if i > 0:
+            cur = orc.seed(cur, pl[i - 1].shape[2], pl[i - 1].shape[1])
+    assert any(r < orc.iterations_for_level(i) for i, r in enumerate(ran)), ran  # the threshold does bite somewhere
+    with lib.Context(levels=levels, early_exit_threshold=eps) as c:
+        out = np.empty((3, H, W), np.float32)
+        c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        its = (C.c_int * 32)()
+        c.check(c.lib.ugsm_last_iterations(c.handle, 0, its))
+    assert list(its[:levels]) == ran
+    assert_bit_equal(out, cur, "early exit, whole matcher")

@@ -425,7 +425,8 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
     if (early) {
         const size_t lvl = 3 * (size_t)W * H;
         UCHK(grow(ctx, s.d2, s.d2_cap, std::max(lvl, s.lvl_cap)));
-        third = s.d2;
+        // the three field buffers rotate through the levels: the spare one is whichever is neither `cur` nor `other` right now
+        third = (s.d0 != cur && s.d0 != other) ? s.d0 : ((s.d1 != cur && s.d1 != other) ? s.d1 : s.d2);
         final_out = nullptr;
     }
     int ran = 0;
