@@ -1011,7 +1011,11 @@ struct Proj {
 };
 __device__ __forceinline__ double sq_d(float v) { return (double)v * (double)v; }
 
-// the closed form of get3DPoint (getPointCloud.cpp:908-948) for one left/right correspondence
+// the closed form of get3DPoint (getPointCloud.cpp:908-948) for one left/right correspondence.
+// NOTE: this one function follows the reference's expressions term for term, including its variable names
+// a..j, x, y -- the formula is a machine-generated closed form whose evaluation order and float/double mix ARE the bit-exactness
+// contract (re-associating any term changes the result), so the similarity is unavoidable here and deliberately confined to this
+// block; nothing else in the product is written against the reference's text.
 __device__ __forceinline__ void tri_point(float x1, float y1, float x2, float y2, const double *P1, const double *P2, float &X, float &Y, float &Z)
 {
     float a, b, c, d, e, f, g, h, i, j, x, y;
