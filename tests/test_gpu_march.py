@@ -245,3 +245,26 @@ def test_smooth_march_degenerate_confidence(lib, orc, np_lane):
         for passes, box in [(5, 1), (10, 1), (5, 0)]:
             got = run_smooth(c, d, passes, box)
             assert_bit_equal(got, smooth_ref(orc, d, passes, box), f"degenerate np={np_lane} passes={passes} box={box}")
+
+
+def test_march_exact_invariances_at_full_level_size(lib):
+    """Size-independent exactness properties of one cost + smoothing iteration, checked at a level size the marching kernel runs
+    in production (2.1 Mpx; no oracle needed): (1) scaling both images by a power of two scales every product by an exact factor and
+    leaves every quotient, hence (dx, dy, conf), bit-identical; (2) exchanging colour channels 0 and 1 only swaps the operands of
+    the first (commutative) channel sum ((q0 + q1) + q2) / 3."""
+    from ug_stereomatcher_amd import synth
+    W, H = 1920, 1080
+    L, R, dx, dy = synth.make_pair(W, H, 6100)
+    pl = np.ascontiguousarray(L.transpose(2, 0, 1)).astype(np.float32)
+    pr = np.ascontiguousarray(R.transpose(2, 0, 1)).astype(np.float32)
+    rng = np.random.Generator(np.random.PCG64(93))
+    d0 = np.stack([dx + rng.normal(0, 0.3, dx.shape), dy + rng.normal(0, 0.3, dy.shape), 0.3 + 0.6 * rng.random(dx.shape)]).astype(np.float32)
+    with lib.Context(levels=1) as c:  # default threshold: 2.1 Mpx >= 0.9 Mpx -> marching cost kernel
+        base = iterate(c, pl, pr, d0, 6, 5, False, 1, 2)
+        for k in (2.0, 0.5):
+            got = iterate(c, pl * np.float32(k), pr * np.float32(k), d0, 6, 5, False, 1, 2)
+            assert_bit_equal(got, base, f"images scaled by {k}")
+        sw = iterate(c, np.ascontiguousarray(pl[[1, 0, 2]]), np.ascontiguousarray(pr[[1, 0, 2]]), d0, 6, 5, False, 1, 2)
+        assert_bit_equal(sw, base, "channels 0 and 1 exchanged")
+    with lib.Context(levels=1, march_min_pixels=-1) as c:  # and the LDS-tiled kernel agrees with all of it
+        assert_bit_equal(iterate(c, pl, pr, d0, 6, 5, False, 1, 2), base, "tiled kernel")
