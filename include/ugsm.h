@@ -66,7 +66,9 @@ typedef struct ugsm_config {
                              confidence-weighted mean change of dx and of dy between two iterations is below it
                              (differenceIterations / weightedDifference, MatchGPULib.cpp:1323-1437 -- dead code in the
                              reference, whose results this option therefore leaves; one host round trip per iteration) */
-    int reserved[1];
+    int small_max_pixels; /* levels of at most this many pixels run K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip:
+                             channel-parallel 16 x 12 tiles, one thread per pixel; same results bit for bit); 0 = default
+                             threshold, < 0 = never */
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);

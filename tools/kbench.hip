@@ -5,6 +5,7 @@
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march.hip"
+#include "../ug_stereomatcher_amd/csrc/ugsm_kernels_small.hip"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -87,6 +88,51 @@ int main(int argc, char **argv)
         const int np = argc > 5 ? atoi(argv[5]) : 1, rows = argc > 6 ? atoi(argv[6]) : 0;
         for (int i = 0; i < reps; i++) launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, np, rows, rb);
         CK(hipStreamSynchronize(st));
+        return 0;
+    }
+    if (argc > 4 && atoi(argv[4]) == 7) {  // latency kernels of the coarse levels against the LDS-tiled ones: kbench W H reps 7
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        auto cmp = [&](const char *what) {
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < 3 * n; i++)
+                if (memcmp(&ha[i], &hb[i], 4) != 0) { if (!bad) first = i; bad++; }
+            printf("%s: %zu of %zu values differ%s\n", what, bad, 3 * n, bad ? "" : " (bit-exact)");
+            if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+        };
+        for (int blend = 0; blend < 2; blend++) {
+            CK(hipMemset(o, 0xff, 12 * n)); CK(hipMemset(o2, 0xee, 12 * n));
+            launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, blend);
+            launch_cost_small(st, iL, iR, A, d, o2, W, H, 0.55f, blend);
+            cmp(blend ? "k_cost_small vs k_cost_split (blend)" : "k_cost_small vs k_cost_split");
+        }
+        for (int P = 0; P <= 5; P++)
+            for (int box = 0; box < 2; box++) {
+                if (P == 0 && !box) continue;
+                for (int rh : {18, 24, 32}) {
+                    CK(hipMemset(o, 0xff, 12 * n)); CK(hipMemset(o2, 0xee, 12 * n));
+                    launch_smooth_fused(st, d, o, W, H, P, box);
+                    launch_smooth_small(st, d, o2, W, H, P, box, rh);
+                    char nm[96]; snprintf(nm, sizeof nm, "k_smooth_small rh=%d P=%d box=%d vs k_smooth_fused", rh, P, box);
+                    cmp(nm);
+                }
+            }
+        for (int round = 0; round < 2; round++) {
+            for (int rh : {18, 24, 32}) {
+                char nm[96]; snprintf(nm, sizeof nm, "k_smooth_small rh=%d p5+box", rh);
+                timeit(nm, [&]() { launch_smooth_small(st, o, o2, W, H, 5, 1, rh); });
+                snprintf(nm, sizeof nm, "small + smooth_small rh=%d", rh);
+                timeit(nm, [&]() { launch_cost_small(st, iL, iR, A, d, o, W, H, 0.55f, 1); launch_smooth_small(st, o, o2, W, H, 5, 1, rh); });
+            }
+            timeit("k_cost_split", [&]() { launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1); });
+            timeit("k_cost_small", [&]() { launch_cost_small(st, iL, iR, A, d, o2, W, H, 0.55f, 1); });
+            timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, o, o2, W, H, 5, 1); });
+            timeit("split + smooth_fused", [&]() { launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1); launch_smooth_fused(st, o, o2, W, H, 5, 1); });
+            timeit("small + smooth_fused", [&]() { launch_cost_small(st, iL, iR, A, d, o, W, H, 0.55f, 1); launch_smooth_fused(st, o, o2, W, H, 5, 1); });
+        }
+        CK(hipGetLastError());
         return 0;
     }
     if (argc > 4 && atoi(argv[4]) == 5) {  // marching K-smooth against the LDS-tiled one: bit comparison + timing

@@ -37,6 +37,11 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 // lane (1 or 2; 0 = default), rows = strip height (0 = automatic), fmad = the contracted float contract.
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
                        int np, int rows, const unsigned *range_bad);
+// The same iteration for the coarse levels (ugsm_kernels_small.hip): the three channels of a 16 x 12 tile side by side, built for the
+// latency of one tile rather than for throughput.
+void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend);
+// `passes` (<= 5) Jacobi passes (+ box) for the coarse levels: one thread per pixel of an 18 x (rh - 14) tile + halo 7 (rh = 18, 24 or 32)
+void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh);
 // range_bad (device word, may be null = unknown): 0 when every pyramid value of the pair passed range_ok (ugsm_exact.hpp),
 // which lets K-cost use the range-guarded division; launch_range_scan ORs the check of `count` floats into it.
 void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad);

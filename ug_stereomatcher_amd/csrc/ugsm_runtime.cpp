@@ -27,11 +27,11 @@ namespace {
 
 constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
-enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COUNT };
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
     {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_smooth_march",
-     "k_pyr_base"},
-    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-"}};
+     "k_pyr_base", "k_cost_small", "k_smooth_small"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-"}};
 constexpr int kNoLevel = UGSM_MAX_LEVELS;  // stats cell of launches that belong to no pyramid level
 struct StatCell {
     long long launches = 0;
@@ -83,6 +83,8 @@ struct ugsm_ctx {
     std::vector<Slot> slots;
     std::string err;
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
+    int small_mask = 3;      // experiments (UGSM_SMALL_MASK): bit 0 = k_cost_small, bit 1 = k_smooth_small
+    int small_rh_force = 0;  // tests (UGSM_SMALL_RH): region height of k_smooth_small whatever the level size
 };
 
 namespace {
@@ -259,7 +261,7 @@ struct Timer {
     {
         // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
         // has ~750 launches; bracketing all of them costs slot 0 about 20 %); 2: every kernel class
-        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && (kclass == KC_COST || kclass == KC_COST_MARCH)));
+        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && (kclass == KC_COST || kclass == KC_COST_MARCH || kclass == KC_COST_SMALL)));
         if (!on) return;
         rec.kclass = kclass;
         rec.level = sl->cur_level;
@@ -348,6 +350,25 @@ bool use_march(const ugsm_config &cfg, int W, int H)
     return (long long)W * H >= thr;
 }
 
+// K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
+// has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
+// (tools/kbench mode 7).  Returns the K-smooth region height to use (0 = not a small level).
+constexpr int kSmallDefaultMaxPixels = 150000;
+int small_rh(const ugsm_ctx *ctx, int W, int H)
+{
+    const ugsm_config &cfg = ctx->cfg;
+    if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
+    const long long thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : kSmallDefaultMaxPixels;
+    const long long px = (long long)W * H;
+    if (px > thr || use_march(cfg, W, H)) return 0;
+    if (ctx->small_rh_force) return ctx->small_rh_force;
+    // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other slots' pairs share the chip -- the 18 x 4 / 18 x 10 tiles
+    // redo 8 x / 4.6 x the work, free on an idle chip, 3.5 % of the throughput with three pairs in flight (tools/sweep_small.sh).
+    // A one-slot context has nothing to overlap with: the smallest tile that still gives every workgroup a CU of its own, or nearly.
+    if (cfg.slots > 1) return 32;
+    return px <= 36000 ? 18 : (px <= 80000 ? 24 : 32);
+}
+
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
 // result and `b` is scratch.
 // final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
@@ -372,11 +393,13 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             left -= p;
             if (p == 0 && !do_box) break;
             const bool march = p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx->cfg, W, H);
-            Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : KC_SMOOTH, px);
+            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H) : 0;
+            Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : (rh ? KC_SMOOTH_SMALL : KC_SMOOTH), px);
             const bool box_now = do_box && left == 0;
             float *dst = (left == 0 && final_out) ? final_out : b;
             // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
             if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, ctx->cfg.march_np, ctx->cfg.march_rows);
+            else if (rh) launch_smooth_small(s.st, a, dst, W, H, p, box_now, rh);
             else launch_smooth_fused(s.st, a, dst, W, H, p, box_now);
             if (dst == final_out) a = final_out;
             else std::swap(a, b);
@@ -450,8 +473,10 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
             const bool march = use_march(ctx->cfg, W, H);
-            Timer t(ctx, &s, si, march ? KC_COST_MARCH : KC_COST, px);
+            const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H) != 0;
+            Timer t(ctx, &s, si, march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST), px);
             if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            else if (small) launch_cost_small(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
         ran = m;
@@ -737,6 +762,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (const char *e = getenv("UGSM_MARCH_NP")) cfg.march_np = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_ROWS")) cfg.march_rows = atoi(e);
     if (const char *e = getenv("UGSM_MARCH_SMOOTH")) cfg.march_smooth = atoi(e);
+    if (const char *e = getenv("UGSM_SMALL_MAX_PIXELS")) cfg.small_max_pixels = atoi(e);
     {   // the kernels carry the Gaussian taps as literals (ugsm_device.hpp); they must be the numbers the reference computes at
         // start-up: five float literals divided by their float sum (MatchGPULib.cpp:761-774)
         const float lit[5] = {0.0816475f, 0.218507f, 0.303281f, 0.218507f, 0.0816475f};
@@ -754,6 +780,11 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (hipSetDevice(cfg.device) != hipSuccess) return UGSM_ERR_NO_DEVICE;
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
+    if (const char *e = getenv("UGSM_SMALL_MASK")) ctx->small_mask = atoi(e);
+    if (const char *e = getenv("UGSM_SMALL_RH")) {
+        const int v = atoi(e);
+        if (v == 18 || v == 24 || v == 32) ctx->small_rh_force = v;
+    }
     ctx->slots.resize(cfg.slots);
     for (Slot &s : ctx->slots) {
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&s.range_bad, 64) != hipSuccess) {
