@@ -268,3 +268,29 @@ def test_march_exact_invariances_at_full_level_size(lib):
         assert_bit_equal(sw, base, "channels 0 and 1 exchanged")
     with lib.Context(levels=1, march_min_pixels=-1) as c:  # and the LDS-tiled kernel agrees with all of it
         assert_bit_equal(iterate(c, pl, pr, d0, 6, 5, False, 1, 2), base, "tiled kernel")
+
+
+def test_seeding_fused_into_the_first_cost_launch(lib, monkeypatch):
+    """A level whose K-cost is the marching kernel is seeded inside its first launch (launch_cost_march_seeded): same planes as with
+    the separate k_seed launch, in full and foveated mode (fovea crop offsets, off-centre fovea), and the k_seed launches are gone."""
+    import ctypes as C
+    from ug_stereomatcher_amd import synth
+    W, H = 700, 500
+    L, R, _, _ = synth.make_pair(W, H, 6200)
+    monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("UGSM_FUSE_SEED", fuse)
+        with lib.Context(levels=9, fovea_levels=4, profile_events=2) as c:
+            full = np.empty((3, H, W), np.float32)
+            c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, W * 3, full[0].ctypes.data, full[1].ctypes.data, full[2].ctypes.data))
+            seeds_full = sum(s["launches"] for s in c.kernel_stats() if s["name"] == "k_seed")
+            fw, fh = C.c_int(), C.c_int()
+            c.check(c.lib.ugsm_fovea_dims(W, H, 9, 4, C.byref(fw), C.byref(fh)))
+            st = np.empty((3, 4, fh.value, fw.value), np.float32)
+            c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data, R.ctypes.data, W, H, W * 3, 37, -21, st[0].ctypes.data, st[1].ctypes.data,
+                                              st[2].ctypes.data, None, None))
+            res[fuse] = (full, st, seeds_full)
+    assert res["1"][2] == 0 and res["0"][2] == 8, (res["1"][2], res["0"][2])
+    assert_bit_equal(res["1"][0], res["0"][0], "full mode, fused seeding")
+    assert_bit_equal(res["1"][1], res["0"][1], "foveated mode, fused seeding")

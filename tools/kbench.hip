@@ -90,6 +90,21 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 9) {  // pyramid base: whole kernel against its level-0 part alone (no level-1 / level-2 sites): kbench W H reps 9
+        uint8_t *rgb; CK(hipMalloc(&rgb, 3 * n)); CK(hipMemset(rgb, 77, 3 * n));
+        const int W1 = (int)(W / 1.41421356), H1 = (int)(H / 1.41421356), W2 = W / 2, H2 = H / 2;
+        float *l1 = R, *l2 = A;
+        for (int round = 0; round < 3; round++) {
+            timeit("k_pyr_base", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb); });
+            timeit("k_pyr_base level 0 only", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, 0, 0, l2, 0, 0, rb); });
+            timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f, nullptr); });
+            timeit("blur_decimate 2", [&]() { launch_blur_decimate(st, L, W, H, o, W2, H2, 2.0f, nullptr); });
+            timeit("seed 8M -> 16M", [&]() { launch_seed(st, d, W1, H1, o, W, H, 0, 0); });
+            timeit("sqblur", [&]() { launch_sqblur_clamp(st, iL, W, H, o); });
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 7) {  // latency kernels of the coarse levels against the LDS-tiled ones: kbench W H reps 7
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);

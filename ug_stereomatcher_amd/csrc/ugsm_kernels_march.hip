@@ -160,17 +160,22 @@ struct MarchRow {
     float R[3][NP], L[3][NP], A[3][NP], O[3][NP];
 };
 
-template <int NP, bool EDGE, bool FMAD, bool FAST>
+// SEED: d3 is the coarser level's field (sm.Ws x sm.Hs) and this is the level's first iteration: every (dx, dy, conf) the
+// iteration reads is subsampleDispKernel's value (MatchLib.cu:372-401, k_seed in ugsm_kernels_ref.hip) formed on the fly,
+// SCALE * coarse[floor((x + cx + .5f) * sf), floor((y + cy + .5f) * sf)] with the product in binary64 -- the seeded field is never
+// written to memory (at 16 MP: 290 MB and a 95 us launch per level saved for ~3 % more arithmetic in this one iteration).
+template <int NP, bool EDGE, bool FMAD, bool FAST, bool SEED = false>
 __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                 float *__restrict__ nd3, const int W, const int H, const float thr, const int blend,
-                                                const int X0, const int xs, const int xe, const int ys, const int ye)
+                                                const int X0, const int xs, const int xe, const int ys, const int ye, const SeedMap sm = SeedMap{0, 0, 0, 0})
 {
     const int lane = threadIdx.x & 63;
     const size_t n = (size_t)W * H;
+    const size_t nD = SEED ? (size_t)sm.Ws * sm.Hs : n;  // plane size of the field d3 points at
     gchar_c *const Lb[3] = {uniform_base(L.p), uniform_base(L.p + L.plane), uniform_base(L.p + 2 * L.plane)};
     gchar_c *const Rb[3] = {uniform_base(R.p), uniform_base(R.p + R.plane), uniform_base(R.p + 2 * R.plane)};
     gchar_c *const Ab[3] = {uniform_base(A3), uniform_base(A3 + n), uniform_base(A3 + 2 * n)};
-    gchar_c *const Db[3] = {uniform_base(d3), uniform_base(d3 + n), uniform_base(d3 + 2 * n)};
+    gchar_c *const Db[3] = {uniform_base(d3), uniform_base(d3 + nD), uniform_base(d3 + 2 * nD)};
     gchar_c *const Nb[3] = {uniform_base(nd3), uniform_base(nd3 + n), uniform_base(nd3 + 2 * n)};
 
     // per-lane column constants.  px: the pixel whose R', L and products the lane holds; po = px - SKEW: the pixel whose row-pass
@@ -191,6 +196,19 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
         xc[j] = (float)pc + 0.5f;
         stv[j] = po[j] >= xs && po[j] < xe;
     }
+    const float seed_sf = (float)(1 / UGSM_SCALE);
+    unsigned scol[NP], scolo[NP];  // SEED: byte offsets of the coarse columns the (clamped) columns px / po sample
+    if constexpr (SEED) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            scol[j] = (unsigned)tex_index(((float)(clampi(px[j], 0, W - 1) + sm.cx) + 0.5f) * seed_sf, sm.Ws) * 4u;
+            scolo[j] = (unsigned)tex_index(((float)(clampi(po[j], 0, W - 1) + sm.cx) + 0.5f) * seed_sf, sm.Ws) * 4u;
+        }
+    }
+    auto seedv = [&](const float v) -> float {
+        if constexpr (SEED) return (float)(UGSM_SCALE * (double)v);
+        else return v;
+    };
     const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     auto rowc = [&](int r) { return min(max(r, 0), H - 1); };  // rows are clamped with scalar ops in every strip
@@ -200,19 +218,29 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
         for (int j = 0; j < NP; j++) off[j] = ro + (skewed ? coffo[j] : coff[j]);
     };
 
+    // row offsets into the field d3 points at: the level's own rows, or (SEED) the coarse rows they sample
+    auto d_off = [&](const int r, unsigned (&off)[NP], const bool skewed) {
+        if constexpr (SEED) {
+            const unsigned ro = (unsigned)tex_index(((float)(rowc(r) + sm.cy) + 0.5f) * seed_sf, sm.Hs) * ((unsigned)sm.Ws * 4u);
+#pragma unroll
+            for (int j = 0; j < NP; j++) off[j] = ro + (skewed ? scolo[j] : scol[j]);
+        } else {
+            row_off(r, pitchW, off, skewed);
+        }
+    };
     auto load_d = [&](const int r, float (&dx)[NP], float (&dy)[NP]) {
         unsigned off[NP];
-        row_off(r, pitchW, off);
-        ld_row<NP, EDGE>(Db[0], off, dx);
-        ld_row<NP, EDGE>(Db[1], off, dy);
+        d_off(r, off, false);
+        ld_row<NP, EDGE || SEED>(Db[0], off, dx);
+        ld_row<NP, EDGE || SEED>(Db[1], off, dy);
     };
     // warpAbyB (MatchLib.cu:510-515): R'[x,y] = tex(R, x + 0.5 + dx, y + 0.5 + dy) at the clamped pixel
     auto gather = [&](const int r, const float (&dx)[NP], const float (&dy)[NP], float (&o)[3][NP]) {
         const float yc = (float)rowc(r) + 0.5f;
 #pragma unroll
         for (int j = 0; j < NP; j++) {
-            const int sx = tex_index_nb(xc[j] + dx[j], wm1);
-            const int sy = tex_index_nb(yc + dy[j], hm1);
+            const int sx = tex_index_nb(xc[j] + seedv(dx[j]), wm1);
+            const int sy = tex_index_nb(yc + seedv(dy[j]), hm1);
             const unsigned off = (__umul24((unsigned)sy, (unsigned)R.pitch) + (unsigned)sx) * 4u;
 #pragma unroll
             for (int k = 0; k < 3; k++) o[k][j] = ld_at(Rb[k], off);
@@ -229,8 +257,10 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
         row_off(r, pitchW, off, true);
 #pragma unroll
         for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k], off, a[k]);
+        unsigned offd[NP];
+        d_off(r, offd, true);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Db[k], off, od[k]);
+        for (int k = 0; k < 3; k++) ld_row<NP, EDGE || SEED>(Db[k], offd, od[k]);
     };
 
     // ---- state carried down the rows --------------------------------------------------------------------------
@@ -335,9 +365,9 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 poly_fast(Q[4][j], Q[0][j], Q[1][j], thr, ddx, rx);
                 poly_fast(Q[4][j], Q[2][j], Q[3][j], thr, ddy, ry);
                 float kap = ry * rx;
-                if (blend) kap = blend_conf(cur.O[2][j], kap);
-                ndx[j] = cur.O[0][j] + ddx;
-                ndy[j] = cur.O[1][j] + ddy;
+                if (blend) kap = blend_conf(seedv(cur.O[2][j]), kap);
+                ndx[j] = seedv(cur.O[0][j]) + ddx;
+                ndy[j] = seedv(cur.O[1][j]) + ddy;
                 nkp[j] = kap;
             }
             const unsigned ro = (unsigned)o * pitchW;
@@ -406,7 +436,7 @@ __device__ long long *g_march_stamps = nullptr;  // per workgroup: delta s_memti
 template <int NP, bool FMAD>
 __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
-                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad)
+                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm)
 {
 #ifdef UGSM_MARCH_STAMP  // diagnostic build only (tools/kbench_stamp): in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
     const long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -421,6 +451,18 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
     const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && ys >= 2 && ye <= H - 2;
     // range-guarded division (ugsm_exact.hpp) when the pyramid builder found every value of the pair in range
     const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
+    if constexpr (NP == 1 && !FMAD) {
+        if (sm.Ws > 0) {  // first iteration of a level, seeded from the coarser level's field (kernel-uniform)
+            if (fast) {
+                if (interior) cost_march_body<NP, false, FMAD, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+                else cost_march_body<NP, true, FMAD, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+            } else {
+                if (interior) cost_march_body<NP, false, FMAD, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+                else cost_march_body<NP, true, FMAD, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+            }
+            return;
+        }
+    }
     if (fast) {
         if (interior) cost_march_body<NP, false, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
         else cost_march_body<NP, true, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
@@ -439,7 +481,7 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 
 template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
-                                int fmad, int rows, const unsigned *range_bad)
+                                int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0})
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
@@ -455,8 +497,14 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
     const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
-    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
-    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad);
+    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+}
+
+void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
+                              int blend, int rows, const unsigned *range_bad)
+{
+    launch_cost_march_t<1>(st, L, R, A3, coarse3, nd3, W, H, thr, blend, 0, rows, range_bad, sm);
 }
 
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,

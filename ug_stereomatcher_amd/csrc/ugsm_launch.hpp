@@ -17,6 +17,12 @@ struct Img3 {
     size_t plane;
 };
 
+// Where a level's first iteration finds its starting field when the seeding is fused into K-cost: the coarser level's
+// (dx, dy, conf), Ws x Hs, sampled as subsampleDispKernel does (MatchLib.cu:372-401) with the fovea crop offset (cx, cy).
+struct SeedMap {
+    int Ws, Hs, cx, cy;
+};
+
 // ---- kernel_path 1 (ugsm_kernels_ref.hip) -------------------------------------------
 void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes);
 void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
@@ -42,6 +48,9 @@ void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend);
 // `passes` (<= 5) Jacobi passes (+ box) for the coarse levels: one thread per pixel of an 18 x (rh - 14) tile + halo 7 (rh = 18, 24 or 32)
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh);
+// First iteration of a level with the seeding fused in: coarse3 = the coarser level's field (never materialised at this level's size)
+void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
+                              int blend, int rows, const unsigned *range_bad);
 // range_bad (device word, may be null = unknown): 0 when every pyramid value of the pair passed range_ok (ugsm_exact.hpp),
 // which lets K-cost use the range-guarded division; launch_range_scan ORs the check of `count` floats into it.
 void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad);

@@ -83,6 +83,7 @@ struct ugsm_ctx {
     std::vector<Slot> slots;
     std::string err;
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
+    int fuse_seed = 1;       // experiments (UGSM_FUSE_SEED=0): seed every level with its own launch
     int small_mask = 3;      // experiments (UGSM_SMALL_MASK): bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // tests (UGSM_SMALL_RH): region height of k_smooth_small whatever the level size
 };
@@ -369,6 +370,15 @@ int small_rh(const ugsm_ctx *ctx, int W, int H)
     return px <= 36000 ? 18 : (px <= 80000 ? 24 : 32);
 }
 
+// Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is the marching
+// kernel in its default one-pixel-per-lane form: the seeded field is then never written (launch_cost_march_seeded).  Not with the early
+// exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
+bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
+{
+    const ugsm_config &cfg = ctx->cfg;
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && cfg.march_np != 2 && use_march(cfg, W, H);
+}
+
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
 // result and `b` is scratch.
 // final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
@@ -433,8 +443,10 @@ int weighted_difference(ugsm_ctx *ctx, Slot &s, const float *newd3, const float 
 // on entry and on exit; other is scratch of the same size.
 // final_out (optional, fused path only): where the last iteration leaves its result instead of the ping-pong buffer
 // (saves the device-to-device copy of the finished level); cur/other are then not meaningful afterwards.
+// seed (optional, see fuse_seed): `cur` holds the COARSER level's field (seed->Ws x seed->Hs) and iteration m_from reads its starting
+// field through the seeding map instead of from a materialised seeded field.
 int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int mi, int S, bool is_top, int m_from,
-              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr)
+              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr, const SeedMap *seed = nullptr)
 {
     const bool ref = ctx->cfg.kernel_path == 1;
     const double px = (double)W * H;
@@ -475,7 +487,9 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             const bool march = use_march(ctx->cfg, W, H);
             const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H) != 0;
             Timer t(ctx, &s, si, march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST), px);
-            if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            if (march && seed && m == m_from)
+                launch_cost_march_seeded(s.st, L, R, s.A, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            else if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else if (small) launch_cost_small(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
@@ -529,18 +543,26 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
+    SeedMap sm{0, 0, 0, 0};
+    bool seeded = false;
     for (int i = top; i >= 0; i--) {
         s.cur_level = i;
         const int mi = level_iterations(i);
         // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
         const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0 && !(ctx->cfg.early_exit_threshold > 0.0f);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr));
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr, seeded ? &sm : nullptr));
         if (direct) return UGSM_OK;
+        seeded = false;
         if (i > 0) {
-            Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
-            launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
-            std::swap(cur, other);
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1])) {  // the next level's first K-cost launch reads `cur` through the seeding map
+                sm = SeedMap{s.w[i], s.h[i], 0, 0};
+                seeded = true;
+            } else {
+                Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
+                launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+                std::swap(cur, other);
+            }
         }
     }
     HIPCHK(ctx, hipMemcpyAsync(d_out, cur, sizeof(float) * 3 * (size_t)s.W * s.H, hipMemcpyDeviceToDevice, s.st));
@@ -555,15 +577,23 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
+    SeedMap sm{0, 0, 0, 0};
+    bool seeded = false;
     for (int i = top; i >= F - 1; i--) {
         s.cur_level = i;
         const int mi = level_iterations(i);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr));
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr));
+        seeded = false;
         if (i > F - 1) {
-            Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
-            launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
-            std::swap(cur, other);
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1])) {
+                sm = SeedMap{s.w[i], s.h[i], 0, 0};
+                seeded = true;
+            } else {
+                Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
+                launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+                std::swap(cur, other);
+            }
         }
     }
     HIPCHK(ctx, hipMemcpyAsync(d_state, cur, sizeof(float) * 3 * (size_t)s.w[F - 1] * s.h[F - 1], hipMemcpyDeviceToDevice, s.st));
@@ -585,14 +615,17 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
     launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)(F - 1) * fn, (size_t)F * fn, g.fw);
     for (int i = F - 2; i >= 0; i--) {
         s.cur_level = i;
-        {   // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
+        // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
+        const SeedMap sm{g.fw, g.fh, g.cx[i], g.cy[i]};
+        const bool seeded = fuse_seed(ctx, g.fw, g.fh);
+        if (!seeded) {
             Timer t(ctx, &s, si, KC_SEED, (double)fn);
             launch_seed(s.st, cur, g.fw, g.fh, other, g.fw, g.fh, g.cx[i], g.cy[i]);
             std::swap(cur, other);
         }
         const int mi = level_iterations(i);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, g.ox[i], g.oy[i]), level_view(s, s.pyrR, i, g.ox[i], g.oy[i]),
-                       g.fw, g.fh, mi, level_smooth(i), false, 1, mi, cur, other, nullptr));
+                       g.fw, g.fh, mi, level_smooth(i), false, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr));
         launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)i * fn, (size_t)F * fn, g.fw);
     }
     // pyramid stacks as the node publishes them (UG_GPU_matcher.cpp:203-213): [level][channel][row]
@@ -781,6 +814,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
     if (const char *e = getenv("UGSM_SMALL_MASK")) ctx->small_mask = atoi(e);
+    if (const char *e = getenv("UGSM_FUSE_SEED")) ctx->fuse_seed = atoi(e);
     if (const char *e = getenv("UGSM_SMALL_RH")) {
         const int v = atoi(e);
         if (v == 18 || v == 24 || v == 32) ctx->small_rh_force = v;
