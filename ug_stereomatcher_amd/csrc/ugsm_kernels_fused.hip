@@ -1358,25 +1358,32 @@ __global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, fl
 // sampled rows.  One workgroup = a 64x16 tile of level 0 (+ halo 2); every level-1 / level-2 pixel belongs to the tile
 // that contains its sampling site, so each output is written exactly once.
 // =========================================================================================
-constexpr int BTX = 64, BTY = 16, BRW = BTX + 4, BRH = BTY + 4, BC1 = 52, BR1 = 16, BC2 = 32, BR2 = 8;
-
+// Where the time goes (ablations, tools/kbench mode 9, 16 MP): the 5-tap passes are bound by LDS instructions, not by arithmetic.
+// So the row pass is computed DENSELY, once for both levels, a quad of outputs from two 16-byte LDS reads (64 columns instead of
+// the 84 candidate columns of the two levels, and a third of the LDS instructions); only the column pass runs at the sampled
+// sites: waves 0-2 own the 52 candidate columns of level 1 (one row phase each), wave 3 the 32 columns of level 2 (two rows at a
+// time), so that an output row segment is written by the lanes of one wave.  Level 0 leaves as 16-byte stores.
+constexpr int BTX = 64, BTY = 16, BRW = BTX + 8, BRH = BTY + 4, BC1 = 52, BR1 = 16, BC2 = 32, BR2 = 8;
+// ABL: development-only ablation mask (tools/kbench.hip mode 9): 1 = no level-1/2 stores, 2 = no column pass, 4 = no row pass, 8 = no level-0 store
+template <int ABL = 0>
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
                                                   float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
                                                   unsigned *__restrict__ range_bad)
 {
-    __shared__ float sS[3][BRH * BRW];
-    __shared__ float sT1[3][BRH * BC1];
-    __shared__ float sT2[3][BRH * BC2];
+    __shared__ __attribute__((aligned(16))) float sS[3][BRH * BRW];  // tile + halo 2: region column c at [c], rows 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float sT[3][BRH * BTX];  // row pass of every tile column, every region row
+    __shared__ int sRowSite[BR1 + BR2];  // region row of the sampling site of candidate row ly (level 1, then level 2), -1 = not in this tile
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * BTX, y0 = blockIdx.y * BTY;
     const float sf1 = (float)1.41421356, sf2 = 2.0f;
     {   // rgb8 -> float planes of tile + halo 2, zero outside the image (the blur's zero padding, U2/U3)
-        constexpr int NLD = (BRH * BRW + 255) / 256;
+        constexpr int RW = BTX + 4;
+        constexpr int NLD = (BRH * RW + 255) / 256;
         float v[NLD][3];
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
-            const int it = min(tid + u * 256, BRH * BRW - 1);
-            const int r = it / BRW, c = it - r * BRW;
+            const int it = min(tid + u * 256, BRH * RW - 1);
+            const int r = it / RW, c = it - r * RW;
             const int gx = x0 - 2 + c, gy = y0 - 2 + r;
             const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
             const uint8_t *p = rgb + (size_t)min(max(gy, 0), H - 1) * stride + 3 * min(max(gx, 0), W - 1);
@@ -1388,25 +1395,11 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
             const int it = tid + u * 256;
-            if (it < BRH * BRW) {
-                sS[0][it] = v[u][0];
-                sS[1][it] = v[u][1];
-                sS[2][it] = v[u][2];
-            }
-        }
-    }
-    __syncthreads();
-    {   // level 0: the tile itself, rows of 64 floats
-        const size_t n = (size_t)W * H;
-        for (int it = tid; it < BTX * BTY; it += 256) {
-            const int r = it / BTX, c = it - r * BTX;
-            const int gx = x0 + c, gy = y0 + r;
-            if (gx < W && gy < H) {
-                const size_t at = (size_t)gy * W + gx;
-                const int la = (r + 2) * BRW + c + 2;
-                lvl0[at] = sS[0][la];
-                lvl0[n + at] = sS[1][la];
-                lvl0[2 * n + at] = sS[2][la];
+            if (it < BRH * RW) {
+                const int r = it / RW, c = it - r * RW;
+                sS[0][r * BRW + c] = v[u][0];
+                sS[1][r * BRW + c] = v[u][1];
+                sS[2][r * BRW + c] = v[u][2];
             }
         }
     }
@@ -1415,48 +1408,79 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
     // rounding slip of the float quotient); at most 12 rows, 16 candidates.  Level 2: site = 2i+1, exactly 32 x 8.
     const int ib1 = max((int)((float)x0 / sf1) - 1, 0), jb1 = max((int)((float)y0 / sf1) - 1, 0);
     const int ib2 = x0 / 2, jb2 = y0 / 2;
-    // row pass at the sampled columns, every region row, three channels
-    for (int it = tid; it < BRH * (BC1 + BC2); it += 256) {
-        const int r = it / (BC1 + BC2), l = it - r * (BC1 + BC2);
-        const bool one = l < BC1;
-        const int lx = one ? l : l - BC1;
-        const int i = (one ? ib1 : ib2) + lx;
-        if (i < (one ? W1 : W2)) {
-            const int site = tex_index(((float)i + 0.5f) * (one ? sf1 : sf2), W);
-            if (site >= x0 && site < x0 + BTX) {
-                const int c = site - (x0 - 2);
+    if (tid < BR1 + BR2) {
+        const bool o1 = tid < BR1;
+        const int j = (o1 ? jb1 : jb2) + (o1 ? tid : tid - BR1);
+        int site = -1;
+        if (j < (o1 ? H1 : H2)) {
+            const int sy = tex_index(((float)j + 0.5f) * (o1 ? sf1 : sf2), H);
+            if (sy >= y0 && sy < y0 + BTY) site = sy - (y0 - 2);
+        }
+        sRowSite[tid] = site;
+    }
+    __syncthreads();
+    if constexpr (!(ABL & 8)) {  // level 0: the tile itself; a thread owns 4 consecutive pixels of one row
+        const size_t n = (size_t)W * H;
+        const int r = tid >> 4, c = (tid & 15) * 4;
+        const int gx = x0 + c, gy = y0 + r;
+        if (gy < H && gx < W) {
+            const size_t at = (size_t)gy * W + gx;
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float *p = &sS[k][r * BRW + c];
-                    const float t = tap5(p[-2], p[-1], p[0], p[1], p[2]);
-                    if (one) sT1[k][r * BC1 + lx] = t;
-                    else sT2[k][r * BC2 + lx] = t;
+            for (int k = 0; k < 3; k++) {
+                float q[4];
+                ld2(&sS[k][(r + 2) * BRW + c + 2], q);
+                ld2(&sS[k][(r + 2) * BRW + c + 4], q + 2);
+                if ((W & 3) == 0) {  // (then gx + 3 < W, and every plane row starts 16-byte aligned)
+                    *reinterpret_cast<float4 *>(lvl0 + k * n + at) = make_float4(q[0], q[1], q[2], q[3]);
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        if (gx + i < W) lvl0[k * n + at + i] = q[i];
                 }
             }
         }
     }
+    // row pass, dense: tile columns 4q .. 4q+3 of region row r from region columns 4q .. 4q+7 (level-0 values are >= 0: tap5p = tap5
+    // without its "0 +")
+    if constexpr (!(ABL & 4)) {
+        for (int it = tid; it < 3 * BRH * (BTX / 4); it += 256) {
+            const int k = it / (BRH * (BTX / 4)), rem = it - k * (BRH * (BTX / 4));
+            const int r = rem / (BTX / 4), q = rem - r * (BTX / 4);
+            float p[8], o[4];
+            ld4(&sS[k][r * BRW + 4 * q], p);
+            ld4(&sS[k][r * BRW + 4 * q + 4], p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = tap5p(p[i], p[i + 1], p[i + 2], p[i + 3], p[i + 4]);
+            st4(&sT[k][r * BTX + 4 * q], o);
+        }
+    }
     __syncthreads();
-    // column pass at the sampled rows (level 0 holds the integers 0..255: always inside range_ok; levels 1 and 2 are checked)
+    // column pass at the sampled sites (level 0 holds the integers 0..255: always inside range_ok; levels 1 and 2 are checked)
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool one = wave < 3;
+    static_assert(BC1 <= 64 && 2 * BC2 == 64, "waves 0-2: one level-1 row per step; wave 3: two level-2 rows per step");
+    const int lx = one ? lane : (lane % BC2);
+    const int phase = one ? wave : (lane / BC2), nphase = one ? 3 : 2;
+    const int ci = (one ? ib1 : ib2) + lx;
+    int tcol = -1;  // tile column of this candidate column's sampling site, -1 = not in this tile
+    if ((!one || lane < BC1) && ci < (one ? W1 : W2)) {
+        const int site = tex_index(((float)ci + 0.5f) * (one ? sf1 : sf2), W);
+        if (site >= x0 && site < x0 + BTX) tcol = site - x0;
+    }
     bool bad = false;
-    for (int it = tid; it < BR1 * BC1 + BR2 * BC2; it += 256) {
-        const bool one = it < BR1 * BC1;
-        const int l = one ? it : it - BR1 * BC1;
-        const int cw = one ? BC1 : BC2;
-        const int ly = l / cw, lx = l - ly * cw;
-        const int i = (one ? ib1 : ib2) + lx, j = (one ? jb1 : jb2) + ly;
-        const int Wd = one ? W1 : W2, Hd = one ? H1 : H2;
-        if (i < Wd && j < Hd) {
-            const float sf = one ? sf1 : sf2;
-            const int sx = tex_index(((float)i + 0.5f) * sf, W), sy = tex_index(((float)j + 0.5f) * sf, H);
-            if (sx >= x0 && sx < x0 + BTX && sy >= y0 && sy < y0 + BTY) {
-                const int cy = sy - (y0 - 2);
-                float *dst = one ? lvl1 : lvl2;
-                const size_t nd = (size_t)Wd * Hd, at = (size_t)j * Wd + i;
+    if (tcol >= 0 && !(ABL & 2)) {
+        float *const dst = one ? lvl1 : lvl2;
+        const int Wd = one ? W1 : W2;
+        const size_t nd = (size_t)Wd * (one ? H1 : H2);
+        const int nrow = one ? BR1 : BR2, jb = one ? jb1 : jb2, tb = one ? 0 : BR1;
+        for (int ly = phase; ly < nrow; ly += nphase) {
+            const int cy = sRowSite[tb + ly];
+            if (cy >= 0) {
+                const size_t at = (size_t)(jb + ly) * Wd + ci;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const float *p = (one ? &sT1[k][cy * BC1 + lx] : &sT2[k][cy * BC2 + lx]);
-                    const float v = tap5(p[-2 * cw], p[-cw], p[0], p[cw], p[2 * cw]);
-                    dst[k * nd + at] = v;
+                    const float *p = &sT[k][cy * BTX + tcol];
+                    const float v = tap5p(p[-2 * BTX], p[-BTX], p[0], p[BTX], p[2 * BTX]);
+                    if (!(ABL & 1) || v == 12345.678f) dst[k * nd + at] = v;
                     bad |= !range_ok(v);
                 }
             }
@@ -1468,7 +1492,7 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
                      int H2, unsigned *range_bad)
 {
-    hipLaunchKernelGGL(k_pyr_base, dim3((W + BTX - 1) / BTX, (H + BTY - 1) / BTY), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
+    hipLaunchKernelGGL(k_pyr_base<0>, dim3((W + BTX - 1) / BTX, (H + BTY - 1) / BTY), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
                        H2, range_bad);
 }
 
