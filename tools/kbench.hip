@@ -90,6 +90,18 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(st));
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 10) {  // strip heights of the marching K-cost on a mid level: kbench W H reps 10
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        for (int round = 0; round < 2; round++) {
+            timeit("k_cost_split", [&]() { launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1); });
+            for (int rows : {0, 8, 10, 12, 14, 16, 18, 20, 24, 28, 32, 40, 48, 64}) {
+                char nm[64]; snprintf(nm, sizeof nm, "k_cost_march rows=%d", rows);
+                timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, 1, rows, rb); });
+            }
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 9) {  // pyramid base: whole kernel against its level-0 part alone (no level-1 / level-2 sites): kbench W H reps 9
         uint8_t *rgb; CK(hipMalloc(&rgb, 3 * n)); CK(hipMemset(rgb, 77, 3 * n));
         const int W1 = (int)(W / 1.41421356), H1 = (int)(H / 1.41421356), W2 = W / 2, H2 = H / 2;

@@ -485,14 +485,26 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
-    // strip height: as tall as possible (6 halo rows are recomputed per strip) while the grid still fills the wave slots
-    // the register allocation allows (256 CUs x 4 SIMDs x waves/SIMD)
-    const int slots = 256 * 4 * MARCH_WAVES(NP);
+    // strip height.  Every strip is resident at once when there are at most 1024 x w of them (256 CUs x 4 SIMDs, w waves per SIMD,
+    // w <= what the register allocation allows); a launch then lasts as long as one strip: (rows + halo and prologue) row steps, and
+    // a step takes longer the more waves share the SIMD.  Measured (tools/kbench mode 10, 0.5-8 Mpx): 1.57 us per step and 4.3
+    // extra steps at one wave per SIMD, 1.83 us and 7.3 at two, 2.6 us and 6.5 at three.  Take the shortest strips that fit for
+    // each w and keep the w that finishes first: large levels end up at the full occupancy with tall strips (6 halo rows recomputed
+    // per strip matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
     int Hs = rows;
     if (Hs <= 0) {
-        const int sy = (slots / strips_x) > 0 ? (slots / strips_x) : 1;
-        Hs = (H + sy - 1) / sy;
-        if (Hs < 16) Hs = 16;
+        static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
+        float best = 0.0f;
+        for (int w = 1; w <= MARCH_WAVES(NP); w++) {
+            const int sy = (256 * 4 * w / strips_x) > 0 ? (256 * 4 * w / strips_x) : 1;  // strips per column of strips that still fit
+            int h = (H + sy - 1) / sy;
+            if (h < 6) h = 6;
+            const float t = t_step[w - 1] * ((float)h + extra[w - 1]);
+            if (w == 1 || t < best) {
+                best = t;
+                Hs = h;
+            }
+        }
     }
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
