@@ -325,6 +325,11 @@ def main():
                 "traffic": traffic, "kernel": dom["name"], "launches_per_pair": dom["launches_per_pair"], "avg_launch_us": dom["avg_us"],
                 "algorithmic_bytes_per_launch_avg": BYTES_PER_PIXEL_ITER * e["pixel_launches"] / e["launches"],
                 "level0": dom.get("level0"),
+                # the same figure level by level (level 0 = the full frame; each next level has half the pixels): the average above
+                # weights every launch equally, and the coarser levels' launches last as long as one strip, not as long as their bytes
+                "per_level": [{"level": lv, "launches_per_pair": st["launches"] / n_pairs, "avg_us": 1e3 * st["total_ms"] / st["launches"],
+                               "frac": BYTES_PER_PIXEL_ITER * st["pixel_launches"] / (st["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                              for lv, st in sorted(e["levels"].items()) if st["launches"]],
                 "traffic_source": (f"profiles/pmc_traffic.json ({prof.get('_tag', '?')}: PMC passes of tools/profile_round.sh, not measured in this run)"
                                    if traffic is not None else None),
                 "note": "algorithmic bytes (48 B per pixel-iteration x pixels of the launch) / HIP-event duration on the launching stream, "

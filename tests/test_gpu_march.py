@@ -259,7 +259,7 @@ def test_march_exact_invariances_at_full_level_size(lib):
     pr = np.ascontiguousarray(R.transpose(2, 0, 1)).astype(np.float32)
     rng = np.random.Generator(np.random.PCG64(93))
     d0 = np.stack([dx + rng.normal(0, 0.3, dx.shape), dy + rng.normal(0, 0.3, dy.shape), 0.3 + 0.6 * rng.random(dx.shape)]).astype(np.float32)
-    with lib.Context(levels=1) as c:  # default threshold: 2.1 Mpx >= 0.9 Mpx -> marching cost kernel
+    with lib.Context(levels=1) as c:  # default threshold (0.2-0.4 Mpx) -> marching cost kernel
         base = iterate(c, pl, pr, d0, 6, 5, False, 1, 2)
         for k in (2.0, 0.5):
             got = iterate(c, pl * np.float32(k), pr * np.float32(k), d0, 6, 5, False, 1, 2)

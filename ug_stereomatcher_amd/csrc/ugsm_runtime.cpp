@@ -343,11 +343,14 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
 
 // K-cost / K-smooth as the marching kernels (ugsm_kernels_march.hip) or the LDS-tiled ones: a strip of a marching kernel is one wave
 // working down >= 16 rows, so a level must be large enough to fill the chip with strips.
-constexpr int kMarchDefaultMinPixels = 900000;
+// Default threshold (tools/sweep of UGSM_MARCH_MIN_PIXELS, 16 MP pairs): with several pairs in flight the marching kernel pays down
+// to the 0.25 Mpx level (it does less work per pixel than the tiles with their halos: 159.9 against 157.3 pairs/s); a pair alone on the
+// chip is a little faster with the LDS-tiled kernel there (106.4 against 105.4 pairs/s), so a one-slot context stops at 0.5 Mpx.
+constexpr int kMarchDefaultMinPixels = 200000, kMarchDefaultMinPixelsOneSlot = 400000;
 bool use_march(const ugsm_config &cfg, int W, int H)
 {
     if (cfg.march_min_pixels < 0) return false;
-    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchDefaultMinPixels;
+    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (cfg.slots > 1 ? kMarchDefaultMinPixels : kMarchDefaultMinPixelsOneSlot);
     return (long long)W * H >= thr;
 }
 
