@@ -17,7 +17,7 @@ out = os.path.join(ROOT, "profiles")
 shutil.copy(glob.glob(base + "/trace/**/*kernel_stats.csv", recursive=True)[0], f"{out}/{tag}_kernel_stats.csv")
 for f in ("bench_default.json", "bench_under_rocprof.json"):
     shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
-for f in ("kbench_16mp.txt", "kbench_smooth_16mp.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json",
+for f in ("kbench_16mp.txt", "kbench_smooth_16mp.txt", "kbench_small.txt", "kbench_aux_16mp.txt", "kbench_strips.txt", "level_breakdown.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json",
           "bench_fovea16mp.json"):
     if os.path.exists(f"{base}/{f}"):
         shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
@@ -98,7 +98,7 @@ try:
 except Exception as ex:  # a pass without the counter
     clock = {"error": str(ex)}
 json.dump({"_tag": tag, "full16mp": traffic, "clock_GHz_level0": clock, "valu_insts_per_simd_cycle_level0": valu_busy, "valu_insts_level0": valu_insts,
-           "_note": "HBM bytes per launch (mean over the 218 launches of a 16 MP pair) of the dominant kernel: exact read bytes from "
+           "_note": "HBM bytes per launch (mean over the launches of a 16 MP pair) of each hot kernel: exact read bytes from "
                     f"the size-binned TCC_EA0_RDREQ counters + WRITE_SIZE; see profiles/{tag}_hbm_traffic.md.  valu_insts_level0: "
                     "SQ_INSTS_VALU of the largest grid of each kernel (the level-0 launch), mean per dispatch"},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)

@@ -17,7 +17,8 @@ python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_f
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
-pmc() { name=$1; shift; timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
+# (UGSM_MARCH_MIN_PIXELS: a one-slot context would otherwise stop the marching kernel one level earlier than the 4-slot bench line does)
+pmc() { name=$1; shift; UGSM_MARCH_MIN_PIXELS=200000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 pmc pmc_write WRITE_SIZE
 pmc pmc_fetch FETCH_SIZE
@@ -27,6 +28,10 @@ pmc pmc_sq3 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ
 cd $R
 timeout -k 10 200 ./tools/kbench 4928 3264 10 2 > $O/kbench_16mp.txt 2>&1; step "kbench (marching vs tiled K-cost)"
 timeout -k 10 200 ./tools/kbench 4928 3264 10 5 > $O/kbench_smooth_16mp.txt 2>&1; step "kbench (marching vs tiled K-smooth)"
+{ for sz in "54 36" "154 102" "436 289" "616 408"; do timeout -k 10 100 ./tools/kbench $sz 200 7 | grep -v "P=[0-4]"; done; } > $O/kbench_small.txt 2>&1; step "kbench (latency kernels of the coarse levels)"
+timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; step "kbench (pyramid base ablations, blur+decimate, seed, sqblur)"
+{ for sz in "2464 1632" "1742 1154" "1232 816" "871 577"; do timeout -k 10 100 ./tools/kbench $sz 50 10; done; } > $O/kbench_strips.txt 2>&1; step "kbench (strip heights of the marching K-cost)"
+timeout -k 10 100 python tools/level_breakdown.py > $O/level_breakdown.txt 2>&1; step "per-level breakdown of one pair"
 timeout -k 10 100 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
 ls $O
