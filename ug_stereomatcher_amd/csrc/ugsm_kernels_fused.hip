@@ -1244,12 +1244,14 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
 constexpr int PTX = 64, PTY = 16, PRW = 2 * PTX + 8, PRH = 2 * PTY + 6;
 
 __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3,
-                                                             int W2, int H2, float sf, unsigned *__restrict__ range_bad)
+                                                             int W2, int H2, float sf, unsigned *__restrict__ range_bad, int tiles_x, int n_tiles)
 {
     __shared__ float sS[PRH * PRW];
     __shared__ float sT[PRH * PTX];
     const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * PTX, oy0 = blockIdx.y * PTY;
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);  // (grid: n_tiles x 1 x 3 planes; the plane only rotates the XCD labels)
+    const int ox0 = tile_x * PTX, oy0 = tile_y * PTY;
     const float *src = src3 + (size_t)blockIdx.z * W * H;
     // parent region covered by this tile of outputs (sampling sites are monotone in ix / iy)
     const int ox1 = min(ox0 + PTX, W2) - 1, oy1 = min(oy0 + PTY, H2) - 1;
@@ -1305,43 +1307,70 @@ __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__rest
 
 // A = colconv_clamp(rowconv_clamp(L^2)) (Square + convolutionRows/ColumnsKernelT, MatchLib.cu:556-578,
 // 1461-1565), once per level: it does not depend on the iteration.  64x16 tile, region +2 clamped.
-__global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3)
+__global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3, int tiles_x, int n_tiles)
 {
-    constexpr int RW = PTX + 4, RH = PTY + 4;
-    __shared__ float sS[RH * RW];
-    __shared__ float sT[RH * PTX];
+    // One workgroup = the 64x16 tile of all three planes: a workgroup of this kernel lives about as long as its global loads
+    // take to arrive, so the three planes' loads are in flight together (a third of the workgroups, each with three times the
+    // loads outstanding).  Both passes work on quads (4 consecutive x) through 16-byte LDS accesses.  Squares are >= +0 (or NaN):
+    // tap5p = tap5.
+    constexpr int RW = PTX + 8, RH = PTY + 4;  // region columns 0 .. PTX+3 used; rows 16-byte aligned
+    __shared__ __attribute__((aligned(16))) float sS[3][RH * RW];
+    __shared__ __attribute__((aligned(16))) float sT[3][RH * PTX];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PTX, y0 = blockIdx.y * PTY;
-    const float *s = src.p + (size_t)blockIdx.z * src.plane;
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);  // neighbouring tiles share an XCD's L2: their halo lines are fetched from HBM once
+    const int x0 = tile_x * PTX, y0 = tile_y * PTY;
     {
-        constexpr int NLD = (RH * RW + 255) / 256;
-        float v[NLD];
+        constexpr int LW = PTX + 4;
+        constexpr int NLD = (RH * LW + 255) / 256;
+        float v[NLD][3];
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
-            const int it = min(tid + u * 256, RH * RW - 1);
-            const int r = it / RW, c = it - r * RW;
-            v[u] = s[(size_t)clampi(y0 + r - 2, 0, H - 1) * src.pitch + clampi(x0 + c - 2, 0, W - 1)];
+            const int it = min(tid + u * 256, RH * LW - 1);
+            const int r = it / LW, c = it - r * LW;
+            const size_t at = (size_t)clampi(y0 + r - 2, 0, H - 1) * src.pitch + clampi(x0 + c - 2, 0, W - 1);
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[u][k] = src.p[k * src.plane + at];
         }
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
             const int it = tid + u * 256;
-            if (it < RH * RW) sS[it] = v[u] * v[u];
+            if (it < RH * LW) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) sS[k][(it / LW) * RW + (it % LW)] = v[u][k] * v[u][k];
+            }
         }
     }
     __syncthreads();
-    const int lx = tid & (PTX - 1);
-    for (int r = tid / PTX; r < RH; r += 256 / PTX) {
-        const float *p = &sS[r * RW + lx];
-        sT[r * PTX + lx] = tap5(p[0], p[1], p[2], p[3], p[4]);
+    for (int it = tid; it < 3 * RH * (PTX / 4); it += 256) {  // rows: tile columns 4q .. 4q+3 from region columns 4q .. 4q+7
+        const int k = it / (RH * (PTX / 4)), rem = it - k * (RH * (PTX / 4));
+        const int r = rem / (PTX / 4), q = rem - r * (PTX / 4);
+        float p[8], o[4];
+        ld4(&sS[k][r * RW + 4 * q], p);
+        ld4(&sS[k][r * RW + 4 * q + 4], p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = tap5p(p[i], p[i + 1], p[i + 2], p[i + 3], p[i + 4]);
+        st4(&sT[k][r * PTX + 4 * q], o);
     }
     __syncthreads();
-    const int gx = x0 + lx;
-    if (gx < W) {
-        for (int ly = tid / PTX; ly < PTY; ly += 256 / PTX) {
-            const int gy = y0 + ly;
-            if (gy < H) {
-                const float *p = &sT[ly * PTX + lx];
-                dst3[(size_t)blockIdx.z * W * H + (size_t)gy * W + gx] = tap5(p[0], p[PTX], p[2 * PTX], p[3 * PTX], p[4 * PTX]);
+    {   // columns: one quad of one tile row per thread and plane
+        const int ly = tid / (PTX / 4), q = tid - ly * (PTX / 4);
+        const int gx = x0 + 4 * q, gy = y0 + ly;
+        if (gx < W && gy < H) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float a[4], b[4], c[4], d[4], e[4], o[4];
+                const float *p = &sT[k][ly * PTX + 4 * q];
+                ld4(p, a); ld4(p + PTX, b); ld4(p + 2 * PTX, c); ld4(p + 3 * PTX, d); ld4(p + 4 * PTX, e);
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = tap5p(a[i], b[i], c[i], d[i], e[i]);
+                float *const dst = dst3 + (size_t)k * W * H + (size_t)gy * W + gx;
+                if ((W & 3) == 0) {  // (then gx + 3 < W and the row segment is 16-byte aligned)
+                    *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+                    for (int i = 0; i < 4; i++)
+                        if (gx + i < W) dst[i] = o[i];
+                }
             }
         }
     }
@@ -1368,13 +1397,15 @@ constexpr int BTX = 64, BTY = 16, BRW = BTX + 8, BRH = BTY + 4, BC1 = 52, BR1 = 
 template <int ABL = 0>
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
                                                   float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
-                                                  unsigned *__restrict__ range_bad)
+                                                  unsigned *__restrict__ range_bad, int tiles_x, int n_tiles)
 {
     __shared__ __attribute__((aligned(16))) float sS[3][BRH * BRW];  // tile + halo 2: region column c at [c], rows 16-byte aligned
     __shared__ __attribute__((aligned(16))) float sT[3][BRH * BTX];  // row pass of every tile column, every region row
     __shared__ int sRowSite[BR1 + BR2];  // region row of the sampling site of candidate row ly (level 1, then level 2), -1 = not in this tile
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BTX, y0 = blockIdx.y * BTY;
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);  // neighbouring tiles share an XCD's L2 (halo lines, partially written output lines)
+    const int x0 = tile_x * BTX, y0 = tile_y * BTY;
     const float sf1 = (float)1.41421356, sf2 = 2.0f;
     {   // rgb8 -> float planes of tile + halo 2, zero outside the image (the blur's zero padding, U2/U3)
         constexpr int RW = BTX + 4;
@@ -1492,8 +1523,8 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
                      int H2, unsigned *range_bad)
 {
-    hipLaunchKernelGGL(k_pyr_base<0>, dim3((W + BTX - 1) / BTX, (H + BTY - 1) / BTY), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
-                       H2, range_bad);
+    const int tiles_x = (W + BTX - 1) / BTX, n_tiles = tiles_x * ((H + BTY - 1) / BTY);
+    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles);
 }
 
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad)
@@ -1503,14 +1534,14 @@ void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float
         if (range_bad) launch_range_scan(st, dst3, 3 * (size_t)W2 * H2, range_bad);
         return;
     }
-    dim3 grid((W2 + PTX - 1) / PTX, (H2 + PTY - 1) / PTY, 3);
-    hipLaunchKernelGGL(k_blur_decimate_tiled, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad);
+    const int tiles_x = (W2 + PTX - 1) / PTX, n_tiles = tiles_x * ((H2 + PTY - 1) / PTY);
+    hipLaunchKernelGGL(k_blur_decimate_tiled, dim3(n_tiles, 1, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles);
 }
 
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3)
 {
-    dim3 grid((W + PTX - 1) / PTX, (H + PTY - 1) / PTY, 3);
-    hipLaunchKernelGGL(k_sqblur_tiled, grid, dim3(256), 0, st, src, W, H, dst3);
+    const int tiles_x = (W + PTX - 1) / PTX, n_tiles = tiles_x * ((H + PTY - 1) / PTY);
+    hipLaunchKernelGGL(k_sqblur_tiled, dim3(n_tiles), dim3(256), 0, st, src, W, H, dst3, tiles_x, n_tiles);
 }
 
 }  // namespace ugsm
