@@ -962,6 +962,20 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                 }
             }
         }
+        if ((W & 3) == 0) {  // rows are 16-byte aligned: the quads leave as they are (a wave's lanes hold consecutive quads of a row)
+#pragma unroll
+            for (int u = 0; u < CMAXR; u++) {
+                const int r = HY + brg + u * BRG;
+                const int gx = tx0 + bq * 4, gy = y0 + r;
+                if (brg < BRG && r < HY + STY && gx < W && gy < H) {
+                    const size_t at = (size_t)gy * W + gx;
+#pragma unroll
+                    for (int f = 0; f < 3; f++)
+                        *reinterpret_cast<float4 *>(o3 + f * n + at) = make_float4(cv[u][f][0], cv[u][f][1], cv[u][f][2], cv[u][f][3]);
+                }
+            }
+            return;
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
