@@ -1237,8 +1237,8 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
-    // big levels: 112x36 tiles, 512 threads, 79 KB LDS -> two workgroups per CU, so one's load/store phase overlaps
-    // the other's passes.  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
+    // big levels: 112x36 tiles, 512 threads, 79 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
+    // the other's passes; measured, the two phases still nearly add up: DESIGN.md section 4).  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
     // columns every pass recomputes are 12.5 % of the row instead of 20 % (at 16 MP: 5 passes 227 us against 266 us for
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills

@@ -2,12 +2,13 @@
 //
 // Below ~0.2 Mpx a level has fewer tiles than the chip has CUs and one matcher iteration is two DEPENDENT launches whose
 // duration is the critical path of a single tile (tools/level_breakdown.py: k_cost_split 14 us, k_smooth_fused 11 us per launch
-// from 54 x 36 up to 436 x 289, 22 iterations per level, 7 such levels = 4 of the 11 ms a pair takes when it is alone on the GPU).
+// from 54 x 36 up to 436 x 289, 22 iterations per level, 7 such levels = 4 of the 11 ms a pair took when it was alone on the GPU).
 // These kernels do the same arithmetic -- same helpers, same operation order, bit for bit (tests/test_gpu_small.py) -- with the
 // tile's chain cut short instead of its instruction count:
 //   k_cost_small   the three colour channels of a tile run side by side in three thread groups (own LDS images each) instead of
 //                  three barrier-separated rounds; tile 16 x 12; the global loads go straight to LDS.
-//   k_smooth_small one thread per pixel, double-buffered fields (one barrier per Jacobi pass instead of two), tile 16 x 16.
+//   k_smooth_small one thread per pixel of tile + halo 7, double-buffered fields (one barrier per Jacobi pass instead of two),
+//                  tile 18 x 4, 18 x 10 or 18 x 18.
 // Citations: /root/reference/src/gpu_matcher/<file>:<line>, as in ugsm_kernels_fused.hip.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
@@ -486,6 +487,10 @@ static void launch_smooth_small_t(hipStream_t st, const float *s3, float *o3, in
 
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh)
 {
+    if (passes < 0 || passes > 5) {  // the halo of 7 covers five passes + the box (callers split longer runs, enqueue_smooth)
+        launch_smooth_fused(st, s3, o3, W, H, passes, do_box);
+        return;
+    }
     if (rh == 18) launch_smooth_small_t<18>(st, s3, o3, W, H, passes, do_box);
     else if (rh == 24) launch_smooth_small_t<24>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_small_t<32>(st, s3, o3, W, H, passes, do_box);
