@@ -70,6 +70,8 @@ __device__ long long *g_stamps = nullptr;  // per wave: delta s_memtime, delta s
 
 #define B_ADDDPP(i) asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
 #define B_MULDPP(i) asm volatile("v_mul_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+#define B_ADDDPPROW(i) asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+#define B_ADDDPPQUAD(i) asm volatile("v_add_f32_dpp %0, %1, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
 #define B_MULLIT(i) asm volatile("v_mul_f32 %0, 0x3e779fea, %0" : "+v"(a[i]));
 #define B_FMA3(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
 #define B_FMAC(i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -87,6 +89,8 @@ KERNEL(k_add_lshl_u32, DECLF, B_IADDLSHL, a[0] + a[1] + a[2] + a[3] + a[4] + a[5
 KERNEL(k_med3_i32, DECLF, B_IMED3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_add_dpp, DECLF, B_ADDDPP, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_mul_dpp, DECLF, B_MULDPP, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_add_dpp_row, DECLF, B_ADDDPPROW, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
+KERNEL(k_add_dpp_quad, DECLF, B_ADDDPPQUAD, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_mul_literal, DECLF, B_MULLIT, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_fma_3src, DECLF, B_FMA3, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
 KERNEL(k_fmac, DECLF, B_FMAC, a[0] + a[1] + a[2] + a[3] + a[4] + a[5] + a[6] + a[7])
@@ -195,7 +199,7 @@ int main()
         printf("%-16s %-12d %-22.2f %-12.2f (%.2f)\n", name, wg_per_cu, cyc[nw / 2], clk[nw / 2], nom);
     };
 #define RUN(k) run(#k, k, 1); run(#k, k, 2); run(#k, k, 3); run(#k, k, 4);
-    RUN(k_fma) RUN(k_fma_3src) RUN(k_fmac) RUN(k_mul) RUN(k_mul_literal) RUN(k_add) RUN(k_add_dpp) RUN(k_mul_dpp) RUN(k_dpp) RUN(k_mov) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma)
+    RUN(k_fma) RUN(k_fma_3src) RUN(k_fmac) RUN(k_mul) RUN(k_mul_literal) RUN(k_add) RUN(k_add_dpp) RUN(k_add_dpp_row) RUN(k_add_dpp_quad) RUN(k_mul_dpp) RUN(k_dpp) RUN(k_mov) RUN(k_pkmul) RUN(k_pkadd) RUN(k_pkfma)
     RUN(k_rcp) RUN(k_dscale) RUN(k_dfmas) RUN(k_dfix) RUN(k_minimum3) RUN(k_min3) RUN(k_cmp_cnd_vcc) RUN(k_cmp_cnd_sgpr) RUN(k_cnd64) RUN(k_max) RUN(k_med3)
     RUN(k_cmp_vcc) RUN(k_cmp_sgpr) RUN(k_floor) RUN(k_cvt_i32) RUN(k_add_u32) RUN(k_mad_u32_u24) RUN(k_lshlrev_b32) RUN(k_add_lshl_u32) RUN(k_med3_i32)
     RUN(k_fma64) RUN(k_mul64) RUN(k_add64) RUN(k_rcp64) RUN(k_cvt_f64_f32) RUN(k_cvt_f32_f64)
