@@ -161,3 +161,35 @@ def c_match_fov(c, L, R):
     c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p), W, H, W * 3, 0, 0,
                                       out[0].ctypes.data_as(C.c_void_p), out[1].ctypes.data_as(C.c_void_p), out[2].ctypes.data_as(C.c_void_p), None, None))
     return out
+
+
+def test_random_sizes_production_path_against_the_one_kernel_per_stage_path(lib):
+    """Which kernel runs a level depends on the level's size and on the slot count (marching from 0.2 / 0.4 Mpx, latency kernels up to
+    0.15 Mpx, seeding fused where the next level marches, strip heights from a model): random image sizes, pyramid depths, slot counts
+    and fovea offsets, production path against kernel_path 1, full and foveated mode (tools/stress_pipeline.py runs hundreds)."""
+    import ctypes as C
+    from ug_stereomatcher_amd import synth
+    rng = np.random.Generator(np.random.PCG64(507))
+    for case in range(10):
+        W, H = (int(rng.integers(900, 1800)), int(rng.integers(600, 1100))) if case % 5 == 4 else (int(rng.integers(48, 800)), int(rng.integers(40, 600)))
+        max_levels, w, h = 1, W, H
+        while max_levels < 14 and int(w / 1.41421356) >= 8 and int(h / 1.41421356) >= 8:
+            w, h, max_levels = int(w / 1.41421356), int(h / 1.41421356), max_levels + 1
+        levels = int(rng.integers(2, max_levels + 1))
+        F = int(rng.integers(2, levels + 1))
+        off = (int(rng.integers(-W // 8, W // 8 + 1)), int(rng.integers(-H // 8, H // 8 + 1)))
+        slots = int(rng.choice([1, 2, 4]))
+        L, R, _, _ = synth.make_pair(W, H, 5500 + case)
+        out = []
+        for path, sl in ((0, slots), (1, 1)):
+            with lib.Context(levels=levels, fovea_levels=F, slots=sl, kernel_path=path) as c:
+                full = np.empty((3, H, W), np.float32)
+                c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, W * 3, full[0].ctypes.data, full[1].ctypes.data, full[2].ctypes.data))
+                fw, fh = C.c_int(), C.c_int()
+                c.check(c.lib.ugsm_fovea_dims(W, H, levels, F, C.byref(fw), C.byref(fh)))
+                st = np.empty((3, F, fh.value, fw.value), np.float32)
+                c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data, R.ctypes.data, W, H, W * 3, off[0], off[1], st[0].ctypes.data,
+                                                  st[1].ctypes.data, st[2].ctypes.data, None, None))
+                out.append((full, st))
+        assert_bit_equal(out[0][0], out[1][0], f"full {W}x{H} levels={levels} slots={slots}")
+        assert_bit_equal(out[0][1], out[1][1], f"foveated {W}x{H} levels={levels} F={F} off={off} slots={slots}")
