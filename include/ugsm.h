@@ -97,6 +97,16 @@ int ugsm_fovea_dims(int W, int H, int levels, int fovea_levels, int *fovW, int *
 /* Sum over levels of iterations x pixels; fovea_levels==0 => full-resolution mode */
 long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
 
+/* Which kernels a W x H level runs under `cfg` (NULL = defaults), for maintainers and the host tests; results never depend on it.
+ * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_cost_split / k_smooth_fused), 1 = marching (k_cost_march / k_smooth_march),
+ * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1);
+ * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
+ * seed_fused: 1 if the level's seeding rides on its first K-cost launch. */
+typedef struct ugsm_level_plan {
+    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, reserved[3];
+} ugsm_level_plan;
+int ugsm_plan_level(const ugsm_config *cfg, int W, int H, ugsm_level_plan *out);
+
 /* ---- the service path: host buffers in, host buffers out ------------------------ */
 
 /* MatchGPULib::match(L, R, 0), MatchGPULib.cpp:303-403, as used by

@@ -1,0 +1,52 @@
+"""Host-only checks of the per-level kernel choice (ugsm_plan_level: the same policy functions the launch path calls; no GPU needed).
+Which kernel runs a level never changes a result (the GPU suite proves that); these tests pin the policy itself."""
+import pytest
+
+from ug_stereomatcher_amd import _lib
+
+TILED, MARCH, SMALL, STAGED = 0, 1, 2, 3
+
+
+def levels_16mp():
+    w, h = _lib.level_dims(4928, 3264, 14)
+    return list(zip(w, h))
+
+
+def test_default_plan_of_a_16mp_pyramid_with_several_pairs_in_flight():
+    plans = [_lib.plan_level(w, h, slots=4) for (w, h) in levels_16mp()]
+    # levels 0-6 (>= 0.2 Mpx) march and carry their own seeding; levels 7-13 (<= 0.15 Mpx) run the latency kernels on 18 x 18 tiles
+    assert [p["cost_kernel"] for p in plans] == [MARCH] * 7 + [SMALL] * 7
+    assert [p["smooth_kernel"] for p in plans] == [TILED] * 7 + [SMALL] * 7
+    assert [p["seed_fused"] for p in plans] == [1] * 7 + [0] * 7
+    assert all(p["smooth_rh"] == 32 for p in plans[7:]) and all(p["smooth_rh"] == 0 for p in plans[:7])
+    rows = [p["strip_rows"] for p in plans[:7]]
+    assert rows[0] == 91 and all(6 <= r <= 100 for r in rows) and all(p["strip_rows"] == 0 for p in plans[7:])
+
+
+def test_one_slot_context_is_tuned_for_a_pair_alone():
+    plans = [_lib.plan_level(w, h, slots=1) for (w, h) in levels_16mp()]
+    assert [p["cost_kernel"] for p in plans] == [MARCH] * 6 + [TILED] + [SMALL] * 7   # marching stops at 0.4 Mpx; level 6 is tiled
+    assert [p["smooth_rh"] for p in plans[7:]] == [32, 24, 18, 18, 18, 18, 18]           # the smallest tile that still fills the chip
+
+
+def test_switches():
+    assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
+    assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0)
+    assert _lib.plan_level(300, 200, small_max_pixels=-1)["cost_kernel"] == TILED
+    assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
+    assert _lib.plan_level(300, 200, march_min_pixels=1, march_rows=17)["strip_rows"] == 17
+    assert _lib.plan_level(4928, 3264, early_exit_threshold=0.1)["seed_fused"] == 0     # the field before the first iteration is needed
+    assert _lib.plan_level(4928, 3264, march_np=2)["seed_fused"] == 0
+    assert _lib.plan_level(4928, 3264, march_smooth=1)["smooth_kernel"] == MARCH
+    with pytest.raises(_lib.UgsmError):
+        _lib.plan_level(0, 10)
+
+
+def test_strip_rows_fill_the_chip_or_one_round():
+    """The strips of a marching level never need more than three waves per SIMD (3 072 strips of 58 columns), and small levels get
+    short strips (a launch lasts as long as one strip)."""
+    for (w, h) in levels_16mp()[:7] + [(1920, 1080), (615, 407), (871, 577)]:
+        rows = _lib.plan_level(w, h, slots=4, march_min_pixels=1)["strip_rows"]
+        strips = -(-w // 58) * -(-h // rows)
+        assert rows >= 6 and strips <= 3072 + (-(-w // 58)), (w, h, rows, strips)
+    assert _lib.plan_level(871, 577, march_min_pixels=1)["strip_rows"] <= 12

@@ -27,7 +27,7 @@ UGSM_MAX_LEVELS = 32
 EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
-    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_match_full",
+    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_match_full",
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
@@ -45,6 +45,11 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("levels", C.c_int), ("fovea_levels", C.c_int), ("slots", C.c_int),
                 ("kernel_path", C.c_int), ("profile_events", C.c_int), ("march_min_pixels", C.c_int), ("march_np", C.c_int),
                 ("march_rows", C.c_int), ("march_smooth", C.c_int), ("early_exit_threshold", C.c_float), ("small_max_pixels", C.c_int)]
+
+
+class LevelPlan(C.Structure):
+    _fields_ = [("cost_kernel", C.c_int), ("smooth_kernel", C.c_int), ("smooth_rh", C.c_int), ("strip_rows", C.c_int), ("seed_fused", C.c_int),
+                ("reserved", C.c_int * 3)]
 
 
 class KernelStat(C.Structure):
@@ -82,6 +87,7 @@ def load():
     lib.ugsm_fovea_dims.argtypes = [i, i, i, i, ip, ip]
     lib.ugsm_pixel_iterations.argtypes = [i, i, i, i]
     lib.ugsm_pixel_iterations.restype = C.c_longlong
+    lib.ugsm_plan_level.argtypes = [C.POINTER(Config), i, i, C.POINTER(LevelPlan)]
     lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_match_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
     lib.ugsm_match_foveated_full.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp]
@@ -282,6 +288,20 @@ class Context:
 
     def reset_kernel_stats(self):
         self.check(self.lib.ugsm_reset_kernel_stats(self._h))
+
+
+def plan_level(W: int, H: int, **cfg_fields):
+    """Which kernels a W x H level runs (host only): dict of ugsm_level_plan; cfg_fields override the default ugsm_config."""
+    lib = load()
+    cfg = Config()
+    lib.ugsm_default_config(C.byref(cfg))
+    for k, v in cfg_fields.items():
+        setattr(cfg, k, v)
+    out = LevelPlan()
+    st = lib.ugsm_plan_level(C.byref(cfg), W, H, C.byref(out))
+    if st != 0:
+        raise UgsmError(st, "ugsm_plan_level")
+    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused")}
 
 
 def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):

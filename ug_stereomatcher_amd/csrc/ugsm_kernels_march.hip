@@ -479,33 +479,40 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 #endif
 }
 
+// Strip height of the marching K-cost.  Every strip is resident at once when there are at most 1024 x w of them (256 CUs x 4 SIMDs,
+// w waves per SIMD, w <= what the register allocation allows); a launch then lasts as long as one strip: (rows + halo and prologue)
+// row steps, and a step takes longer the more waves share the SIMD.  Measured (tools/kbench mode 10, 0.5-8 Mpx): 1.57 us per step and
+// 4.3 extra steps at one wave per SIMD, 1.83 us and 7.3 at two, 2.6 us and 6.5 at three.  Take the shortest strips that fit for each w
+// and keep the w that finishes first: large levels end up at the full occupancy with tall strips (6 halo rows recomputed per strip
+// matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
+int march_strip_rows(int W, int H, int np)
+{
+    const int vx = np == 2 ? March<2>::VX : March<1>::VX, org = np == 2 ? March<2>::ORG : March<1>::ORG;
+    const int strips_x = (W - org + vx - 1) / vx;
+    static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
+    const int max_w = np == 2 ? MARCH_WAVES(2) : MARCH_WAVES(1);
+    float best = 0.0f;
+    int Hs = 6;
+    for (int w = 1; w <= max_w && w <= 3; w++) {
+        const int sy = (256 * 4 * w / strips_x) > 0 ? (256 * 4 * w / strips_x) : 1;  // strips per column of strips that still fit
+        int h = (H + sy - 1) / sy;
+        if (h < 6) h = 6;
+        const float t = t_step[w - 1] * ((float)h + extra[w - 1]);
+        if (w == 1 || t < best) {
+            best = t;
+            Hs = h;
+        }
+    }
+    return Hs;
+}
+
 template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
                                 int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0})
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
-    // strip height.  Every strip is resident at once when there are at most 1024 x w of them (256 CUs x 4 SIMDs, w waves per SIMD,
-    // w <= what the register allocation allows); a launch then lasts as long as one strip: (rows + halo and prologue) row steps, and
-    // a step takes longer the more waves share the SIMD.  Measured (tools/kbench mode 10, 0.5-8 Mpx): 1.57 us per step and 4.3
-    // extra steps at one wave per SIMD, 1.83 us and 7.3 at two, 2.6 us and 6.5 at three.  Take the shortest strips that fit for
-    // each w and keep the w that finishes first: large levels end up at the full occupancy with tall strips (6 halo rows recomputed
-    // per strip matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
-    int Hs = rows;
-    if (Hs <= 0) {
-        static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
-        float best = 0.0f;
-        for (int w = 1; w <= MARCH_WAVES(NP); w++) {
-            const int sy = (256 * 4 * w / strips_x) > 0 ? (256 * 4 * w / strips_x) : 1;  // strips per column of strips that still fit
-            int h = (H + sy - 1) / sy;
-            if (h < 6) h = 6;
-            const float t = t_step[w - 1] * ((float)h + extra[w - 1]);
-            if (w == 1 || t < best) {
-                best = t;
-                Hs = h;
-            }
-        }
-    }
+    const int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP);
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
     const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;

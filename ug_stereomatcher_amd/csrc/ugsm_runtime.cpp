@@ -862,6 +862,27 @@ int ugsm_level_dims(int W, int H, int levels, int *w, int *h)
 }
 int ugsm_level_iterations(int level) { return level < 0 ? 0 : level_iterations(level); }
 int ugsm_level_smooth_passes(int level) { return level < 0 ? 0 : level_smooth(level); }
+
+int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *out)
+{
+    if (!out || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    ugsm_ctx probe;  // host-only: the same policy functions the launch path calls, on a context that owns no device state
+    if (cfg_in) probe.cfg = *cfg_in;
+    else ugsm_default_config(&probe.cfg);
+    memset(out, 0, sizeof *out);
+    if (probe.cfg.kernel_path == 1) {
+        out->cost_kernel = out->smooth_kernel = 3;
+        return UGSM_OK;
+    }
+    const bool march = use_march(probe.cfg, W, H);
+    const int rh = small_rh(&probe, W, H);
+    out->cost_kernel = march ? 1 : (rh ? 2 : 0);
+    out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : (rh ? 2 : 0);
+    out->smooth_rh = rh;
+    out->strip_rows = march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, probe.cfg.march_np == 2 ? 2 : 1)) : 0;
+    out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
+    return UGSM_OK;
+}
 int ugsm_threshold_schedule(int mi, float *out)
 {
     if (mi < 1 || !out) return UGSM_ERR_BAD_ARG;
