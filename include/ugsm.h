@@ -58,7 +58,8 @@ typedef struct ugsm_config {
     int profile_events; /* slot 0 brackets kernels with HIP events: 1 = the cost kernel only, 2 = every kernel class */
     int march_min_pixels; /* levels of at least this many pixels run K-cost as the marching kernel (one wave per strip of
                              columns, no LDS); 0 = default threshold, < 0 = never (the LDS-tiled kernel everywhere) */
-    int march_np;         /* tuning / tests: pixels per lane of the marching kernel (1 or 2; 0 = default) */
+    int march_np;         /* ignored since ABI 3 (kept for layout): the two-pixels-per-lane development form of the marching kernel
+                             is no longer in the library (tools/kbench.hip instantiates it) */
     int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
     int march_smooth;     /* 1: those levels also run K-smooth (five passes at a time) as a marching kernel; 0 (default): the
                              LDS-tiled K-smooth everywhere -- the marching form is bit-identical but no faster */

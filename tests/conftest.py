@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the kernel-choice overrides the tests use (UGSM_MARCH_MIN_PIXELS, UGSM_SMALL_RH, ...) are development switches: the library
+# reads them only under UGSM_DEV=1 (ugsm_runtime.cpp, apply_dev_env)
+os.environ["UGSM_DEV"] = "1"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

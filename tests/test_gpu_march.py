@@ -39,7 +39,7 @@ def planes(orc, W, H, seed):
     return pl, pr
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_march_one_iteration_sizes_and_strip_heights(lib, orc, np_lane):
     """One cost iteration (no smoothing: S = 0 passes still runs the box, so compare after the full stage) on sizes
     around the strip widths (58 / 122 columns), with strips shorter and taller than the image."""
@@ -54,7 +54,7 @@ def test_march_one_iteration_sizes_and_strip_heights(lib, orc, np_lane):
         assert_bit_equal(got, exp, f"{W}x{H} rows={rows} np={np_lane}")
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_march_large_disparities_top_level_and_zero_patches(lib, orc, np_lane):
     rng = np.random.Generator(np.random.PCG64(78))
     W, H = 200, 77
@@ -70,7 +70,7 @@ def test_march_large_disparities_top_level_and_zero_patches(lib, orc, np_lane):
             assert_bit_equal(got, exp, f"top={is_top} np={np_lane}")
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_march_wild_disparities(lib, orc, np_lane):
     """NaN, +-Inf, huge and denormal disparities go through the branch-free texture index exactly like tex_index
     (NaN -> 0, clamp otherwise)."""
@@ -96,8 +96,7 @@ def test_march_equals_tiled_end_to_end(lib, orc, monkeypatch):
     exp = orc.match_full(L, R, 8)
     monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
     monkeypatch.setenv("UGSM_MARCH_SMOOTH", "1")
-    for np_lane in (1, 2):
-        monkeypatch.setenv("UGSM_MARCH_NP", str(np_lane))
+    for np_lane in (1,):
         m = MatchGPULib(levels=8)
         got = m.match(L, R, 0)
         m.close()
@@ -151,7 +150,7 @@ def test_division_in_range_is_ieee(lib):
     assert_bit_equal(got, exp, "range-guarded division")
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_march_values_outside_the_division_range_take_the_full_division(lib, orc, np_lane):
     """A plane value outside range_ok (tiny, huge, negative) must switch the pair to the compiler's division; results
     stay bit-exact either way.  The in-range case of the same images exercises the guarded division."""
@@ -178,8 +177,7 @@ def test_march_on_fovea_views(lib, orc, monkeypatch):
     g = load_golden("fovea_320x240_l9_f4.npz")
     monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
     monkeypatch.setenv("UGSM_MARCH_SMOOTH", "1")
-    for np_lane in (1, 2):
-        monkeypatch.setenv("UGSM_MARCH_NP", str(np_lane))
+    for np_lane in (1,):
         m = MatchGPULib(3, ["node", "x", str(int(g["F"]))], levels=int(g["levels"]))
         st = m.matchStack(g["L"], g["R"])
         m.close()
@@ -208,7 +206,7 @@ def run_smooth(c, d, passes, box):
         c.free(p)
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_smooth_march_sizes_strip_seams_and_borders(lib, orc, np_lane):
     """Five passes (+ box), and ten as two launches, on sizes around the strip widths (50 / 54 columns for one pixel per lane,
     113 / 117 for two), with strips shorter and taller than the image, down to images narrower than a halo."""
@@ -223,7 +221,7 @@ def test_smooth_march_sizes_strip_seams_and_borders(lib, orc, np_lane):
                 assert_bit_equal(got, smooth_ref(orc, d, passes, box), f"{W}x{H} rows={rows} np={np_lane} passes={passes} box={box}")
 
 
-@pytest.mark.parametrize("np_lane", [1, 2])
+@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
 def test_smooth_march_degenerate_confidence(lib, orc, np_lane):
     """Confidence fields that push sumCorr out of the shared-reciprocal range (zero patches: 0/0 -> NaN spreading one pixel per
     pass; negative, 1e-30, 1e30 weights), also on the frame and across strip seams."""

@@ -36,7 +36,7 @@ def test_switches():
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
     assert _lib.plan_level(300, 200, march_min_pixels=1, march_rows=17)["strip_rows"] == 17
     assert _lib.plan_level(4928, 3264, early_exit_threshold=0.1)["seed_fused"] == 0     # the field before the first iteration is needed
-    assert _lib.plan_level(4928, 3264, march_np=2)["seed_fused"] == 0
+    assert _lib.plan_level(4928, 3264, march_np=2) == _lib.plan_level(4928, 3264)           # ignored since ABI 3 (development form, tools/kbench)
     assert _lib.plan_level(4928, 3264, march_smooth=1)["smooth_kernel"] == MARCH
     with pytest.raises(_lib.UgsmError):
         _lib.plan_level(0, 10)
@@ -50,3 +50,23 @@ def test_strip_rows_fill_the_chip_or_one_round():
         strips = -(-w // 58) * -(-h // rows)
         assert rows >= 6 and strips <= 3072 + (-(-w // 58)), (w, h, rows, strips)
     assert _lib.plan_level(871, 577, march_min_pixels=1)["strip_rows"] <= 12
+
+
+def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
+    """ugsm_plan_level applies the overrides ugsm_create applies: none without UGSM_DEV=1, all of them with it."""
+    base = _lib.plan_level(300, 200)
+    monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
+    monkeypatch.delenv("UGSM_DEV", raising=False)
+    assert _lib.plan_level(300, 200) == base                                    # a stray variable changes nothing in production
+    monkeypatch.setenv("UGSM_DEV", "1")
+    assert _lib.plan_level(300, 200)["cost_kernel"] == MARCH
+    monkeypatch.delenv("UGSM_MARCH_MIN_PIXELS")
+    monkeypatch.setenv("UGSM_SMALL_MASK", "1")
+    p = _lib.plan_level(300, 200)
+    assert p["cost_kernel"] == SMALL and p["smooth_kernel"] == TILED and p["smooth_rh"] == 0
+    monkeypatch.setenv("UGSM_SMALL_MASK", "3")
+    monkeypatch.setenv("UGSM_SMALL_RH", "24")
+    assert _lib.plan_level(300, 200)["smooth_rh"] == 24
+    monkeypatch.delenv("UGSM_SMALL_RH")
+    monkeypatch.setenv("UGSM_FUSE_SEED", "0")
+    assert _lib.plan_level(4928, 3264)["seed_fused"] == 0

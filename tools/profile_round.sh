@@ -4,6 +4,7 @@
 #   python profiles/make_summaries.py gpurun_out/prof_r02 r02
 # Counter passes are separate rocprofv3 runs with at most 8 counters each (--kernel-trace only beside --pmc), each
 # behind its own timeout; a line is printed after every step so that the call never looks hung.
+export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 set -u
 TAG=${1:-r02}
 R=$PWD

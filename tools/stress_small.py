@@ -5,6 +5,7 @@ against the separate k_seed launch, through whole full-mode and foveated matches
 to the oracle by tests/.  Development tool:  python tools/stress_small.py [cases]"""
 import ctypes as C
 import os
+os.environ["UGSM_DEV"] = "1"  # the kernel-choice overrides used below are development switches
 import sys
 
 import numpy as np

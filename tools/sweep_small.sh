@@ -1,5 +1,6 @@
 #!/bin/bash
 # 3-slot and 1-slot throughput with the latency kernels of the coarse levels on / off / one at a time
+export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 run() { echo -n "$1: "; env $2 python bench.py --no-events $3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1))"; }
 for rep in 1 2; do
 run "slots3 off      " UGSM_SMALL_MAX_PIXELS=-1 ""

@@ -487,6 +487,9 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 // matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
 int march_strip_rows(int W, int H, int np)
 {
+#ifndef UGSM_DEV_KERNELS
+    np = 1;
+#endif
     const int vx = np == 2 ? March<2>::VX : March<1>::VX, org = np == 2 ? March<2>::ORG : March<1>::ORG;
     const int strips_x = (W - org + vx - 1) / vx;
     static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
@@ -516,8 +519,14 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
     const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
-    if (fmad) hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
-    else hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+#ifdef UGSM_DEV_KERNELS
+    if (fmad) {
+        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+        return;
+    }
+#endif
+    (void)fmad;
+    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
 }
 
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
@@ -529,8 +538,17 @@ void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, c
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
                        int np, int rows, const unsigned *range_bad)
 {
-    if (np == 2) launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
-    else launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+    // The product library holds the one-pixel-per-lane, literal-contract kernel only.  The two development forms -- two pixels per
+    // lane (spills at any occupancy that pays) and FMA-contracted convolutions (no parity claim; slower) -- are instantiated by
+    // tools/kbench.hip, which defines UGSM_DEV_KERNELS; here `np` and `fmad` are ignored.
+#ifdef UGSM_DEV_KERNELS
+    if (np == 2) {
+        launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+        return;
+    }
+#endif
+    (void)np;
+    launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
 }
 
 // =========================================================================================
@@ -842,10 +860,15 @@ static void launch_smooth_march_t(hipStream_t st, const float *s3, float *o3, in
 // five passes (+ box) per launch; other pass counts belong to the LDS-tiled kernel (launch_smooth_fused)
 void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows)
 {
+#ifdef UGSM_DEV_KERNELS
     if (np == 2) {
         if (do_box) launch_smooth_march_t<2, 5, true>(st, s3, o3, W, H, rows);
         else launch_smooth_march_t<2, 5, false>(st, s3, o3, W, H, rows);
-    } else {
+        return;
+    }
+#endif
+    (void)np;
+    {
         if (do_box) launch_smooth_march_t<1, 5, true>(st, s3, o3, W, H, rows);
         else launch_smooth_march_t<1, 5, false>(st, s3, o3, W, H, rows);
     }

@@ -83,9 +83,7 @@ struct ugsm_ctx {
     std::vector<Slot> slots;
     std::string err;
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
-    int fuse_seed = 1;       // experiments (UGSM_FUSE_SEED=0): seed every level with its own launch
-    int small_mask = 3;      // experiments (UGSM_SMALL_MASK): bit 0 = k_cost_small, bit 1 = k_smooth_small
-    int small_rh_force = 0;  // tests (UGSM_SMALL_RH): region height of k_smooth_small whatever the level size
+    int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
 };
 
 namespace {
@@ -302,6 +300,40 @@ void harvest(ugsm_ctx *ctx, Slot &s)
     s.pending.clear();
 }
 
+// ---- development overrides ---------------------------------------------------------------
+// tools/ and tests/ steer the per-level kernel choice through environment variables.  They are read ONLY when UGSM_DEV=1 is set
+// as well, so that a production process never changes behaviour because of a stray variable, and in ONE place, shared by
+// ugsm_create and ugsm_plan_level (which therefore reports what a context created under the same environment launches).
+struct DevKnobs {
+    int fuse_seed = 1;       // UGSM_FUSE_SEED=0: seed every level with its own launch
+    int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
+    int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
+    int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
+};
+bool dev_env_on()
+{
+    const char *e = getenv("UGSM_DEV");
+    return e && e[0] == '1';
+}
+void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
+{
+    if (!dev_env_on()) return;
+    auto geti = [](const char *name, int &dst) {
+        if (const char *e = getenv(name)) dst = atoi(e);
+    };
+    geti("UGSM_KERNEL_PATH", cfg.kernel_path);
+    geti("UGSM_MARCH_MIN_PIXELS", cfg.march_min_pixels);
+    geti("UGSM_MARCH_ROWS", cfg.march_rows);
+    geti("UGSM_MARCH_SMOOTH", cfg.march_smooth);
+    geti("UGSM_SMALL_MAX_PIXELS", cfg.small_max_pixels);
+    geti("UGSM_SMALL_MASK", k.small_mask);
+    geti("UGSM_FUSE_SEED", k.fuse_seed);
+    geti("UGSM_COARSE_GRAPH", k.graph);
+    int rh = 0;
+    geti("UGSM_SMALL_RH", rh);
+    if (rh == 18 || rh == 24 || rh == 32) k.small_rh_force = rh;
+}
+
 // ---- stages ----------------------------------------------------------------------------
 
 int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int stride, float *pyr)
@@ -379,7 +411,7 @@ int small_rh(const ugsm_ctx *ctx, int W, int H)
 bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
 {
     const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && cfg.march_np != 2 && use_march(cfg, W, H);
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && use_march(cfg, W, H);
 }
 
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
@@ -411,7 +443,7 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             const bool box_now = do_box && left == 0;
             float *dst = (left == 0 && final_out) ? final_out : b;
             // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
-            if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, ctx->cfg.march_np, ctx->cfg.march_rows);
+            if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, 1, ctx->cfg.march_rows);
             else if (rh) launch_smooth_small(s.st, a, dst, W, H, p, box_now, rh);
             else launch_smooth_fused(s.st, a, dst, W, H, p, box_now);
             if (dst == final_out) a = final_out;
@@ -492,7 +524,7 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             Timer t(ctx, &s, si, march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST), px);
             if (march && seed && m == m_from)
                 launch_cost_march_seeded(s.st, L, R, s.A, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
-            else if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, ctx->cfg.march_np, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            else if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, 1, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else if (small) launch_cost_small(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
             else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
         }
@@ -793,12 +825,8 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ugsm_config cfg;
     if (cfg_in) cfg = *cfg_in;
     else ugsm_default_config(&cfg);
-    if (const char *e = getenv("UGSM_KERNEL_PATH")) cfg.kernel_path = atoi(e);  // A/B switches for debugging
-    if (const char *e = getenv("UGSM_MARCH_MIN_PIXELS")) cfg.march_min_pixels = atoi(e);
-    if (const char *e = getenv("UGSM_MARCH_NP")) cfg.march_np = atoi(e);
-    if (const char *e = getenv("UGSM_MARCH_ROWS")) cfg.march_rows = atoi(e);
-    if (const char *e = getenv("UGSM_MARCH_SMOOTH")) cfg.march_smooth = atoi(e);
-    if (const char *e = getenv("UGSM_SMALL_MAX_PIXELS")) cfg.small_max_pixels = atoi(e);
+    DevKnobs knobs;
+    apply_dev_env(cfg, knobs);  // (nothing unless UGSM_DEV=1)
     {   // the kernels carry the Gaussian taps as literals (ugsm_device.hpp); they must be the numbers the reference computes at
         // start-up: five float literals divided by their float sum (MatchGPULib.cpp:761-774)
         const float lit[5] = {0.0816475f, 0.218507f, 0.303281f, 0.218507f, 0.0816475f};
@@ -816,12 +844,9 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (hipSetDevice(cfg.device) != hipSuccess) return UGSM_ERR_NO_DEVICE;
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
-    if (const char *e = getenv("UGSM_SMALL_MASK")) ctx->small_mask = atoi(e);
-    if (const char *e = getenv("UGSM_FUSE_SEED")) ctx->fuse_seed = atoi(e);
-    if (const char *e = getenv("UGSM_SMALL_RH")) {
-        const int v = atoi(e);
-        if (v == 18 || v == 24 || v == 32) ctx->small_rh_force = v;
-    }
+    ctx->small_mask = knobs.small_mask;
+    ctx->fuse_seed = knobs.fuse_seed;
+    ctx->small_rh_force = knobs.small_rh_force;
     ctx->slots.resize(cfg.slots);
     for (Slot &s : ctx->slots) {
         if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&s.range_bad, 64) != hipSuccess) {
@@ -869,6 +894,13 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     ugsm_ctx probe;  // host-only: the same policy functions the launch path calls, on a context that owns no device state
     if (cfg_in) probe.cfg = *cfg_in;
     else ugsm_default_config(&probe.cfg);
+    {   // ... under the same development overrides ugsm_create would apply in this process (none unless UGSM_DEV=1)
+        DevKnobs knobs;
+        apply_dev_env(probe.cfg, knobs);
+        probe.small_mask = knobs.small_mask;
+        probe.fuse_seed = knobs.fuse_seed;
+        probe.small_rh_force = knobs.small_rh_force;
+    }
     memset(out, 0, sizeof *out);
     if (probe.cfg.kernel_path == 1) {
         out->cost_kernel = out->smooth_kernel = 3;
@@ -876,10 +908,10 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     }
     const bool march = use_march(probe.cfg, W, H);
     const int rh = small_rh(&probe, W, H);
-    out->cost_kernel = march ? 1 : (rh ? 2 : 0);
-    out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : (rh ? 2 : 0);
-    out->smooth_rh = rh;
-    out->strip_rows = march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, probe.cfg.march_np == 2 ? 2 : 1)) : 0;
+    out->cost_kernel = march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0);
+    out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
+    out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
+    out->strip_rows = march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1)) : 0;
     out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
     return UGSM_OK;
 }
@@ -1087,7 +1119,10 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
     float *cur = s->d0, *other = s->d1;
     HIPCHK(ctx, hipMemcpyAsync(cur, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     const size_t n = (size_t)W * H;
-    // the planes arrive ready-made: check their range here (the pyramid kernels do it for the matcher proper)
+    // the planes arrive ready-made: check their range here (the pyramid kernels do it for the matcher proper).  The slot's range
+    // word then describes THESE planes, no longer the slot's pyramids: a fovea phase submitted afterwards must rebuild them first
+    s->have_pyr = false;
+    s->have_coarse = false;
     s->range_known = ctx->cfg.kernel_path != 1;
     if (s->range_known) {
         HIPCHK(ctx, hipMemsetAsync(s->range_bad, 0, sizeof(unsigned), s->st));
