@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL_ITER = 48.0  # L 12 + R 12 + (dx,dy,conf) in 12 + out 12
 BYTES_PER_PIXEL = {"k_cost": BYTES_PER_PIXEL_ITER, "k_smooth": 24.0, "k_box": 24.0, "k_warp": 36.0, "k_sqblur": 24.0, "k_seed": 24.0}
 REFERENCE_PAIRS_PER_S = {"full16mp": 0.1, "fovea16mp": 1.0 / 3.0}  # BASELINE.md section 1 (README.md:15-16)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 WORKLOADS = {
     "full16mp": dict(W=4928, H=3264, mode="full", desc="16MP (4928x3264) stereo pair, full-res 14-level pyramid"),
@@ -56,6 +56,36 @@ WORKLOADS = {
     "fovea-shard": dict(W=4928, H=3264, mode="fovea-shard",
                         desc="16MP stereo pair, one fovea window per GPU, coarse state broadcast over RCCL"),
 }
+
+
+def whole_pair_algorithmic_bytes(W: int, H: int, levels: int, F: int) -> float:
+    """SURVEY.md 8d, derived from the level sizes: matching 48 B per pixel-iteration; pyramid per image = rgb8 read (3 B/px of level 0)
+    + level-0 planes written (12 B/px) + for every level >= 1 its parent read once and the level written (12 B/px each; level 1's parent
+    is level 0, level i+2's parent is level i); seeding = 12 B x (source + destination pixels) per level transition.  Full mode only
+    distinguishes F = 0; the foveated stack crops levels < F-1 to the fovea for matching and seeding (the pyramids are built whole)."""
+    from ug_stereomatcher_amd import _lib
+    ws, hs = _lib.level_dims(W, H, levels)
+    px = [w * h for (w, h) in zip(ws, hs)]
+    fpx = px[F - 1] if F >= 2 else None
+    mpx = [(fpx if (fpx is not None and i < F - 1) else px[i]) for i in range(levels)]
+    match = BYTES_PER_PIXEL_ITER * _lib.pixel_iterations(W, H, levels, F)
+    pyr = 3.0 * px[0] + 12.0 * px[0]
+    for i in range(1, levels):
+        parent = px[0] if i == 1 else px[i - 2]
+        pyr += 12.0 * (parent + px[i])
+    seed = sum(12.0 * (mpx[i] + mpx[i - 1]) for i in range(1, levels))
+    return match + 2.0 * pyr + seed
+
+
+def kernel_source_sha16() -> str:
+    """The hash tools/valu_model.py stamps its model with: sha256 over ug_stereomatcher_amd/csrc/*.hip, *.hpp."""
+    import hashlib
+    csrc = os.path.join(ROOT, "ug_stereomatcher_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def log(*a):
@@ -96,21 +126,19 @@ def usable_cpus() -> int:
 
 
 def cpu_baseline(wl: dict, runs: int = 3):
-    """The CPU oracle (kind 'port') on a bounded sample -- one 1920x1080 pair of the same generator, scaled to the
-    workload's unit by pixel-iterations -- with 1 thread and with every core of this host; median of `runs`."""
+    """The CPU oracle (kind 'port': the reference has no CPU matcher).  All cores: timed on THE WORKLOAD'S OWN PAIR (16 MP for the
+    headline line), median of `runs`, wall-clock bracket around the library call only (UG_GPU_matcher.cpp:422-426).
+    One thread: a 1920x1080 pair of the same generator scaled by pixel-iterations (a 16 MP single-thread run takes minutes)."""
     from oracle import oracle as orc
     from ug_stereomatcher_amd import _lib, synth
     orc.build()
-    W, H = 1920, 1080
-    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 2)
     F = 0 if wl["mode"] == "full" else 7
-    pi_sample = _lib.pixel_iterations(W, H, 14, F)
-    pi_unit = _lib.pixel_iterations(wl["W"], wl["H"], 14, F)
     # "all cores" = what this process may use, capped at the GPU box's CPU share of 16 per GPU (UGSM_CPU_THREADS overrides):
     # an OpenMP team the size of the host's 256 hardware threads inside a 16-CPU share does not finish in minutes
     ncpu = int(os.environ.get("UGSM_CPU_THREADS", min(usable_cpus(), 16)))
 
-    def leg(threads):
+    def leg(threads, W, H, seed):
+        L, R, _, _ = synth.make_pair(W, H, seed)
         orc.set_num_threads(threads)
         ts = []
         for _ in range(runs):
@@ -121,16 +149,19 @@ def cpu_baseline(wl: dict, runs: int = 3):
                 orc.match_foveated(L, R, 14, F)
             ts.append(time.perf_counter() - t0)
         med = sorted(ts)[len(ts) // 2]
-        return {"threads": threads, "seconds_median": med, "seconds": ts, "value": (pi_sample / med) / pi_unit}
+        pi_sample = _lib.pixel_iterations(W, H, 14, F)
+        pi_unit = _lib.pixel_iterations(wl["W"], wl["H"], 14, F)
+        return {"threads": threads, "size": f"{W}x{H}", "seconds_median": med, "seconds": ts, "value": (pi_sample / med) / pi_unit,
+                "scaled_by_pixel_iterations": (W, H) != (wl["W"], wl["H"])}
 
-    log(f"cpu_baseline: oracle on one {W}x{H} pair, {ncpu} threads x{runs} ...")
-    allc = leg(ncpu)
-    log(f"cpu_baseline: ... and 1 thread x{runs} ...")
-    one = leg(1)
+    log(f"cpu_baseline: oracle on the {wl['W']}x{wl['H']} pair itself, {ncpu} threads x{runs} ...")
+    allc = leg(ncpu, wl["W"], wl["H"], synth.BASE_SEED + 2)
+    log(f"cpu_baseline: ... and 1 thread on one 1920x1080 pair x{runs} (scaled) ...")
+    one = leg(1, 1920, 1080, synth.BASE_SEED + 2)
     return {"value": allc["value"], "unit": "pairs/s", "cores": ncpu, "kind": "port",
-            "sample": f"one {W}x{H} {wl['mode']}-mode pair ({pi_sample} pixel-iterations), median of {runs} runs, scaled by "
-                      f"pixel-iterations to the {wl['W']}x{wl['H']} workload ({pi_unit}); wall-clock bracket around the library "
-                      "call only, as UG_GPU_matcher.cpp:422-426",
+            "sample": f"all cores: the {wl['W']}x{wl['H']} {wl['mode']}-mode pair of the timed workload itself, median of {runs} runs "
+                      f"({allc['seconds_median']:.2f} s each); one thread: one 1920x1080 pair scaled by pixel-iterations; wall-clock bracket "
+                      "around the library call only, as UG_GPU_matcher.cpp:422-426",
             "host_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": cpu_model(), "all_cores": allc, "one_thread": one}
 
 
@@ -156,10 +187,11 @@ def main():
     ap.add_argument("--profile-pairs", type=int, default=3, help="pairs of the single-pair event pass after the timed region (0 = skip)")
     ap.add_argument("--repeats", type=int, default=2, help="extra timed repetitions of the K steps (value_repeats)")
     ap.add_argument("--no-service", action="store_true", help="skip the PCIe-inclusive service-call leg")
-    ap.add_argument("--no-events", action="store_true", help="same as --profile-pairs 0 --no-service --repeats 0 (bare throughput line)")
+    ap.add_argument("--single-pairs", type=int, default=12, help="pairs of the un-instrumented one-slot leg (single_pair_no_events; 0 = skip)")
+    ap.add_argument("--no-events", action="store_true", help="same as --profile-pairs 0 --no-service --repeats 0 --single-pairs 0 (bare throughput line)")
     args = ap.parse_args()
     if args.no_events:
-        args.profile_pairs, args.no_service, args.repeats = 0, True, 0
+        args.profile_pairs, args.no_service, args.repeats, args.single_pairs = 0, True, 0, 0
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1 on the way
@@ -266,7 +298,8 @@ def main():
         "config": {"workload": wl["desc"], "pairs_in_flight_per_gpu": slots, "kernel_path": args.kernel_path,
                    "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}"},
         "value_repeats": repeats,
-        "whole_pair_algorithmic_GBps": (8.913e9 if args.workload == "full16mp" else BYTES_PER_PIXEL_ITER * pi) * value / n_gpus / 1e9,
+        "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),
+        "whole_pair_algorithmic_GBps": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F) * value / n_gpus / 1e9,
     }
 
     # ---- single-pair event pass: uncontended kernel durations (rank 0) ------------------------------------------------
@@ -343,6 +376,32 @@ def main():
                 except Exception as ex:  # a stale model file must not take the line down
                     result["valu_roofline"] = {"error": str(ex)}
 
+    # ---- one pair at a time, un-instrumented, on a ONE-SLOT context: the reference's call pattern (UG_GPU_matcher.cpp:497-694) ------
+    if rank == 0 and n_gpus == 1 and mode != "fovea-shard" and args.single_pairs > 0:
+        ctx1 = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=1, kernel_path=args.kernel_path, profile_events=0)
+        out1 = outs[0]
+
+        def one(k):
+            Lt, Rt = pairs[k % 2]
+            if mode == "full":
+                ctx1.check(ctx1.lib.ugsm_submit_full(ctx1.handle, 0, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, out1.data_ptr()))
+            else:
+                ctx1.check(ctx1.lib.ugsm_submit_foveated(ctx1.handle, 0, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, 0, 0, out1.data_ptr(), None, None))
+            ctx1.check(ctx1.lib.ugsm_wait(ctx1.handle, 0))
+        for k in range(3):
+            one(k)
+        ts = []
+        for k in range(args.single_pairs):
+            t0 = time.perf_counter()
+            one(k)
+            ts.append(time.perf_counter() - t0)
+        ctx1.close()
+        med = sorted(ts)[len(ts) // 2]
+        result["single_pair_no_events"] = {"ms_per_pair_median": 1e3 * med, "pairs_per_s": 1.0 / med, "ms_per_pair_mean": 1e3 * sum(ts) / len(ts),
+                                           "pairs": len(ts),
+                                           "note": "one-slot context, one pair in flight (submit, then wait), inputs resident in HBM, no event recorded "
+                                                   "anywhere; host wall clock per pair"}
+
     # ---- device copy rate and the PCIe-inclusive service call (rank 0, N = 1) ------------------------------------------
     if rank == 0 and n_gpus == 1 and not args.no_service:
         torch.cuda.synchronize()
@@ -401,7 +460,11 @@ def valu_roofline(vm: dict, by_name: dict, n_pairs: int, px0: int) -> dict:
     vm = profiles/rNN_valu_model.json (tools/valu_model.py): per kernel the mean issue cost of a VALU instruction of its hot
     loops (ISA mix x tools/valubench.hip costs in actual cycles) and the in-kernel clock; profiles/pmc_traffic.json holds
     SQ_INSTS_VALU of the level-0 launch (PMC pass).  model = instructions x mean cost / (SIMDs x clock)."""
-    out = {"source": vm.get("_source"), "clock_GHz": vm["clock_GHz"], "simds": vm["simds"], "kernels": []}
+    built = kernel_source_sha16()
+    out = {"source": vm.get("_source"), "clock_GHz": vm["clock_GHz"], "simds": vm["simds"], "kernels": [],
+           "model_kernel_source_sha16": vm.get("_kernel_source_sha16"), "built_kernel_source_sha16": built,
+           # instruction counts and mixes come from committed profiles: they describe the sources they were collected on
+           "stale": vm.get("_kernel_source_sha16") != built}
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         insts, clocks = pj.get("valu_insts_level0", {}), pj.get("clock_GHz_level0", {})
@@ -415,13 +478,17 @@ def valu_roofline(vm: dict, by_name: dict, n_pairs: int, px0: int) -> dict:
         measured_us = 1e3 * l0["total_ms"] / l0["launches"]
         clk = clocks.get(name) if isinstance(clocks.get(name), (int, float)) else vm["clock_GHz"]  # the clock held during that launch
         model_us = insts[name] * m["mean_cycles_per_valu"] / vm["simds"] / (clk * 1e3)
+        guide_us = insts[name] * m.get("mean_cycles_per_valu_guide", m["mean_cycles_per_valu"]) / vm["simds"] / (clk * 1e3)
         out["kernels"].append({"name": name, "level0_measured_us": measured_us, "level0_valu_model_us": model_us, "frac": model_us / measured_us,
+                               "level0_valu_model_us_guide_costs": guide_us, "frac_guide_costs": guide_us / measured_us,
+                               "mean_cycles_per_valu_guide": m.get("mean_cycles_per_valu_guide"),
                                "clock_GHz": clk,
                                "valu_instructions_level0": insts[name], "mean_cycles_per_valu": m["mean_cycles_per_valu"],
                                "valu_lane_instructions_per_pixel": insts[name] * 64.0 / px0})
-    out["note"] = ("frac = time the launch's VALU instruction stream needs at the measured per-instruction issue costs (actual cycles, four waves "
-                   "per SIMD) / measured duration; near 1 = VALU-issue bound.  Instruction counts and costs come from profiles/ (PMC pass and "
-                   "valubench of this round), the duration is measured in this run")
+    out["note"] = ("frac = time the launch's VALU instruction stream needs at the MEASURED per-instruction issue costs (tools/valubench, actual cycles, "
+                   "four waves per SIMD: 2.2 / 4.2 / 8.1 for full-rate / half-rate / transcendental instructions) / measured duration; "
+                   "frac_guide_costs = the same at the hardware guide's nominal 2 / 4 / 8; near 1 = VALU-issue bound.  Instruction counts and mixes "
+                   "come from profiles/ (PMC pass, ISA of the hot loops); `stale` = those were collected on other kernel sources than the ones built")
     return out
 
 

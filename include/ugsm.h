@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UGSM_ABI_VERSION 2
+#define UGSM_ABI_VERSION 3  /* 3: ugsm_config grew (lr_check_threshold), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked */
 
 /* status codes */
 #define UGSM_OK                0
@@ -70,6 +70,12 @@ typedef struct ugsm_config {
     int small_max_pixels; /* levels of at most this many pixels run K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip:
                              channel-parallel 16 x 12 tiles, one thread per pixel; same results bit for bit); 0 = default
                              threshold, < 0 = never */
+    float lr_check_threshold; /* LR-consistency check, OFF at 0 (default).  Named by the north star; THE REFERENCE HAS NONE (no
+                             right-to-left pass in MatchLib.cu / MatchGPULib.cpp), so any value > 0 leaves the reference's results:
+                             full mode only (ugsm_match_full / ugsm_submit_full), the pair is matched a second time with the images
+                             exchanged, and the confidence of every left pixel whose match (x + dx, y + dy) in the right-to-left
+                             field does not point back within this many pixels, in x or in y, is set to 0 (dx, dy unchanged).
+                             Doubles the matching work of a call. */
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);
@@ -146,6 +152,10 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
                          float *d_pyrL, float *d_pyrR);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
 int ugsm_wait_all(ugsm_ctx *ctx);
+/* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the
+ * RCCL collective of the fovea shard -- order them after the slot's work ON THE DEVICE (record an event on this stream, make the
+ * other stream wait for it) instead of blocking in ugsm_wait.  The stream stays owned by the context. */
+int ugsm_slot_stream(ugsm_ctx *ctx, int slot, void **hip_stream);
 
 /* Fovea sharding over several GPUs (north-star; no reference counterpart: the
  * reference has one centred fovea on one GPU).  coarse: pyramids + levels
@@ -221,6 +231,11 @@ int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, c
 /* Row f-4: weightedDifference (MatchGPULib.cpp:1336-1437) of two device (dx, dy, conf) fields, weights = the new field's
  * conf: out2[0] = dx, out2[1] = dy (host).  Fixed-order binary64 sums, identical to the CPU restatement. */
 int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const float *d_old3, int W, int H, float *out2);
+/* The LR-consistency check (ugsm_config.lr_check_threshold; no reference counterpart) on two device (dx, dy, conf) fields: zeroes
+ * d_left3's confidence where d_right3 does not point back within tau; *marked (host, may be NULL) = number of pixels marked. */
+int ugsm_stage_lr_check(ugsm_ctx *ctx, float *d_left3, const float *d_right3, int W, int H, float tau, long long *marked);
+/* Pixels the LR check of the last full-mode call on `slot` marked (-1: the call ran without the check).  Valid after ugsm_wait. */
+long long ugsm_last_lr_marked(ugsm_ctx *ctx, int slot);
 /* Iterations each level of the last call on `slot` actually ran (early_exit_threshold > 0 can stop a level early);
  * per_level[UGSM_MAX_LEVELS], -1 for levels not run.  ugsm_stage_iterate records its count at index 0. */
 int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level);

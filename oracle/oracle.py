@@ -282,3 +282,14 @@ def weighted_difference(new3: np.ndarray, old3: np.ndarray):
     lib().orc_weighted_difference(_fp(np.ascontiguousarray(new3, np.float32)), _fp(np.ascontiguousarray(old3, np.float32)), W, H, _fp(out))
     return float(out[0]), float(out[1])
 
+
+
+def lr_check(left3: np.ndarray, right3: np.ndarray, tau: float):
+    """LR-consistency check (no reference counterpart): returns (left3 with the confidence of inconsistent pixels
+    zeroed, number of pixels marked)."""
+    _, H, W = left3.shape
+    out = np.ascontiguousarray(left3, np.float32).copy()
+    f = lib().orc_lr_check
+    f.restype = C.c_long
+    marked = f(_fp(out), _fp(np.ascontiguousarray(right3, np.float32)), W, H, C.c_float(tau))
+    return out, int(marked)

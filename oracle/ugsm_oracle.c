@@ -889,3 +889,32 @@ void orc_weighted_difference(const float *newd3, const float *oldd3, int W, int 
     out2[1] = (float)(S[1] / C);
 }
 
+
+/* LR-consistency check.  Named by BASELINE.json's north_star; the REFERENCE HAS NONE (no right-to-left pass anywhere in
+ * MatchLib.cu / MatchGPULib.cpp), so this restates the build's own definition, opt-in and OFF in
+ * every parity run.  left3 / right3: (dx, dy, conf) of the left-to-right match and of the match with the images exchanged.  The
+ * match of left pixel (x, y) is right pixel (x + dx, y + dy) (getPointCloud.cpp:910-913); the right field is fetched there the way
+ * the matcher fetches -- nearest neighbour, clamped: tex_index on the same float coordinate as the warp (MatchLib.cu:510-515) --
+ * and should point back.  Where !(|dxL + dxR'| <= tau) or !(|dyL + dyR'| <= tau) (so also where either sum is a NaN) the left
+ * confidence becomes 0; dx and dy stay.  Returns the number of pixels marked. */
+long orc_lr_check(float *left3, const float *right3, int W, int H, float tau)
+{
+    const size_t n = (size_t)W * H;
+    long marked = 0;
+    for (int iy = 0; iy < H; iy++) {
+        const float y = (float)iy + 0.5f;
+        for (int ix = 0; ix < W; ix++) {
+            const float x = (float)ix + 0.5f;
+            const size_t at = (size_t)iy * W + ix;
+            const float dxl = left3[at], dyl = left3[n + at];
+            const int sx = tex_index(x + dxl, W), sy = tex_index(y + dyl, H);
+            const size_t rt = (size_t)sy * W + sx;
+            const float ex = fabsf(dxl + right3[rt]), ey = fabsf(dyl + right3[n + rt]);
+            if (!(ex <= tau) || !(ey <= tau)) {
+                left3[2 * n + at] = 0.0f;
+                marked++;
+            }
+        }
+    }
+    return marked;
+}

@@ -114,6 +114,10 @@ int orc_reconstruct_full(const float *stack3, int W, int H, int levels, int F, i
  * between two (dx, dy, conf) fields, weights = the new field's conf; fixed-order binary64 sums (see the .c file). */
 void orc_weighted_difference(const float *newd3, const float *oldd3, int W, int H, float out2[2]);
 
+/* LR-consistency check (north_star; no reference counterpart): zeroes the confidence of left pixels whose match in the
+ * right-to-left field does not point back within tau (in x or in y); returns how many.  See the .c file for the definition. */
+long orc_lr_check(float *left3, const float *right3, int W, int H, float tau);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

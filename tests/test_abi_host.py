@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     so = C.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
-    assert lib.load().ugsm_abi_version() == 2
+    assert lib.load().ugsm_abi_version() == 3
 
 
 def test_status_strings(lib):

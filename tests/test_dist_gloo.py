@@ -98,17 +98,30 @@ class OracleShardDriver:
     Work is deferred to wait() / the next use of the slot, like the asynchronous library, so that a state buffer shared
     between slots -- the hazard the per-slot buffers remove -- would be caught."""
 
-    def __init__(self, orc, levels, F):
+    def __init__(self, orc, levels, F, on_device=False):
         self.orc, self.levels, self.F = orc, levels, F
         self.slot = {}
+        self.on_device = on_device  # answer of orders_on_device(): stands for "CUDA tensors over RCCL" (round 3: no host wait on the source rank)
+        self.log = []
+
+    def orders_on_device(self, state):
+        return self.on_device
+
+    def current_after_slot(self, slot):
+        self.log.append(("current_after_slot", slot))  # (the double's coarse phase has already written the state: nothing to order)
+
+    def slot_after_current(self, slot):
+        self.log.append(("slot_after_current", slot))
 
     def submit_pyramids(self, slot, L, R, W, H, stride):
+        self.log.append(("pyramids", slot))
         self._finish(slot)
         o = self.orc
         self.slot[slot] = dict(pl=o.pyramid(o.rgb_to_planes(L.numpy()), self.levels), pr=o.pyramid(o.rgb_to_planes(R.numpy()), self.levels),
                                W=W, H=H, fine=None)
 
     def submit_coarse(self, slot, state):
+        self.log.append(("coarse", slot))
         o, s = self.orc, self.slot[slot]
         top = self.levels - 1
         cur = np.zeros_like(s["pl"][top])
@@ -120,9 +133,11 @@ class OracleShardDriver:
         state.copy_(torch.from_numpy(cur))
 
     def wait(self, slot):
+        self.log.append(("wait", slot))
         self._finish(slot)
 
     def submit_fine(self, slot, state, off, out):
+        self.log.append(("fine", slot))
         self.slot[slot]["fine"] = (state, off, out)  # reads `state` later, like the stream-ordered copy in the library
 
     def _finish(self, slot):
@@ -155,32 +170,57 @@ def _shard_worker(rank, world, port, out_q):
     fw, fh, *_ = orc.fovea_geometry(W, H, levels, F)
     pairs = [tuple(torch.from_numpy(a) for a in synth.make_pair(W, H, 900 + j)[:2]) for j in range(2)]
     offsets = [(0, 0), (37, -21)]
-    drv = OracleShardDriver(orc, levels, F)
-    states = [torch.zeros((3, fh, fw)) for _ in range(slots)]
-    outs = [torch.zeros((3, F, fh, fw)) for _ in range(slots)]
-    got = []
-    for k in range(steps):  # bench.py's submit(): slot free? then the step
-        s = k % slots
-        drv.wait(s)
-        if k >= slots:
-            got.append((k - slots, outs[s].clone()))
-        L, R = pairs[k % 2]
-        ud.fovea_shard_step(drv, s, L, R, W, H, 3 * W, states[s], offsets[rank], outs[s], rank)
-    for k in range(max(steps - slots, 0), steps):
-        drv.wait(k % slots)
-        got.append((k, outs[k % slots].clone()))
-    ok = True
-    for k, st in got:
-        L, R = pairs[k % 2]
-        exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[rank][0], offsets[rank][1])
-        ok = ok and bool((st.numpy().view(np.uint32) == exp.view(np.uint32)).all())
-    out_q.put((rank, ok, len(got)))
+    ok, n_got, no_host_wait = True, 0, True
+    for on_device in (False, True):
+        drv = OracleShardDriver(orc, levels, F, on_device)
+        states = [torch.zeros((3, fh, fw)) for _ in range(slots)]
+        outs = [torch.zeros((3, F, fh, fw)) for _ in range(slots)]
+        got = []
+        for k in range(steps):  # bench.py's submit(): slot free? then the step
+            s = k % slots
+            drv.wait(s)
+            if k >= slots:
+                got.append((k - slots, outs[s].clone()))
+            L, R = pairs[k % 2]
+            mark = len(drv.log)
+            ud.fovea_shard_step(drv, s, L, R, W, H, 3 * W, states[s], offsets[rank], outs[s], rank)
+            step_log = drv.log[mark:]
+            if on_device:
+                # the step itself never waits on the host, on any rank; the source rank orders the collective after its coarse phase
+                # and every rank orders its fine phase after the collective, both on the device
+                no_host_wait = no_host_wait and all(c[0] != "wait" for c in step_log)
+                want = [("pyramids", s)] + ([("coarse", s)] if rank == 0 else []) + [("current_after_slot", s), ("slot_after_current", s), ("fine", s)]
+                no_host_wait = no_host_wait and step_log == want
+            elif rank == 0:
+                no_host_wait = no_host_wait and ("wait", s) in step_log  # (the host path: the state is complete before gloo sends it)
+        for k in range(max(steps - slots, 0), steps):
+            drv.wait(k % slots)
+            got.append((k, outs[k % slots].clone()))
+        for k, st in got:
+            L, R = pairs[k % 2]
+            exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[rank][0], offsets[rank][1])
+            ok = ok and bool((st.numpy().view(np.uint32) == exp.view(np.uint32)).all())
+        n_got += len(got)
+        # the optional gather of every rank's stack on one consumer rank
+        last = outs[(steps - 1) % slots]
+        stacks = ud.gather_stacks(last, dst=0)
+        if rank == 0:
+            L, R = pairs[(steps - 1) % 2]
+            ok = ok and stacks is not None and len(stacks) == world
+            for r in range(world):
+                exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[r][0], offsets[r][1])
+                ok = ok and bool((stacks[r].numpy().view(np.uint32) == exp.view(np.uint32)).all())
+        else:
+            ok = ok and stacks is None
+    out_q.put((rank, ok and no_host_wait, n_got))
     dist.destroy_process_group()
 
 
 def test_fovea_shard_sequence_world_size_2_two_slots():
     """coarse on rank 0 -> one broadcast -> fine on every rank, three steps over two slots: rank 0's window (the centred fovea)
-    equals the one-shot foveated result bit for bit, and so does rank 1's off-centre window."""
+    equals the one-shot foveated result bit for bit, and so does rank 1's off-centre window.  Run twice: with the host-side wait a
+    gloo broadcast needs, and with the device-side ordering the RCCL path uses (the step then never calls wait: rank 0 keeps
+    submitting); the stacks gathered on rank 0 equal each rank's own result."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -192,4 +232,4 @@ def test_fovea_shard_sequence_world_size_2_two_slots():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True, 3), (1, True, 3)]
+    assert res == [(0, True, 6), (1, True, 6)]

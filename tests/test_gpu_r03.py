@@ -1,0 +1,132 @@
+"""Round-3 additions, HIP (through the C-ABI) against the CPU oracle, bit for bit:
+
+* the LR-consistency check (BASELINE.json north_star; the reference has none -- SURVEY.md 0.4 -- so the oracle restates the
+  build's own definition; opt-in, OFF in every other test);
+* the slot's side stream (right pyramid and the A planes beside the left pyramid): same results as one stream;
+* the host team of the service path at several sizes.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from ug_stereomatcher_amd import _lib
+    return _lib
+
+
+def full_match(c, L, R):
+    H, W, _ = L.shape
+    out = np.empty((3, H, W), np.float32)
+    c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+    return out
+
+
+def test_lr_check_kernel_matches_the_oracle(lib, orc):
+    rng = np.random.Generator(np.random.PCG64(301))
+    for (W, H, tau) in ((97, 61, 0.75), (320, 200, 1.0), (640, 33, 0.0)):
+        left = np.stack([rng.normal(0, 4, (H, W)), rng.normal(0, 2, (H, W)), rng.random((H, W))]).astype(np.float32)
+        # a right field that mostly points back (so that both outcomes occur), with wild values sprinkled in
+        yy, xx = np.mgrid[0:H, 0:W]
+        sx = np.clip(np.floor(xx + 0.5 + left[0]), 0, W - 1).astype(int)
+        sy = np.clip(np.floor(yy + 0.5 + left[1]), 0, H - 1).astype(int)
+        right = np.stack([rng.normal(0, 4, (H, W)), rng.normal(0, 2, (H, W)), rng.random((H, W))]).astype(np.float32)
+        keep = rng.random((H, W)) < 0.6
+        right[0][sy[keep], sx[keep]] = -left[0][keep] + rng.normal(0, 0.4, keep.sum()).astype(np.float32)
+        right[1][sy[keep], sx[keep]] = -left[1][keep] + rng.normal(0, 0.4, keep.sum()).astype(np.float32)
+        wild = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e10, -0.5, 1e-45], np.float32)
+        idx = rng.integers(0, H * W, 64)
+        left[0].ravel()[idx[:32]] = wild[rng.integers(0, len(wild), 32)]
+        right[1].ravel()[idx[32:]] = wild[rng.integers(0, len(wild), 32)]
+        with np.errstate(all="ignore"):
+            exp, n_exp = orc.lr_check(left, right, tau)
+        with lib.Context(levels=1) as c:
+            pl, pr = c.to_device(left), c.to_device(right)
+            marked = C.c_longlong(-1)
+            c.check(c.lib.ugsm_stage_lr_check(c.handle, pl, pr, W, H, C.c_float(tau), C.byref(marked)))
+            got = c.to_host(pl, left.shape)
+            c.free(pl)
+            c.free(pr)
+        assert_bit_equal(got, exp, f"lr check {W}x{H} tau={tau}")
+        assert marked.value == n_exp and 0 < n_exp < W * H
+
+
+def test_lr_check_through_the_matcher_and_off_by_default(lib, orc):
+    from ug_stereomatcher_amd import synth
+    L, R, _, _ = synth.make_pair(200, 150, synth.BASE_SEED + 310)
+    fwd, bwd = orc.match_full(L, R, 8), orc.match_full(R, L, 8)
+    exp, n_exp = orc.lr_check(fwd, bwd, 1.0)
+    with lib.Context(levels=8, lr_check_threshold=1.0) as c:
+        got = full_match(c, L, R)
+        assert c.lib.ugsm_last_lr_marked(c.handle, 0) == n_exp
+    assert_bit_equal(got, exp, "match + LR check")
+    assert 0 < n_exp < 200 * 150 and (got[2] == 0).sum() >= n_exp
+    assert_bit_equal(got[:2], fwd[:2], "the check leaves dx, dy alone")
+    with lib.Context(levels=8) as c:  # OFF by default: the reference's result, no second match
+        assert_bit_equal(full_match(c, L, R), fwd, "no LR check")
+        assert c.lib.ugsm_last_lr_marked(c.handle, 0) == -1
+    with pytest.raises(lib.UgsmError):
+        lib.Context(levels=8, lr_check_threshold=-1.0)
+
+
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_side_stream_gives_the_same_results(lib, orc, monkeypatch, two):
+    """Right pyramid + A planes on the slot's side stream (UGSM_TWO_STREAMS=1; the default of one-slot contexts) against everything in line (=0): both equal
+    the oracle, full and foveated mode, two submits back to back on one slot (the second pair's side stream must wait for the first)."""
+    from ug_stereomatcher_amd import synth
+    monkeypatch.setenv("UGSM_TWO_STREAMS", two)
+    W, H = 420, 300
+    pairs = [synth.make_pair(W, H, synth.BASE_SEED + 320 + j)[:2] for j in range(2)]
+    refs = [orc.match_full(L, R, 10) for (L, R) in pairs]
+    with lib.Context(levels=10, fovea_levels=5, slots=2) as c:
+        d_in = [(c.to_device(L), c.to_device(R)) for (L, R) in pairs]
+        outs = [c.alloc(3 * W * H * 4) for _ in range(2)]
+        for rep in range(3):  # the same slot again and again without a wait in between
+            for j in range(2):
+                c.check(c.lib.ugsm_submit_full(c.handle, 0, d_in[j][0], d_in[j][1], W, H, 3 * W, outs[j]))
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        for j in range(2):
+            assert_bit_equal(c.to_host(outs[j], (3, H, W)), refs[j], f"two_streams={two} pair {j}")
+        # foveated, through the service call
+        L, R = pairs[0]
+        fw, fh = lib.fovea_dims(W, H, 10, 5)
+        st = np.empty((3, 5, fh, fw), np.float32)
+        c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], 0, 0, st[0].ctypes.data, st[1].ctypes.data,
+                                          st[2].ctypes.data, None, None))
+        exp, _, _ = orc.match_foveated(L, R, 10, 5)  # (3, F, fovH, fovW): the layout of the three stack planes
+        assert_bit_equal(st, exp, f"foveated two_streams={two}")
+        for p in outs + [q for pr in d_in for q in pr]:
+            c.free(p)
+
+
+@pytest.mark.parametrize("threads", ["1", "3", "64"])
+def test_service_call_with_any_host_team(lib, orc, monkeypatch, threads):
+    """ugsm_match_full through pageable buffers with a host team of 1, 3 and (capped) 64 members, on a call large enough to use the
+    team (planes > 4 MB) and on one too small for it."""
+    from ug_stereomatcher_amd import synth
+    monkeypatch.setenv("UGSM_COPY_THREADS", threads)
+    for (W, H, lv) in ((1300, 900, 10), (96, 72, 4)):
+        L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 340)
+        with lib.Context(levels=lv) as c:
+            got = full_match(c, L, R)
+            got2 = full_match(c, L, R)
+        assert_bit_equal(got, got2, f"{W}x{H} twice")
+        if W < 200:
+            assert_bit_equal(got, orc.match_full(L, R, lv), f"{W}x{H} team={threads}")
+
+
+def test_slot_stream_is_exported(lib):
+    with lib.Context(levels=1, slots=2) as c:
+        a, b = C.c_void_p(), C.c_void_p()
+        c.check(c.lib.ugsm_slot_stream(c.handle, 0, C.byref(a)))
+        c.check(c.lib.ugsm_slot_stream(c.handle, 1, C.byref(b)))
+        assert a.value and b.value and a.value != b.value
+        assert c.lib.ugsm_slot_stream(c.handle, 2, C.byref(a)) == lib.UGSM_ERR_BAD_ARG

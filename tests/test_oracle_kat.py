@@ -396,3 +396,34 @@ def test_weighted_difference_is_the_weighted_mean_absolute_change(orc):
     new[2, 0, 0] = 2.0  # weights are the NEW field's confidence
     dh2, _ = orc.weighted_difference(new, old)
     assert dh2 == f(1.0 / 11.5)
+
+
+def test_lr_check_known_answers(orc):
+    """The LR-consistency check has NO reference counterpart: these cases pin the build's own definition
+    (DESIGN.md section 8).  A left pixel (x, y) with (dx, dy) looks at the right-to-left field at the pixel the matcher would fetch,
+    floor(x + .5 + dx), floor(y + .5 + dy) clamped to the frame, and keeps its confidence only if that field points back within tau
+    in x AND in y; NaN sums count as inconsistent; dx, dy are never changed."""
+    f = np.float32
+    H, W = 8, 12
+    left = np.zeros((3, H, W), f)
+    right = np.zeros((3, H, W), f)
+    left[2] = 0.5
+    # (x=2, y=3): dx = +3.4 -> fetches right (5, 3) [floor(2.5 + 3.4) = 5]; the right field there says -3.0: |0.4| <= 0.5 -> kept
+    left[0, 3, 2], right[0, 3, 5] = 3.4, -3.0
+    # (x=7, y=1): dx = +1.0, dy = +2.0 -> right (8, 3) says (-1.0, -1.2): x fine, |0.8| > 0.5 in y -> confidence 0
+    left[0, 1, 7], left[1, 1, 7] = 1.0, 2.0
+    right[0, 3, 8], right[1, 3, 8] = -1.0, -1.2
+    # (x=11, y=7): dx = +50 -> clamped to the last column, right (11, 7) says 0 -> |50| > tau -> confidence 0
+    left[0, 7, 11] = 50.0
+    # (x=0, y=0): NaN disparity -> fetch index 0 (tex_index maps NaN to 0), the sum is NaN -> confidence 0
+    left[0, 0, 0] = np.nan
+    with np.errstate(all="ignore"):
+        out, n = orc.lr_check(left, right, 0.5)
+    marked = {(y, x) for y in range(H) for x in range(W) if out[2, y, x] == 0}
+    # besides the three above, the right field's own nonzero entries make the LEFT zero-disparity pixels at (3, 5) and (3, 8) inconsistent
+    assert marked == {(1, 7), (7, 11), (0, 0), (3, 5), (3, 8)} and n == 5
+    assert out[2, 3, 2] == f(0.5)
+    same = (out[:2].view(np.uint32) == left[:2].view(np.uint32))
+    assert same.all()
+    # tau = 0 keeps exact round trips only; a large tau keeps everything but the NaN
+    assert orc.lr_check(left, right, 0.0)[1] == 6 and orc.lr_check(left, right, 100.0)[1] == 1

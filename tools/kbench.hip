@@ -165,35 +165,6 @@ int main(int argc, char **argv)
         CK(hipGetLastError());
         return 0;
     }
-    if (argc > 4 && atoi(argv[4]) == 11) {  // K-smooth, persistent workgroups (round 3) against one workgroup per tile: bits + timing: kbench W H reps 11
-        float *o2; CK(hipMalloc(&o2, 12 * n));
-        std::vector<float> ha(3 * n), hb(3 * n);
-        for (int P = 0; P <= 5; P++)
-            for (int box = 0; box < 2; box++) {
-                if (P == 0 && !box) continue;
-                CK(hipMemset(o, 0xff, 12 * n)); CK(hipMemset(o2, 0xee, 12 * n));
-                smooth_persistent = 0; launch_smooth_fused(st, d, o, W, H, P, box);
-                smooth_persistent = 1; launch_smooth_fused(st, d, o2, W, H, P, box);
-                CK(hipStreamSynchronize(st));
-                CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
-                size_t bad = 0, first = 0;
-                for (size_t i = 0; i < 3 * n; i++)
-                    if (memcmp(&ha[i], &hb[i], 4) != 0) { if (!bad) first = i; bad++; }
-                printf("k_smooth_fused persistent vs per-tile P=%d box=%d: %zu of %zu values differ%s\n", P, box, bad, 3 * n, bad ? "" : " (bit-exact)");
-                if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
-            }
-        for (int round = 0; round < 3; round++)
-            for (int P : {0, 1, 5})
-                for (int box = 0; box < 2; box++)
-                    for (int pers = 0; pers < 2; pers++) {
-                        char nm[64]; snprintf(nm, sizeof nm, "k_smooth_fused P=%d box=%d persistent=%d", P, box, pers);
-                        smooth_persistent = pers;
-                        timeit(nm, [&]() { launch_smooth_fused(st, d, o, W, H, P, box); });
-                    }
-        smooth_persistent = 1;
-        CK(hipGetLastError());
-        return 0;
-    }
     if (argc > 4 && atoi(argv[4]) == 5) {  // marching K-smooth against the LDS-tiled one: bit comparison + timing
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);
@@ -317,12 +288,12 @@ int main(int argc, char **argv)
             timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn); });
         };
         for (int round = 0; round < 2; round++) {
-            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5+box");
-            run((k_smooth_fused<112, 36, 512, 0, false>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 2, true>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
-            run((k_smooth_fused<112, 36, 512, 2, false>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 0, false>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
-            run((k_smooth_fused<112, 36, 512, 0, false>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
+            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
+            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });

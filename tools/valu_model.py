@@ -25,26 +25,41 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
          "--cuda-device-only"]
 
 # valubench kernel -> cost class
-BENCH_CLASS = {"k_fma": "fma32", "k_fmac": "fma32", "k_mul": "plain32", "k_add": "plain32", "k_mul_literal": "plain32", "k_mov": "plain32",
-               "k_add_dpp": "dpp", "k_mul_dpp": "dpp", "k_dpp": "dpp", "k_rcp": "trans32", "k_dscale": "div_scale32", "k_dfmas": "slow32",
-               "k_dfix": "slow32", "k_minimum3": "slow32", "k_min3": "slow32", "k_cnd64": "slow32", "k_max": "slow32", "k_med3": "slow32",
-               "k_cmp_vcc": "slow32", "k_cmp_sgpr": "slow32", "k_floor": "slow32", "k_cvt_i32": "slow32", "k_fma64": "f64", "k_mul64": "f64",
-               "k_add64": "f64", "k_rcp64": "trans64", "k_cvt_f64_f32": "f64", "k_cvt_f32_f64": "f64", "k_add_u32": "int",
-               "k_mad_u32_u24": "int3", "k_lshlrev_b32": "int", "k_add_lshl_u32": "int3", "k_med3_i32": "int3", "k_pkmul": "packed",
-               "k_pkadd": "packed", "k_pkfma": "packed"}
+BENCH_CLASS = {"k_fma": "fma32", "k_fmac": "fma32", "k_mul": "plain32", "k_add": "plain32", "k_mov": "mov",
+               "k_add_dpp_wave_shr": "dpp", "k_add_dpp_row_shr": "dpp", "k_mov_dpp": "dpp", "k_rcp": "trans32", "k_exp": "trans32",
+               "k_div_scale": "div_scale32", "k_div_fmas": "slow32", "k_div_fixup": "slow32", "k_minimum3": "slow32", "k_min3": "slow32",
+               "k_max": "slow32", "k_med3": "slow32", "k_cmp_vcc": "slow32", "k_floor": "slow32", "k_cvt_i32": "slow32", "k_fma64": "f64",
+               "k_mul64": "f64", "k_add64": "f64", "k_cvt_f64_f32": "f64", "k_cvt_f32_f64": "f64", "k_add_u32": "int", "k_mad_u32_u24": "int3",
+               "k_lshlrev_b32": "int3", "k_add_lshl_u32": "int3", "k_pk_mul": "packed", "k_pk_add": "packed", "k_pk_fma": "packed"}
+# the guide's nominal figures (MI355X_MICROARCH.md, "Per-instruction cycle constants": v_fma_f32 2 per SIMD at >= 2 waves, transcendentals 8;
+# half-rate classes at twice the full rate) -- the second cost table `valu_roofline` is quoted against
+GUIDE_COSTS = {"fma32": 2.0, "plain32": 2.0, "int": 2.0, "mov": 2.0, "dpp": 4.0, "slow32": 4.0, "int3": 4.0, "f64": 4.0, "div_scale32": 4.0,
+               "trans32": 8.0, "trans64": 16.0, "packed": 4.0}
 
 
 def read_costs(path):
-    """cycles per wave-instruction per SIMD at 4 waves/SIMD: the wall-clock figure (quoted at the nominal 2.4 GHz) x measured clock / 2.4"""
+    """cycles per wave-instruction per SIMD from tools/valubench (round-3 format: kernel, waves/SIMD, stamped, wall, clock GHz): the WALL
+    figure at four waves per SIMD -- the throughput a saturated SIMD sustains (wall time x in-kernel clock / instructions)."""
     acc = collections.defaultdict(list)
     clocks = []
     for line in open(path):
-        m = re.match(r"(k_\w+)\s+(\d)\s+([\d.]+)\s+([\d.]+)\s+\(([\d.]+)\)", line)
+        m = re.match(r"(k_\w+)\s+(\d)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
         if m and m.group(2) == "4" and m.group(1) in BENCH_CLASS:
-            clk = float(m.group(4))
-            acc[BENCH_CLASS[m.group(1)]].append(float(m.group(5)) * clk / 2.4)
-            clocks.append(clk)
-    return {c: sum(v) / len(v) for c, v in acc.items()}, sum(clocks) / max(len(clocks), 1)
+            acc[BENCH_CLASS[m.group(1)]].append(float(m.group(4)))
+            clocks.append(float(m.group(5)))
+    costs = {c: sum(v) / len(v) for c, v in acc.items()}
+    costs.setdefault("trans64", 2 * costs.get("trans32", 8.2))
+    return costs, sum(clocks) / max(len(clocks), 1)
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources: bench.py reports valu_roofline as stale when the built sources differ"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def classify(op, text):
@@ -60,14 +75,17 @@ def classify(op, text):
         return "div_scale32"
     if op.startswith(("v_fma_f32", "v_fmac_f32")):
         return "fma32"
-    if op.startswith(("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32")):
+    if op.startswith("v_mov_b32"):
+        return "mov"
+    if op.startswith(("v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32")):
         return "plain32"
     if op.startswith(("v_mad_u32", "v_mad_i32", "v_add_lshl", "v_lshl_add", "v_add3", "v_med3_i32", "v_med3_u32", "v_lshl_or", "v_and_or", "v_bfe",
                       "v_mul_lo", "v_mul_hi", "v_mad_u64")):
         return "int3"
-    if op.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co", "v_addc", "v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32",
-                      "v_or_b32", "v_xor_b32", "v_mul_u32_u24", "v_mul_i32_i24", "v_add_i32", "v_sub_i32", "v_not_b32")):
+    if op.startswith(("v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co", "v_addc", "v_add_i32", "v_sub_i32")):
         return "int"
+    if op.startswith(("v_lshlrev_b32", "v_lshrrev_b32", "v_ashrrev_i32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mul_u32_u24", "v_mul_i32_i24", "v_not_b32")):
+        return "int3"  # (shifts and logic measure at the half rate: k_lshlrev_b32)
     return "slow32"  # compares, selects, min/max/med3, floor, conversions, div_fmas/div_fixup, readlane ...
 
 
@@ -135,7 +153,9 @@ def price(instrs, costs):
             other["lds"] += 1
     n = sum(mix.values())
     cyc = sum(k * costs.get(c, costs["slow32"]) for c, k in mix.items())
-    return {"valu_instructions": n, "valu_cycles": cyc, "mean_cycles_per_valu": cyc / max(n, 1), "mix": dict(mix), "other": dict(other)}
+    cyc_g = sum(k * GUIDE_COSTS.get(c, 4.0) for c, k in mix.items())
+    return {"valu_instructions": n, "valu_cycles": cyc, "mean_cycles_per_valu": cyc / max(n, 1), "valu_cycles_guide": cyc_g,
+            "mean_cycles_per_valu_guide": cyc_g / max(n, 1), "mix": dict(mix), "other": dict(other)}
 
 
 def main():
@@ -143,22 +163,25 @@ def main():
     costs, clock = read_costs(bench_txt)
     costs.setdefault("int", costs["plain32"])
     costs.setdefault("int3", costs["slow32"])
+    costs.setdefault("mov", costs["plain32"])
     costs.setdefault("packed", 2 * costs["plain32"])
     tmp = "/tmp/ugsm_valu_model"
     os.makedirs(tmp, exist_ok=True)
-    report = {"_source": f"tools/valu_model.py on {os.path.basename(bench_txt)}", "_tag": tag, "clock_GHz": round(clock, 3), "simds": 1024,
-              "cost_cycles_per_wave_instruction": {k: round(v, 2) for k, v in sorted(costs.items())}, "kernels": {}}
+    report = {"_source": f"tools/valu_model.py on {os.path.basename(bench_txt)}", "_tag": tag, "_kernel_source_sha16": source_hash(),
+              "clock_GHz": round(clock, 3), "simds": 1024,
+              "cost_cycles_per_wave_instruction": {k: round(v, 2) for k, v in sorted(costs.items())},
+              "guide_cycles_per_wave_instruction": GUIDE_COSTS, "kernels": {}}
     md = [f"# {tag}: VALU-issue model of the hot kernels\n",
           f"Issue costs (actual shader cycles per wave-instruction per SIMD, four waves per SIMD; `{os.path.basename(bench_txt)}`; mean in-kernel "
           f"clock {clock:.2f} GHz):\n", "| class | cycles | what is in it |", "|---|---|---|"]
-    what = {"plain32": "v_add/sub/mul_f32, v_mov_b32", "fma32": "v_fma_f32, v_fmac_f32", "dpp": "any VALU instruction with a DPP operand (wave_shr/shl)",
+    what = {"plain32": "v_add/sub/mul_f32", "mov": "v_mov_b32", "fma32": "v_fma_f32, v_fmac_f32", "dpp": "any VALU instruction with a DPP operand (wave_shr/shl)",
             "trans32": "v_rcp_f32", "div_scale32": "v_div_scale_f32", "slow32": "v_cmp*, v_cndmask, v_min/max/med3, v_floor, v_cvt_*, v_div_fmas/fixup_f32",
             "f64": "v_fma/mul/add_f64, v_cvt_f64_f32, v_cvt_f32_f64", "trans64": "v_rcp_f64", "int": "v_add_u32, shifts, logic", "int3": "v_mad_u32_u24, v_add_lshl_u32, v_med3_i32",
             "packed": "v_pk_*_f32"}
     for k, v in sorted(costs.items()):
         md.append(f"| {k} | {v:.2f} | {what.get(k, '')} |")
     jobs = [("ugsm_kernels_march.hip", r"k_cost_marchILi1ELb0", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
-            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0", "k_smooth_fused", None),
+            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0ELb1", "k_smooth_fused", None),
             ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None)]
     for src, name_re, short, geom in jobs:
         asm = os.path.join(tmp, src.replace(".hip", ".s"))
@@ -178,7 +201,9 @@ def main():
                 p = rows[pick]
                 entry.update({"loop": pick, "valu_instructions_per_wave_step": p["valu_instructions"] / geom["steps_per_trip"],
                               "valu_cycles_per_wave_step": p["valu_cycles"] / geom["steps_per_trip"],
-                              "mean_cycles_per_valu": p["mean_cycles_per_valu"], "mix_per_trip": p["mix"], "other_per_trip": p["other"],
+                              "mean_cycles_per_valu": p["mean_cycles_per_valu"], "mean_cycles_per_valu_guide": p["mean_cycles_per_valu_guide"],
+                              "valu_cycles_per_wave_step_guide": p["valu_cycles_guide"] / geom["steps_per_trip"],
+                              "mix_per_trip": p["mix"], "other_per_trip": p["other"],
                               "valid_pixels_per_wave_step": geom["valid_pixels_per_wave_step"]})
             else:
                 tot = collections.Counter()
@@ -186,7 +211,8 @@ def main():
                 for h, ins in loops.items():
                     allins += ins
                 p = price(allins, costs)
-                entry.update({"loops": len(loops), "mean_cycles_per_valu": p["mean_cycles_per_valu"], "mix_static": p["mix"]})
+                entry.update({"loops": len(loops), "mean_cycles_per_valu": p["mean_cycles_per_valu"],
+                              "mean_cycles_per_valu_guide": p["mean_cycles_per_valu_guide"], "mix_static": p["mix"]})
             report["kernels"][short] = entry
             md.append(f"\n## {short}\n")
             md.append("```\n" + json.dumps(entry, indent=1) + "\n```")

@@ -31,6 +31,7 @@ EXPORTS = [
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
+    "ugsm_stage_lr_check", "ugsm_last_lr_marked", "ugsm_slot_stream",
     "ugsm_reset_kernel_stats", "ugsm_set_profile_events", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
 
@@ -44,7 +45,8 @@ class UgsmError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("levels", C.c_int), ("fovea_levels", C.c_int), ("slots", C.c_int),
                 ("kernel_path", C.c_int), ("profile_events", C.c_int), ("march_min_pixels", C.c_int), ("march_np", C.c_int),
-                ("march_rows", C.c_int), ("march_smooth", C.c_int), ("early_exit_threshold", C.c_float), ("small_max_pixels", C.c_int)]
+                ("march_rows", C.c_int), ("march_smooth", C.c_int), ("early_exit_threshold", C.c_float), ("small_max_pixels", C.c_int),
+                ("lr_check_threshold", C.c_float)]
 
 
 class LevelPlan(C.Structure):
@@ -111,6 +113,10 @@ def load():
     lib.ugsm_stage_div_probe.argtypes = [vp, vp, vp, vp, i]
     lib.ugsm_stage_weighted_difference.argtypes = [vp, vp, vp, i, i, C.POINTER(C.c_float)]
     lib.ugsm_last_iterations.argtypes = [vp, i, C.POINTER(i)]
+    lib.ugsm_stage_lr_check.argtypes = [vp, vp, vp, i, i, C.c_float, C.POINTER(C.c_longlong)]
+    lib.ugsm_last_lr_marked.argtypes = [vp, i]
+    lib.ugsm_last_lr_marked.restype = C.c_longlong
+    lib.ugsm_slot_stream.argtypes = [vp, i, C.POINTER(vp)]
     lib.ugsm_get_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), i]
     lib.ugsm_reset_kernel_stats.argtypes = [vp]
     lib.ugsm_set_profile_events.argtypes = [vp, i]
@@ -174,7 +180,8 @@ class Context:
 
     def __init__(self, device: int = 0, levels: int = 14, fovea_levels: int = 7, slots: int = 1,
                  kernel_path: int = 0, profile_events: int = 0, march_min_pixels: int = 0, march_np: int = 0,
-                 march_rows: int = 0, march_smooth: int = 0, early_exit_threshold: float = 0.0, small_max_pixels: int = 0):
+                 march_rows: int = 0, march_smooth: int = 0, early_exit_threshold: float = 0.0, small_max_pixels: int = 0,
+                 lr_check_threshold: float = 0.0):
         lib = load()
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))
@@ -185,6 +192,7 @@ class Context:
         cfg.march_smooth = int(march_smooth)
         cfg.early_exit_threshold = float(early_exit_threshold)
         cfg.small_max_pixels = int(small_max_pixels)
+        cfg.lr_check_threshold = float(lr_check_threshold)
         self.cfg = cfg
         self._pinned = []
         self._h = C.c_void_p()

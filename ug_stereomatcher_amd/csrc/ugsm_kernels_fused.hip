@@ -14,7 +14,6 @@
 // Citations: /root/reference/src/gpu_matcher/<file>:<line>.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
-#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -692,15 +691,10 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 // VAR (development switches, tools/kbench.hip): bit 0 = literal per-plane division, bit 1 = per-pixel border selects
 // instead of the replica / repair scheme, bit 2 = west/east neighbours from LDS instead of the neighbouring lanes,
 // bit 3 = the box's halo without the box.  Product: VAR = 0.
-// BOX: with the 3x3 box after the passes -- a template parameter since round 3: with the prefetch of the next tile issued at ONE
-// point of straight-line code the 39 registers in flight stay registers; issued in both arms of a run-time branch they met in a
-// phi that the register allocator routed through scratch memory.
-template <int STX, int STY, int NT, int VAR = 0, bool BOX = true>
-__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int /*do_box: see BOX*/,
+template <int STX, int STY, int NT, int VAR = 0>
+__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
                                                   int tiles_x, int n_tiles)
 {
-    constexpr bool do_box = BOX;
-    constexpr bool EARLY = (VAR & 16) != 0;  // development: the next tile's loads before the final stage's stores instead of after them
     constexpr int HX = 8, HY = 7;
     constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
     constexpr int LW = RWID + 4;             // LDS row stride: +4 keeps rows 16-B aligned and off a 32-bank multiple
@@ -713,85 +707,50 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *f0 = smem, *f1 = smem + LH * LW, *f2 = smem + 2 * LH * LW;
 
-    const int tid0 = threadIdx.x;
+    const int tid = threadIdx.x;
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
+    const int tx0 = tile_x * STX, ty0 = tile_y * STY;
+    const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
     const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
 
-    // PERSISTENT WORKGROUPS.  The launcher starts at most as many workgroups as are resident at once (two per CU for the
-    // 112 x 36 tile) and each walks the tiles vb = blockIdx.x, + gridDim.x, ...  A workgroup that is launched per tile pays, between
-    // the last pass of one tile and the first pass of the next on its CU slot: the drain of its stores, the dispatch of its
-    // successor and a full HBM round trip for the successor's loads -- about 10 us per tile at 16 MP, during which the other
-    // workgroup of the CU computes alone at two waves per SIMD (round 2: load + store 81 us, five passes 98 us, together
-    // 179 us).  Here the next tile's loads are issued into registers BEFORE the current tile's last write-back, box and
-    // copy-out, the stores drain under the next tile's passes, and nothing is dispatched in between.
-    // ---- loads of a tile + needed halo (clamped onto the image) into registers: every global load of the thread is
-    // issued back to back (a rolled loop waits out one HBM round trip per 512 pixels).  Which region cells a thread
-    // loads does not depend on the tile.
-    constexpr int NLD = (LH * RWID + NT - 1) / NT;
-    const int ld_r_lo = HY - h, ld_r_hi = LH - (HY - h);
-    auto issue_loads = [&](const int vb, float (&pv)[NLD][3]) {
-        // (tid through an opaque move: the slot -> cell arithmetic below is then recomputed per tile, ~10 integer operations per
-        // load; hoisted out of the tile loop as loop invariants it would hold ~40 registers across every pass)
-        int tid_l = tid0;
-        asm volatile("" : "+v"(tid_l));
-        int ptx, pty;
-        xcd_tile_at(vb, n_tiles, tiles_x, ptx, pty);
-        const int px0 = ptx * STX - HX, py0 = pty * STY - HY;
+    // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
+    // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
+    {
+        const int r_lo = HY - h, r_hi = LH - (HY - h);
+        constexpr int NLD = (LH * RWID + NT - 1) / NT;
+        float v[NLD][3];
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
-            // every slot loads, unconditionally (a "load or zero" select makes the compiler branch around each load and wait for
-            // it): a cell outside the needed region fetches the nearest needed cell instead -- a line the workgroup reads
-            // anyway -- and what lands in LDS there is never read
-            const int it = min(tid_l + u * NT, LH * RWID - 1);
+            const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            const int rr = clampi(r, ld_r_lo, ld_r_hi - 1), cc = clampi(c, HX - h, RWID - (HX - h) - 1);
-            const int gx = clampi(px0 + cc, 0, W - 1), gy = clampi(py0 + rr, 0, H - 1);
+            const bool need = it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
+            const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
             // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
             // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
             const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
-            pv[u][0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off);
-            pv[u][1] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off);
-            pv[u][2] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off);
+            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
+            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
+            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 0.0f;
         }
-    };
-    auto fill_lds = [&](const float (&pv)[NLD][3]) {
-        int tid_f = tid0;
-        asm volatile("" : "+v"(tid_f));
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
-            const int it = min(tid_f + u * NT, LH * RWID - 1);  // (the surplus slots of the last round rewrite the last cell with its own value)
+            const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            f0[r * LW + c] = pv[u][0];
-            f1[r * LW + c] = pv[u][1];
-            f2[r * LW + c] = pv[u][2];
+            if (it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+                f0[r * LW + c] = v[u][0];
+                f1[r * LW + c] = v[u][1];
+                f2[r * LW + c] = v[u][2];
+            }
         }
-    };
-    {
-        float pv0[NLD][3];
-        issue_loads((int)blockIdx.x, pv0);
-        fill_lds(pv0);
     }
     __syncthreads();
 
-  for (int vb = (int)blockIdx.x; vb < n_tiles; vb += (int)gridDim.x) {
-    // The thread index through an opaque move, once per tile: everything a thread derives from it (its LDS cells, quad, row group,
-    // box rows) is then recomputed per tile -- a few hundred integer operations -- instead of being hoisted out of the tile loop as
-    // ~100 loop-invariant registers, which the compiler then spills (63 spilled VGPRs and 200 KB of scratch traffic per tile when
-    // this loop was first written: slower than one workgroup per tile).
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int q = lane % QW, rg = (tid >> 6) * RPW + lane / QW;
-    const int c0 = q * 4;
+    const int c0 = q * 4, gx0 = x0 + c0;
     const bool lane_on = lane < RPW * QW;
-    const int vb_next = vb + (int)gridDim.x;  // (workgroup-uniform)
-    const bool has_next = vb_next < n_tiles;
-    float pv[NLD][3];  // the next tile, in flight from the prefetch below to the LDS fill at the end of this iteration
-    int tile_x, tile_y;
-    xcd_tile_at(vb, n_tiles, tiles_x, tile_x, tile_y);
-    const int tx0 = tile_x * STX, ty0 = tile_y * STY;
-    const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
-    const int gx0 = x0 + c0;
 
     // Image borders without per-pixel selects.  smoothKernel clamps x+1 / y+1 at the last column / row and leaves
     // row 0 / column 0 untouched (MatchLib.cu:1105-1143).  Here every cell of the region is computed alike; the
@@ -803,7 +762,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     // (VAR & 2, development: the earlier per-pixel selects.)
     const bool edge_e = x0 + RWID > W, edge_s = y0 + LH > H, edge_nw = x0 <= 0 || y0 <= 0;
 
-    auto do_pass = [&](const int p) {
+    for (int p = 1; p <= P; p++) {
         // pass p is needed (and valid) on the region shrunk to halo h-p
         const int r_lo = HY - (h - p), r_hi = LH - (HY - (h - p));
         const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p)));
@@ -913,8 +872,6 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
             __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
         }
-        // the next tile's loads leave now, in the last pass, after its arithmetic (the row operands are dead, the results wait
-        // in nv for the barrier): they have the write-back, the box and the copy-out to arrive
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < MAXR; u++) {
@@ -940,8 +897,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
             __syncthreads();
         }
-    };
-    for (int p = 1; p <= P; p++) do_pass(p);
+    }
 
     if (do_box) {
         // refresh the clamped replicas of out-of-image cells within tile+-2 (only edge tiles have any)
@@ -956,46 +912,41 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
             __syncthreads();
         }
-        // rows (Ta): tile columns, rows tile-2 .. tile+STY+1, rounded to f32, written back in place.  A row pass reads and writes one
-        // row only, and all the quads of a row sit in ONE wave (a row takes a power-of-two group of lanes), which issues its reads
-        // before its writes: no barrier between them and nothing held in registers across one (round 2 kept all the rows of a
-        // thread, 36 registers, from a read loop over a barrier to a write loop).
-        constexpr int BQ = STX / 4, BRG = NT / BQ;
-        constexpr int BQP = BQ <= 8 ? 8 : (BQ <= 16 ? 16 : 32);  // lanes per row
-        constexpr int BROWS = (NT / 64) * (64 / BQP);            // rows in flight per workgroup
-        {
-            const int rq = lane % BQP, rslot = (tid >> 6) * (64 / BQP) + lane / BQP;
+        // rows (Ta): tile columns, rows tile-2 .. tile+STY+1, rounded to f32, written back in place
+        constexpr int BQ = STX / 4, BRG = NT / BQ, BMAXR = (STY + 4 + BRG - 1) / BRG;
+        const int bq = tid % BQ, brg = tid / BQ;
+        const int bc0 = HX + bq * 4;
+        float bv[BMAXR][3][4];
 #pragma unroll
-            for (int u = 0; u < (STY + 4 + BROWS - 1) / BROWS; u++) {
-                const int r = HY - 2 + rslot + u * BROWS;
-                if (rq < BQ && r < HY + STY + 2) {
-                    const int at = r * LW + HX + rq * 4;
-                    float b3[3][4];
+        for (int u = 0; u < BMAXR; u++) {
+            const int r = HY - 2 + brg + u * BRG;
+            if (brg < BRG && r < HY + STY + 2) {
+                const int at = r * LW + bc0;
 #pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        const float *src = (f == 0 ? f0 : (f == 1 ? f1 : f2)) + at;
-                        float v[12];
-                        ld4(src - 4, v); ld4(src, v + 4); ld4(src + 4, v + 8);
+                for (int f = 0; f < 3; f++) {
+                    const float *src = (f == 0 ? f0 : (f == 1 ? f1 : f2)) + at;
+                    float v[12];
+                    ld4(src - 4, v); ld4(src, v + 4); ld4(src + 4, v + 8);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) b3[f][i] = box5f(v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
-                    }
-                    // (every ds_read above has returned to this wave before the first ds_write below is issued: the writes
-                    // depend on all twelve reads of all three fields through b3)
-                    st4(f0 + at, b3[0]); st4(f1 + at, b3[1]); st4(f2 + at, b3[2]);
+                    for (int i = 0; i < 4; i++) bv[u][f][i] = box5f(v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]);
                 }
             }
         }
         __syncthreads();
-        const int bq = tid % BQ, brg = tid / BQ;
-        const int bc0 = HX + bq * 4;
+#pragma unroll
+        for (int u = 0; u < BMAXR; u++) {
+            const int r = HY - 2 + brg + u * BRG;
+            if (brg < BRG && r < HY + STY + 2) {
+                const int at = r * LW + bc0;
+                st4(f0 + at, bv[u][0]); st4(f1 + at, bv[u][1]); st4(f2 + at, bv[u][2]);
+            }
+        }
+        __syncthreads();
         // columns (Ta) into registers, then back to LDS and out with lanes along the rows: a quad-per-lane
         // store touches one 16-B piece per lane (4 instructions per 1-KiB row segment); the copy-out below
         // writes whole contiguous segments
         constexpr int CMAXR = (STY + BRG - 1) / BRG;
         float cv[CMAXR][3][4];
-        if constexpr (EARLY) {
-            if (has_next) issue_loads(vb_next, pv);
-        }
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
             const int r = HY + brg + u * BRG;
@@ -1023,7 +974,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                         *reinterpret_cast<float4 *>(o3 + f * n + at) = make_float4(cv[u][f][0], cv[u][f][1], cv[u][f][2], cv[u][f][3]);
                 }
             }
-        } else {
+            return;
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
@@ -1045,11 +997,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                 o3[2 * n + at] = f2[la];
             }
         }
-        }
     } else {
-        if constexpr (EARLY) {
-            if (has_next) issue_loads(vb_next, pv);
-        }
         for (int it = tid; it < STX * STY; it += NT) {
             const int r = it / STX, c = it - r * STX;
             const int gx = tx0 + c, gy = ty0 + r;
@@ -1062,17 +1010,6 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
     }
-    if (!has_next) break;
-    // The next tile's loads: issued here, after this tile's stores, into registers that nothing else wants (issued any earlier --
-    // before the box or before the copy-out, to have them arrive under that work -- the 39 values do not fit beside it at 128
-    // registers: the allocator spilled some of them behind an s_waitcnt vmcnt(0) each, i.e. serialised the round trips).  What a
-    // persistent workgroup saves is the drain of its stores and the dispatch of a successor; the round trip of the loads is
-    // covered by the CU's other workgroup.
-    if constexpr (!EARLY) issue_loads(vb_next, pv);
-    __syncthreads();  // every read of this tile's LDS fields is done: the next tile may be written
-    fill_lds(pv);
-    __syncthreads();
-  }  // tiles of this workgroup
 }
 
 // =========================================================================================
@@ -1279,13 +1216,6 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 #ifndef UGSM_SMOOTH_SMALL_NT
 #define UGSM_SMOOTH_SMALL_NT 512
 #endif
-// development switch (tools/kbench.hip mode 11): 1 = persistent workgroups (at most as many as are resident, each walking several
-// tiles); 0 (product) = one workgroup per tile.  Measured in round 3 (MI355X, 16 MP, same box): persistent 207.6 / 244.1 us against
-// 185.4 / 215.7 us per tile-per-workgroup launch (five passes / five passes + box); 8 MP: 109.1 / 131.3 against 101.3 / 120.4.
-// The persistent form cannot start the next tile's loads before this tile's stores (39 registers in flight do not fit beside the box
-// or the copy-out at 128 registers; issued after the stores they wait behind them in the in-order vmcnt queue), and the hardware
-// dispatcher balances tiles over CU slots dynamically, which a static tile walk does not.
-int smooth_persistent = 0;
 template <int STX, int STY, int NT>
 static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
 {
@@ -1298,25 +1228,11 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         attr_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + STY - 1) / STY);
-    // persistent workgroups: as many as are resident at once (a multiple of 8, so that a workgroup's tiles stay on its XCD: xcd_tile_at);
-    // each walks the tiles blockIdx.x, + grid, ...  A level with fewer tiles than that gets one workgroup per tile, as before.
-    static std::atomic<int> resident[64];
-    int slots = resident[dev & 63].load(std::memory_order_relaxed);
-    if (slots == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT, 0, true>), NT, bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        slots = std::max(8, (per_cu * cus) & ~7);
-        resident[dev & 63].store(slots, std::memory_order_relaxed);
-    }
-    const int grid = (smooth_persistent && n_tiles > slots) ? slots : n_tiles;
-    if (do_box) hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, true>), dim3(grid), dim3(NT), bytes, st, s3, o3, W, H, passes, 1, tiles_x, n_tiles);
-    else hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, false>), dim3(grid), dim3(NT), bytes, st, s3, o3, W, H, passes, 0, tiles_x, n_tiles);
+    hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles);
 }
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)

@@ -280,6 +280,35 @@ void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
 {
     hipLaunchKernelGGL(k_box, grid2(W, H, 3), dim3(256), 0, st, s3, o3, W, H);
 }
+// --------------------------------------------------------------------------------------
+// LR-consistency check (BASELINE.json north_star; the reference has none: SURVEY.md 0.4 -- the build's own definition, DESIGN.md
+// section 8; opt-in, off in every parity run).  left3 / right3: (dx, dy, conf) of the left-to-right match and of the match with the
+// images exchanged.  Left pixel (x, y) matches right pixel (x + dx, y + dy) (getPointCloud.cpp:910-913); the right field is fetched
+// there as the matcher fetches (tex_index on the warp's float coordinate, MatchLib.cu:510-515) and must point back within tau in x
+// and in y, or the left confidence becomes 0.  `marked` (may be null) counts the pixels.  One pass: 12 B read + gather, 4 B written.
+__global__ __launch_bounds__(256) void k_lr_check(float *__restrict__ left3, const float *__restrict__ right3, int W, int H, float tau,
+                                                  unsigned long long *__restrict__ marked)
+{
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y;
+    bool bad = false;
+    if (ix < W) {
+        const size_t n = (size_t)W * H, at = (size_t)iy * W + ix;
+        const float dxl = left3[at], dyl = left3[n + at];
+        const int sx = tex_index(((float)ix + 0.5f) + dxl, W), sy = tex_index(((float)iy + 0.5f) + dyl, H);
+        const size_t rt = (size_t)sy * W + sx;
+        const float ex = fabsf(dxl + right3[rt]), ey = fabsf(dyl + right3[n + rt]);
+        bad = !(ex <= tau) || !(ey <= tau);
+        if (bad) left3[2 * n + at] = 0.0f;
+    }
+    if (marked) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(marked, (unsigned long long)__builtin_popcountll(m));
+    }
+}
+void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, int H, float tau, unsigned long long *marked)
+{
+    hipLaunchKernelGGL(k_lr_check, grid2(W, H), dim3(256), 0, st, left3, right3, W, H, tau, marked);
+}
 void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch)
 {
     hipLaunchKernelGGL(k_copy_view, grid2(W, H, 3), dim3(256), 0, st, src, W, H, dst, dst_plane, dst_pitch);

@@ -34,6 +34,8 @@ void launch_cost_ref(hipStream_t st, Img3 L, const float *Rw3, const float *A3, 
 void launch_smooth_pass_ref(hipStream_t st, const float *s3, float *o3, int W, int H);
 void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H);
 void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch);
+// LR-consistency check (north_star; no reference counterpart): zeroes the confidence of left3 where right3 does not point back within tau
+void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, int H, float tau, unsigned long long *marked);
 
 // ---- kernel_path 0 (ugsm_kernels_fused.hip) -----------------------------------------
 // One iteration's warp + cost + parabola + update, LDS-tiled.

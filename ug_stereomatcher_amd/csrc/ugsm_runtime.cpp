@@ -17,7 +17,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -53,6 +58,19 @@ struct Slot {
     float *pyrL = nullptr, *pyrR = nullptr;
     size_t pyr_cap = 0;  // floats
     float *A = nullptr, *Rw = nullptr, *B = nullptr, *d0 = nullptr, *d1 = nullptr;
+    // Side stream of the slot (round 3): the right image's upload and pyramid, and then A = G_clamp * L^2 of every full-frame level
+    // (MatchGPULib.cpp:1866-1875, once per level), run there beside the left pyramid and the coarse levels' iterations -- launches
+    // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
+    // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev_in = nullptr, ev_L = nullptr, ev_R = nullptr, ev_A[UGSM_MAX_LEVELS] = {};
+    float *lr = nullptr;     // LR check: the right-to-left field of level 0 (3 planes) + one 8-byte counter behind it
+    size_t lr_cap = 0;
+    unsigned long long *lr_host = nullptr;  // page-locked copy of the counter
+    bool lr_ran = false;
+    float *Apyr = nullptr;   // A of level i at Apyr + off[i] (same layout as the pyramids)
+    size_t apyr_cap = 0;
+    int a_from = -1;         // levels a_from .. top have their A in Apyr (ev_A recorded); -1: none (A is computed in line)
     size_t lvl_cap = 0;  // floats per 3-plane level buffer
     uint8_t *rgbL = nullptr, *rgbR = nullptr;
     size_t rgb_cap = 0;
@@ -76,14 +94,92 @@ struct Slot {
     std::vector<hipEvent_t> pool;
 };
 
+// A persistent team of host threads for the service path's page touching and staging copies (the first version
+// created ~29 std::threads per call; a failed creation -- EAGAIN under a thread or cgroup limit -- threw through an extern "C"
+// entry point with joinable threads on the stack, i.e. std::terminate in the caller's process).  Workers are created once, on the
+// first service call; creation failures are caught and the team simply stays smaller (down to the calling thread alone).
+class HostTeam {
+public:
+    explicit HostTeam(unsigned want)
+    {
+        for (unsigned t = 1; t < want; t++) {
+            try {
+                workers_.emplace_back([this, t] { loop(t); });
+            } catch (const std::system_error &) {
+                break;  // no more threads to be had: run with what there is
+            }
+        }
+    }
+    ~HostTeam()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (std::thread &t : workers_) t.join();
+    }
+    unsigned size() const { return (unsigned)workers_.size() + 1; }
+    // f(member, members) on every member; the caller is member 0.  Returns when all are done.  f must not throw.
+    void run(const std::function<void(unsigned, unsigned)> &f)
+    {
+        const unsigned n = size();
+        if (n == 1) {
+            f(0, 1);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &f;
+            pending_ = n - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        f(0, n);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(unsigned me)
+    {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(unsigned, unsigned)> *job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                job = job_;
+            }
+            if (job) (*job)(me, size());
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned, unsigned)> *job_ = nullptr;
+    unsigned gen_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 struct ugsm_ctx {
+    std::unique_ptr<HostTeam> team;  // service path only; created on first use (host_team below)
     ugsm_config cfg;
     std::vector<Slot> slots;
     std::string err;
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
+    int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
 };
 
 namespace {
@@ -239,6 +335,7 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H)
     for (int i = 0; i < UGSM_MAX_LEVELS; i++) s.iters_run[i] = -1;
     s.have_pyr = false;
     s.have_coarse = false;
+    s.a_from = -1;
     if (tot > s.pyr_cap) {
         size_t cap = s.pyr_cap;
         UCHK(grow(ctx, s.pyrL, cap, tot));
@@ -309,6 +406,7 @@ struct DevKnobs {
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
+    int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
 };
 bool dev_env_on()
 {
@@ -329,6 +427,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_SMALL_MASK", k.small_mask);
     geti("UGSM_FUSE_SEED", k.fuse_seed);
     geti("UGSM_COARSE_GRAPH", k.graph);
+    geti("UGSM_TWO_STREAMS", k.two_streams);
     int rh = 0;
     geti("UGSM_SMALL_RH", rh);
     if (rh == 18 || rh == 24 || rh == 32) k.small_rh_force = rh;
@@ -336,8 +435,9 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
 
 // ---- stages ----------------------------------------------------------------------------
 
-int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int stride, float *pyr)
+int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int stride, float *pyr, hipStream_t stream = nullptr)
 {
+    const hipStream_t pst = stream ? stream : s.st;  // (launches on the side stream are not bracketed by events: Timer records on s.st)
     const int levels = s.levels;
     const bool ref = ctx->cfg.kernel_path == 1;
     // levels 0, 1, 2 in one pass over the rgb8 input (k_pyr_base); the one-stage-per-kernel path keeps the three launches
@@ -345,10 +445,10 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     s.cur_level = 0;
     if (base) {
         Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H);
-        launch_pyr_base(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad);
+        launch_pyr_base(pst, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad);
     } else {
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
-        launch_rgb_planes(s.st, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
+        launch_rgb_planes(pst, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
     }
     // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
@@ -357,15 +457,15 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
             s.cur_level = 1;
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
             float sf = (float)kScale;
-            if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
-            else launch_blur_decimate(s.st, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad);
+            if (ref) launch_blur_decimate_ref(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
+            else launch_blur_decimate(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad);
         }
         if (i + 2 < levels && !(base && i == 0)) {
             s.cur_level = i + 2;
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
-            if (ref) launch_blur_decimate_ref(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
-            else launch_blur_decimate(s.st, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad);
+            if (ref) launch_blur_decimate_ref(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
+            else launch_blur_decimate(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad);
         }
     }
     s.cur_level = kNoLevel;
@@ -480,8 +580,11 @@ int weighted_difference(ugsm_ctx *ctx, Slot &s, const float *newd3, const float 
 // (saves the device-to-device copy of the finished level); cur/other are then not meaningful afterwards.
 // seed (optional, see fuse_seed): `cur` holds the COARSER level's field (seed->Ws x seed->Hs) and iteration m_from reads its starting
 // field through the seeding map instead of from a materialised seeded field.
+// A_pre (optional): A = G_clamp * L^2 of this level, already computed (on the slot's side stream; the caller has made the main
+// stream wait for it); otherwise it is computed here, into s.A.
 int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int mi, int S, bool is_top, int m_from,
-              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr, const SeedMap *seed = nullptr)
+              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr, const SeedMap *seed = nullptr,
+              const float *A_pre = nullptr)
 {
     const bool ref = ctx->cfg.kernel_path == 1;
     const double px = (double)W * H;
@@ -500,7 +603,8 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
         final_out = nullptr;
     }
     int ran = 0;
-    {   // A = G_clamp * L^2 does not depend on the iteration: once per level.
+    const float *const A3 = A_pre ? A_pre : s.A;
+    if (!A_pre) {   // A = G_clamp * L^2 does not depend on the iteration: once per level.
         Timer t(ctx, &s, si, KC_SQBLUR, px);
         if (ref) launch_sqblur_clamp_ref(s.st, L, W, H, s.A);
         else launch_sqblur_clamp(s.st, L, W, H, s.A);
@@ -517,16 +621,16 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
                 launch_sqblur_clamp_ref(s.st, Img3{s.Rw, W, (size_t)W * H}, W, H, s.B);
             }
             Timer t(ctx, &s, si, KC_COST, px);
-            launch_cost_ref(s.st, L, s.Rw, s.A, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
+            launch_cost_ref(s.st, L, s.Rw, A3, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
             const bool march = use_march(ctx->cfg, W, H);
             const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H) != 0;
             Timer t(ctx, &s, si, march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST), px);
             if (march && seed && m == m_from)
-                launch_cost_march_seeded(s.st, L, R, s.A, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
-            else if (march) launch_cost_march(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend, 0, 1, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
-            else if (small) launch_cost_small(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
-            else launch_cost_fused(s.st, L, R, s.A, cur, other, W, H, thr[m - 1], blend);
+                launch_cost_march_seeded(s.st, L, R, A3, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            else if (march) launch_cost_march(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, 1, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+            else if (small) launch_cost_small(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
+            else launch_cost_fused(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
         }
         ran = m;
         if (early) {
@@ -557,7 +661,10 @@ Img3 level_view(const Slot &s, const float *pyr, int lev, int ox, int oy)
     return Img3{pyr + s.off[lev] + (size_t)oy * s.w[lev] + ox, s.w[lev], (size_t)s.w[lev] * s.h[lev]};
 }
 
-int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride)
+// a_from: the levels a_from .. top get their A = G_clamp * L^2 precomputed on the side stream (full mode: 0; foveated: F-1, the
+// fine levels work on crops whose A is clamped at the crop's own border and is computed in line); < 0: none.
+// side_in: the right image's upload is already in flight on the side stream (stage_in), so the fork event is not needed for it.
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int a_from = -1)
 {
     if (!d_rgbL || !d_rgbR) return UGSM_ERR_BAD_ARG;
     if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
@@ -565,16 +672,55 @@ int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, cons
     // the pyramid kernels of the fused path check every value they write (level 0 holds the integers 0..255)
     s.range_known = ctx->cfg.kernel_path != 1 && s.range_bad != nullptr;
     if (s.range_known) HIPCHK(ctx, hipMemsetAsync(s.range_bad, 0, sizeof(unsigned), s.st));
+    // One stream, as in rounds 1 and 2: the one-stage-per-kernel path, and whenever launches are bracketed by events (the
+    // statistics belong to one stream).  Otherwise fork: R's pyramid and the A planes on the side stream.
+    const bool fork = s.st2 != nullptr && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams;
+    s.a_from = -1;
+    if (!fork) {
+        UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
+        UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR));
+        s.have_pyr = true;
+        return UGSM_OK;
+    }
+    // the side stream starts after everything enqueued on this slot so far (the previous pair still reads pyrR and Apyr)
+    HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
+    HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
+    UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2));
+    HIPCHK(ctx, hipEventRecord(s.ev_R, s.st2));
     UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
-    UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR));
+    if (a_from >= 0 && !(ctx->cfg.early_exit_threshold > 0.0f)) {
+        size_t tot = s.off[s.levels - 1] + 3 * (size_t)s.w[s.levels - 1] * s.h[s.levels - 1];
+        UCHK(grow(ctx, s.Apyr, s.apyr_cap, tot));
+        HIPCHK(ctx, hipEventRecord(s.ev_L, s.st));
+        HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_L, 0));
+        for (int i = s.levels - 1; i >= a_from; i--) {  // coarsest first: that is the order the levels need them in
+            launch_sqblur_clamp(s.st2, level_view(s, s.pyrL, i, 0, 0), s.w[i], s.h[i], s.Apyr + s.off[i]);
+            HIPCHK(ctx, hipEventRecord(s.ev_A[i], s.st2));
+        }
+        s.a_from = a_from;
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(s.st, s.ev_R, 0));
+    HIPCHK(ctx, hipGetLastError());
     s.have_pyr = true;
     return UGSM_OK;
 }
 
+// A of full-frame level i if it was precomputed on the side stream (the main stream is made to wait for it here), else null
+const float *level_A(ugsm_ctx *ctx, Slot &s, int i)
+{
+    if (s.a_from < 0 || i < s.a_from) return nullptr;
+    if (hipStreamWaitEvent(s.st, s.ev_A[i], 0) != hipSuccess) return nullptr;
+    (void)ctx;
+    return s.Apyr + s.off[i];
+}
+
 // matching() with foveatedmatching==0, MatchGPULib.cpp:1196-1318
-int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
+// swap: the images exchanged (the right-to-left match of the LR check): the right pyramid is the "left" image; A is then computed
+// in line (the side stream's A planes belong to the left image).
+int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out, bool swap = false)
 {
     const int levels = s.levels;
+    const float *const pL = swap ? s.pyrR : s.pyrL, *const pR = swap ? s.pyrL : s.pyrR;
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
@@ -585,8 +731,9 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
         const int mi = level_iterations(i);
         // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
         const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0 && !(ctx->cfg.early_exit_threshold > 0.0f);
-        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr, seeded ? &sm : nullptr));
+        UCHK(run_level(ctx, s, si, level_view(s, pL, i, 0, 0), level_view(s, pR, i, 0, 0), s.w[i], s.h[i], mi,
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr, seeded ? &sm : nullptr,
+                       swap ? nullptr : level_A(ctx, s, i)));
         if (direct) return UGSM_OK;
         seeded = false;
         if (i > 0) {
@@ -604,6 +751,30 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
     return UGSM_OK;
 }
 
+// Full mode with the optional LR-consistency check (ugsm_config.lr_check_threshold; no reference counterpart): the match, the match
+// with the images exchanged into the slot's own buffer, then one kernel that zeroes the inconsistent confidences of d_out.
+int enqueue_full_lr(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
+{
+    s.lr_ran = false;
+    UCHK(enqueue_full(ctx, s, si, d_out));
+    const float tau = ctx->cfg.lr_check_threshold;
+    if (!(tau > 0.0f)) return UGSM_OK;
+    const size_t n3 = 3 * (size_t)s.W * s.H;
+    UCHK(grow(ctx, s.lr, s.lr_cap, n3 + 4));
+    if (!s.lr_host) HIPCHK(ctx, hipHostMalloc((void **)&s.lr_host, sizeof(unsigned long long), hipHostMallocDefault));
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(s.lr + ((n3 + 1) & ~(size_t)1));  // (8-byte aligned)
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof *cnt, s.st));
+    UCHK(enqueue_full(ctx, s, si, s.lr, true));
+    {
+        Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
+        launch_lr_check(s.st, d_out, s.lr, s.W, s.H, tau, cnt);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s.lr_host, cnt, sizeof *cnt, hipMemcpyDeviceToHost, s.st));
+    HIPCHK(ctx, hipGetLastError());
+    s.lr_ran = true;
+    return UGSM_OK;
+}
+
 // matching() with foveatedmatching==1 (MatchGPULib.cpp:1230-1294), split at level F-1.
 int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
 {
@@ -618,7 +789,7 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
         s.cur_level = i;
         const int mi = level_iterations(i);
         UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr));
+                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr, level_A(ctx, s, i)));
         seeded = false;
         if (i > F - 1) {
             if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1])) {
@@ -695,7 +866,15 @@ int stage_in(ugsm_ctx *ctx, Slot &s, const uint8_t *rgbL, const uint8_t *rgbR, i
         UCHK(grow(ctx, s.rgbR, s.rgb_cap, bytes));
     }
     HIPCHK(ctx, hipMemcpyAsync(s.rgbL, rgbL, bytes, hipMemcpyHostToDevice, s.st));
-    HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st));
+    // the right image goes up on the side stream, where its pyramid is built: the transfer (0.9 ms at 16 MP) then runs under the
+    // left pyramid instead of in front of it.  The side stream first waits for what the slot did before.
+    if (s.st2 && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams) {
+        HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
+        HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
+        HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st2));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st));
+    }
     return UGSM_OK;
 }
 
@@ -714,46 +893,56 @@ bool is_pinned(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
-void team_copy(void *dst, const void *src, size_t bytes)
+// The context's host team (UGSM_COPY_THREADS members, default min(8, hardware threads); 1 = the calling thread only).  Never throws.
+HostTeam *host_team(ugsm_ctx *ctx)
 {
-    static const unsigned team = [] {
+    if (!ctx->team) {
         const char *e = getenv("UGSM_COPY_THREADS");
         unsigned n = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-        return std::max(1u, n);
-    }();
-    if (team == 1 || bytes < (1u << 22)) {
+        n = std::min(std::max(1u, n), 64u);
+        try {
+            ctx->team.reset(new HostTeam(n));
+        } catch (...) {  // (allocation failure of the team object itself)
+            return nullptr;
+        }
+    }
+    return ctx->team.get();
+}
+
+constexpr size_t kTeamMinBytes = 1u << 22;  // below 4 MB a single memcpy / page walk is faster than waking the team
+
+void team_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HostTeam *team = bytes >= kTeamMinBytes ? host_team(ctx) : nullptr;
+    if (!team || team->size() == 1) {
         memcpy(dst, src, bytes);
         return;
     }
-    const size_t chunk = ((bytes / team) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < team; t++) {
-        const size_t off = t * chunk;
-        if (off >= bytes) break;
-        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, std::min(chunk, bytes - off)); });
-    }
-    memcpy(dst, src, std::min(chunk, bytes));
-    for (std::thread &t : th) t.join();
+    team->run([=](unsigned t, unsigned n) {
+        const size_t chunk = ((bytes / n) + 4095) & ~(size_t)4095;
+        const size_t off = (size_t)t * chunk;
+        if (off < bytes) memcpy((char *)dst + off, (const char *)src + off, std::min(chunk, bytes - off));
+    });
 }
 
 // First touch of the caller's (possibly fresh) result pages by the host team WHILE the GPU is still matching: every page of
 // dst[0..2] gets one byte written (the planes are overwritten in full afterwards), so the page faults are off the critical path.
-void prefault_planes(float *const dst[3], size_t plane_floats)
+void prefault_planes(ugsm_ctx *ctx, float *const dst[3], size_t plane_floats)
 {
-    if (is_pinned(dst[0]) && is_pinned(dst[1]) && is_pinned(dst[2])) return;
     const size_t pb = plane_floats * sizeof(float);
-    const unsigned team = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < team; t++)
-        th.emplace_back([=] {
-            for (int k = 0; k < 3; k++) {
-                volatile char *p = (volatile char *)dst[k];
-                const size_t lo = pb * t / team, hi = pb * (t + 1) / team;
-                for (size_t o = (lo + 4095) & ~(size_t)4095; o < hi; o += 4096) p[o] = 0;
-                if (t == 0 && pb) p[0] = 0;
-            }
-        });
-    for (std::thread &t : th) t.join();
+    if (pb < kTeamMinBytes) return;  // (a small call: the copy itself touches the pages)
+    if (is_pinned(dst[0]) && is_pinned(dst[1]) && is_pinned(dst[2])) return;
+    auto touch = [=](unsigned t, unsigned n) {
+        for (int k = 0; k < 3; k++) {
+            volatile char *p = (volatile char *)dst[k];
+            const size_t lo = pb * t / n, hi = pb * (t + 1) / n;
+            for (size_t o = (lo + 4095) & ~(size_t)4095; o < hi; o += 4096) p[o] = 0;
+            if (t == 0 && pb) p[0] = 0;
+        }
+    };
+    HostTeam *team = host_team(ctx);
+    if (team) team->run(touch);
+    else touch(0, 1);
 }
 
 int copy_out_planes(ugsm_ctx *ctx, Slot &s, const float *d_src, size_t plane_floats, float *const dst[3])
@@ -777,7 +966,7 @@ int copy_out_planes(ugsm_ctx *ctx, Slot &s, const float *d_src, size_t plane_flo
     }
     for (int k = 0; k < 3; k++) {
         HIPCHK(ctx, hipEventSynchronize(s.out_ev[k]));
-        team_copy(dst[k], s.hpin + k * plane_floats, pb);
+        team_copy(ctx, dst[k], s.hpin + k * plane_floats, pb);
     }
     return UGSM_OK;
 }
@@ -836,7 +1025,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         if (memcmp(g, k, sizeof g) != 0) return UGSM_ERR_STATE;
     }
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
-        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels)
+        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f))
         return UGSM_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return UGSM_ERR_NO_DEVICE;
@@ -847,9 +1036,17 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->small_mask = knobs.small_mask;
     ctx->fuse_seed = knobs.fuse_seed;
     ctx->small_rh_force = knobs.small_rh_force;
+    // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
+    // beside the left pyramid and the coarse levels).  With four pairs in flight it LOSES 13 % (136 against 157 pairs/s): eight
+    // streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So: one-slot contexts only.
+    ctx->two_streams = knobs.two_streams >= 0 ? knobs.two_streams : (cfg.slots == 1 ? 1 : 0);
     ctx->slots.resize(cfg.slots);
     for (Slot &s : ctx->slots) {
-        if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&s.range_bad, 64) != hipSuccess) {
+        bool ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&s.range_bad, 64) == hipSuccess &&
+                  hipStreamCreateWithFlags(&s.st2, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t *e : {&s.ev_in, &s.ev_L, &s.ev_R}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < cfg.levels; i++) ok = ok && hipEventCreateWithFlags(&s.ev_A[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             ugsm_destroy(ctx);
             return UGSM_ERR_DEVICE;
         }
@@ -864,6 +1061,7 @@ void ugsm_destroy(ugsm_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     for (Slot &s : ctx->slots) {
         if (s.st) (void)hipStreamSynchronize(s.st);
+        if (s.st2) (void)hipStreamSynchronize(s.st2);
         harvest(ctx, s);
         for (hipEvent_t e : s.pool) (void)hipEventDestroy(e);
         for (void *p : {(void *)s.pyrL, (void *)s.pyrR, (void *)s.A, (void *)s.Rw, (void *)s.B, (void *)s.d0, (void *)s.d1,
@@ -873,6 +1071,14 @@ void ugsm_destroy(ugsm_ctx *ctx)
         if (s.hpin) (void)hipHostFree(s.hpin);
         for (hipEvent_t e : s.out_ev)
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {s.ev_in, s.ev_L, s.ev_R})
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : s.ev_A)
+            if (e) (void)hipEventDestroy(e);
+        if (s.Apyr) (void)hipFree(s.Apyr);
+        if (s.lr) (void)hipFree(s.lr);
+        if (s.lr_host) (void)hipHostFree(s.lr_host);
+        if (s.st2) (void)hipStreamDestroy(s.st2);
         if (s.st) (void)hipStreamDestroy(s.st);
     }
     delete ctx;
@@ -947,7 +1153,7 @@ int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     Slot *s;
     UCHK(get_slot(ctx, slot, &s));
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    return enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride);
+    return enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, ctx->cfg.fovea_levels >= 2 ? ctx->cfg.fovea_levels - 1 : -1);
 }
 
 int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, float *d_out)
@@ -956,8 +1162,8 @@ int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8
     UCHK(get_slot(ctx, slot, &s));
     if (!d_out) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride));
-    return enqueue_full(ctx, *s, slot, d_out);
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, 0));
+    return enqueue_full_lr(ctx, *s, slot, d_out);
 }
 
 int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state)
@@ -987,9 +1193,9 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     UCHK(get_slot(ctx, slot, &s));
     if (!d_stack) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride));
     const int F = ctx->cfg.fovea_levels;
     if (F < 2) return UGSM_ERR_BAD_ARG;
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, F - 1));
     // level F-1's state is parked in the (otherwise idle) A buffer's tail? No: use a dedicated spot
     // at the end of d_stack's level F-1 block is not 3-plane contiguous, so stage through hout.
     const size_t fn3 = 3 * (size_t)s->w[F - 1] * s->h[F - 1];
@@ -1024,10 +1230,10 @@ int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int
     UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
     const size_t n = (size_t)W * H;
     UCHK(grow(ctx, s->hout, s->hout_cap, 3 * n));
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
-    UCHK(enqueue_full(ctx, *s, 0, s->hout));
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, 0));
+    UCHK(enqueue_full_lr(ctx, *s, 0, s->hout));
     float *const dst[3] = {dispH, dispV, dispC};
-    prefault_planes(dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
+    prefault_planes(ctx, dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
     UCHK(copy_out_planes(ctx, *s, s->hout, n, dst));
     return ugsm_wait(ctx, 0);
 }
@@ -1051,7 +1257,7 @@ int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR,
     float *d_state = s->hout, *d_stack = d_state + 3 * fn;
     float *d_pl = pyrL ? d_stack + 3 * stackn : nullptr;
     float *d_pr = pyrR ? d_stack + 3 * stackn + (pyrL ? 3 * stackn : 0) : nullptr;
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, F - 1));
     UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
     UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, d_pl, d_pr));
     HIPCHK(ctx, hipMemcpyAsync(stackH, d_stack, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
@@ -1078,12 +1284,12 @@ int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *
     const size_t fn = (size_t)fw * fh, stackn = (size_t)F * fn, n = (size_t)W * H;
     UCHK(grow(ctx, s->hout, s->hout_cap, 3 * fn + 3 * stackn + 3 * n));  // [state][stack][full field]
     float *d_state = s->hout, *d_stack = d_state + 3 * fn, *d_full = d_stack + 3 * stackn;
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride));
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, F - 1));
     UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
     UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, nullptr, nullptr));
     UCHK(ugsm_reconstruct_full(ctx, 0, d_stack, d_stack + stackn, d_stack + 2 * stackn, W, H, off_x, off_y, d_full));
     float *const dst[3] = {outH, outV, outC};
-    prefault_planes(dst, n);
+    prefault_planes(ctx, dst, n);
     UCHK(copy_out_planes(ctx, *s, d_full, n, dst));
     return ugsm_wait(ctx, 0);
 }
@@ -1274,6 +1480,41 @@ int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const flo
     if (!d_new3 || !d_old3 || !out2 || W < 1 || H < 1 || H > 65535 || (long long)W * H > kMaxPixels) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     return weighted_difference(ctx, *s, d_new3, d_old3, W, H, out2);
+}
+
+int ugsm_stage_lr_check(ugsm_ctx *ctx, float *d_left3, const float *d_right3, int W, int H, float tau, long long *marked)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, 0, &s));
+    if (!d_left3 || !d_right3 || W < 1 || H < 1 || H > 65535 || (long long)W * H > kMaxPixels || !(tau >= 0.0f)) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    UCHK(grow(ctx, s->lr, s->lr_cap, std::max<size_t>(s->lr_cap, 8)));
+    if (!s->lr_host) HIPCHK(ctx, hipHostMalloc((void **)&s->lr_host, sizeof(unsigned long long), hipHostMallocDefault));
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(s->lr);
+    HIPCHK(ctx, hipStreamSynchronize(s->st));  // (the counter shares the slot's LR buffer)
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof *cnt, s->st));
+    launch_lr_check(s->st, d_left3, d_right3, W, H, tau, cnt);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(s->lr_host, cnt, sizeof *cnt, hipMemcpyDeviceToHost, s->st));
+    UCHK(ugsm_wait(ctx, 0));
+    if (marked) *marked = (long long)*s->lr_host;
+    return UGSM_OK;
+}
+
+long long ugsm_last_lr_marked(ugsm_ctx *ctx, int slot)
+{
+    Slot *s;
+    if (get_slot(ctx, slot, &s) != UGSM_OK) return -1;
+    return (s->lr_ran && s->lr_host) ? (long long)*s->lr_host : -1;
+}
+
+int ugsm_slot_stream(ugsm_ctx *ctx, int slot, void **hip_stream)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (!hip_stream) return UGSM_ERR_BAD_ARG;
+    *hip_stream = (void *)s->st;
+    return UGSM_OK;
 }
 
 int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level)

@@ -133,11 +133,12 @@ def fovea_window_offsets(n_windows: int, W: int, H: int, fovW: int, fovH: int):
 # ---- the fovea-shard step (bench.py --workload fovea-shard) ------------------------------------------
 
 class UgsmShardDriver:
-    """The four C-ABI calls of one fovea-shard step on a Context, addressed by slot.  Tensors are torch CUDA tensors;
-    tests drive fovea_shard_step with a double that has the same four methods (tests/test_dist_gloo.py)."""
+    """The C-ABI calls of one fovea-shard step on a Context, addressed by slot.  Tensors are torch CUDA tensors;
+    tests drive fovea_shard_step with a double that has the same methods (tests/test_dist_gloo.py)."""
 
     def __init__(self, ctx):
         self.ctx = ctx
+        self._streams = {}
 
     def submit_pyramids(self, slot, L, R, W, H, stride):
         c = self.ctx
@@ -155,6 +156,34 @@ class UgsmShardDriver:
         c = self.ctx
         c.check(c.lib.ugsm_submit_fovea_fine(c.handle, slot, state.data_ptr(), off[0], off[1], out.data_ptr()))
 
+    # ---- device-side ordering between a slot's stream and the stream the collective is launched from (round 3) -------------
+    def orders_on_device(self, state: torch.Tensor) -> bool:
+        """True when the exchange can be ordered against the slot's work on the device: a CUDA tensor sent over RCCL (a gloo
+        broadcast works through the host and needs the data complete when it is called)."""
+        return bool(state.is_cuda) and dist.is_initialized() and dist.get_backend() == "nccl"
+
+    def _stream(self, slot):
+        st = self._streams.get(slot)
+        if st is None:
+            import ctypes
+            p = ctypes.c_void_p()
+            c = self.ctx
+            c.check(c.lib.ugsm_slot_stream(c.handle, slot, ctypes.byref(p)))
+            st = self._streams[slot] = torch.cuda.ExternalStream(p.value)
+        return st
+
+    def current_after_slot(self, slot):
+        """The current torch stream (the one the collective synchronises with) waits, on the device, for everything enqueued on the slot."""
+        ev = torch.cuda.Event()
+        ev.record(self._stream(slot))
+        torch.cuda.current_stream().wait_event(ev)
+
+    def slot_after_current(self, slot):
+        """The slot's stream waits, on the device, for everything enqueued on the current torch stream (the finished collective)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._stream(slot).wait_event(ev)
+
 
 def _collective_done(t: torch.Tensor):
     """Host waits for the collective that was just enqueued on the current stream -- for it alone, not for the device:
@@ -170,11 +199,25 @@ def fovea_shard_step(drv, slot: int, L, R, W: int, H: int, stride: int, state: t
     `state`; ONE broadcast of `state` (3 x fovH x fovW floats); every rank runs the fine levels of its window `off` into `out`.
     `state` belongs to `slot`: the caller reuses a slot (and its state buffer) only after drv.wait(slot), i.e. after the fine
     phase that reads the state has finished, so a later step's broadcast can never overwrite a state still in use; nothing
-    here synchronises the whole device, so the slots overlap."""
+    here synchronises the whole device, so the slots overlap.
+
+    Over RCCL the step never blocks the host (round 3): the collective's stream waits for the slot's coarse
+    phase through an event, and the slot's stream waits for the collective the same way, so rank `src` goes on submitting the
+    next pair's pyramids and coarse levels while this pair's state is still being computed and sent.  Over gloo (CPU rehearsals)
+    the data must be complete when the call is made: there the host waits for the slot first."""
     drv.submit_pyramids(slot, L, R, W, H, stride)
+    on_device = bool(getattr(drv, "orders_on_device", lambda t: False)(state))
     if rank == src:
         drv.submit_coarse(slot, state)
-        drv.wait(slot)  # the state is complete before it is sent
+        if on_device:
+            drv.current_after_slot(slot)  # (device-side: the broadcast reads the state after the coarse phase has written it)
+        else:
+            drv.wait(slot)  # the state is complete before it is sent
+    elif on_device:
+        drv.current_after_slot(slot)  # (a receiving rank: whatever still reads this slot's state buffer has been enqueued before)
     broadcast_coarse_state(state, src)
-    _collective_done(state)
+    if on_device:
+        drv.slot_after_current(slot)  # the fine phase starts, on the device, when the state has arrived
+    else:
+        _collective_done(state)
     drv.submit_fine(slot, state, off, out)
