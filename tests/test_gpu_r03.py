@@ -56,7 +56,7 @@ def test_lr_check_kernel_matches_the_oracle(lib, orc):
             c.free(pl)
             c.free(pr)
         assert_bit_equal(got, exp, f"lr check {W}x{H} tau={tau}")
-        assert marked.value == n_exp and 0 < n_exp < W * H
+        assert marked.value == n_exp and 0 < n_exp <= W * H and (tau == 0.0 or n_exp < W * H)
 
 
 def test_lr_check_through_the_matcher_and_off_by_default(lib, orc):

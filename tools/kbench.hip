@@ -62,9 +62,10 @@ int main(int argc, char **argv)
         return 0;
     }
 #ifdef UGSM_MARCH_STAMP
-    if (argc > 4 && atoi(argv[4]) == 6) {  // in-kernel clock of the marching K-cost under sustained launches: kbench_stamp W H reps 6
-        const int nb = 8192;
-        long long *dst; CK(hipMalloc(&dst, sizeof(long long) * 2 * nb)); CK(hipMemset(dst, 0, sizeof(long long) * 2 * nb));
+    if (argc > 4 && atoi(argv[4]) == 6) {  // in-kernel clock of the marching K-cost under sustained launches + where and when its waves ran: kbench_stamp W H reps 6
+        const int nb = 16384;
+        if (argc > 6) { march_age_permille[0] = atoi(argv[5]); march_age_permille[1] = atoi(argv[6]); printf("strips by age class: %d/%d/%d per mille\n", march_age_permille[0], march_age_permille[1], 1000 - march_age_permille[0] - march_age_permille[1]); }
+        long long *dst; CK(hipMalloc(&dst, sizeof(long long) * 4 * nb)); CK(hipMemset(dst, 0, sizeof(long long) * 4 * nb));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_march_stamps), &dst, sizeof(dst)));
         const auto t_start = std::chrono::steady_clock::now();
         int launches = 0;
@@ -73,18 +74,101 @@ int main(int argc, char **argv)
             CK(hipStreamSynchronize(st));
             launches += 50;
         }
-        std::vector<long long> hs(2 * nb);
-        CK(hipMemcpy(hs.data(), dst, sizeof(long long) * 2 * nb, hipMemcpyDeviceToHost));
+        CK(hipMemset(dst, 0, sizeof(long long) * 4 * nb));
+        launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb);  // the launch that is analysed
+        CK(hipStreamSynchronize(st));
+        std::vector<long long> hs(4 * (size_t)nb);
+        CK(hipMemcpy(hs.data(), dst, sizeof(long long) * 4 * nb, hipMemcpyDeviceToHost));
         std::vector<double> clk, cyc;
-        for (int b = 0; b < nb; b++) if (hs[2 * b + 1] > 0) { clk.push_back((double)hs[2 * b] / (double)hs[2 * b + 1] * 0.1); cyc.push_back((double)hs[2 * b]); }
+        struct Wv { long long key; long long start; double cycles; int wave; };
+        std::vector<Wv> wv;
+        long long t_min = -1;
+        for (int b = 0; b < nb; b++)
+            if (hs[4 * b + 1] > 0) {
+                clk.push_back((double)hs[4 * b] / (double)hs[4 * b + 1] * 0.1);
+                cyc.push_back((double)hs[4 * b]);
+                const unsigned hw = (unsigned)(hs[4 * b + 3] & 0xffffffff), xcc = (unsigned)(hs[4 * b + 3] >> 32) & 0xf;
+                const long long key = ((long long)xcc << 16) | (hw & 0xfff0);  // XCC, SE/SH/CU (bits 15:8), SIMD (bits 5:4)
+                wv.push_back({key, hs[4 * b + 2], (double)hs[4 * b], b});
+                if (t_min < 0 || hs[4 * b + 2] < t_min) t_min = hs[4 * b + 2];
+            }
         std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
         printf("k_cost_march np=1 %dx%d after %d back-to-back launches: in-kernel clock median %.3f GHz (p10 %.3f, p90 %.3f) over %zu waves; "
                "wave lifetime cycles p10 %.0f, median %.0f, p90 %.0f, p99 %.0f, max %.0f\n", W, H, launches, clk[clk.size() / 2], clk[clk.size() / 10], clk[clk.size() * 9 / 10], clk.size(),
                cyc[cyc.size() / 10], cyc[cyc.size() / 2], cyc[cyc.size() * 9 / 10], cyc[cyc.size() * 99 / 100], cyc.back());
+        // census: the waves of every physical SIMD in the order they started
+        std::sort(wv.begin(), wv.end(), [](const Wv &a, const Wv &b) { return a.key != b.key ? a.key < b.key : a.start < b.start; });
+        std::vector<double> by_rank[8], start_by_rank[8];
+        std::vector<int> per_simd;
+        long long dwave_hist[6] = {0, 0, 0, 0, 0, 0};
+        size_t i0 = 0;
+        int printed = 0;
+        while (i0 < wv.size()) {
+            size_t i1 = i0;
+            while (i1 < wv.size() && wv[i1].key == wv[i0].key) i1++;
+            per_simd.push_back((int)(i1 - i0));
+            for (size_t i = i0; i < i1 && i - i0 < 8; i++) {
+                by_rank[i - i0].push_back(wv[i].cycles);
+                start_by_rank[i - i0].push_back((double)(wv[i].start - t_min) * 0.01);  // us
+                if (i > i0) {
+                    const long long db = llabs((long long)wv[i].wave / 4 - (long long)wv[i - 1].wave / 4);  // distance in workgroups
+                    dwave_hist[db == 0 ? 0 : db == 1 ? 1 : db < 8 ? 2 : db < 200 ? 3 : db < 300 ? 4 : 5]++;
+                }
+            }
+            if (printed < 6) {
+                printf("  SIMD %05llx:", (unsigned long long)wv[i0].key);
+                for (size_t i = i0; i < i1; i++) printf("  [wg %d wave %d start %.2f us, %.0f kcycles]", wv[i].wave / 4, wv[i].wave % 4, (wv[i].start - t_min) * 0.01, wv[i].cycles / 1e3);
+                printf("\n");
+                printed++;
+            }
+            i0 = i1;
+        }
+        std::sort(per_simd.begin(), per_simd.end());
+        printf("  %zu SIMDs hold waves: waves per SIMD min %d, median %d, max %d\n", per_simd.size(), per_simd.front(), per_simd[per_simd.size() / 2], per_simd.back());
+        for (int r = 0; r < 8; r++)
+            if (!by_rank[r].empty()) {
+                std::sort(by_rank[r].begin(), by_rank[r].end()); std::sort(start_by_rank[r].begin(), start_by_rank[r].end());
+                printf("  start rank %d on its SIMD: %zu waves, start median %.2f us (p90 %.2f), lifetime median %.0f kcycles (p10 %.0f, p90 %.0f)\n", r, by_rank[r].size(),
+                       start_by_rank[r][start_by_rank[r].size() / 2], start_by_rank[r][start_by_rank[r].size() * 9 / 10],
+                       by_rank[r][by_rank[r].size() / 2] / 1e3, by_rank[r][by_rank[r].size() / 10] / 1e3, by_rank[r][by_rank[r].size() * 9 / 10] / 1e3);
+            }
+        printf("  workgroup-index distance between consecutive starters of one SIMD: same wg %lld, 1: %lld, 2-7: %lld, 8-199: %lld, 200-299: %lld, >=300: %lld\n",
+               dwave_hist[0], dwave_hist[1], dwave_hist[2], dwave_hist[3], dwave_hist[4], dwave_hist[5]);
         timeit("k_cost_march np=1 (stamped build)", [&]() { launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb); });
         return 0;
     }
 #endif
+    if (argc > 4 && atoi(argv[4]) == 12) {  // marching K-cost, strips by age class (round 3): bits against uniform strips + timing over the shares: kbench W H reps 12
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        march_age_permille[0] = march_age_permille[1] = 0;
+        launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
+        const int shares[][2] = {{0, 0}, {420, 350}, {450, 340}, {440, 360}, {460, 350}, {470, 340}, {480, 340}, {450, 360}, {470, 360}, {500, 320}, {480, 330}, {460, 330}, {430, 370}};
+        for (auto &sh : shares) {
+            march_age_permille[0] = sh[0]; march_age_permille[1] = sh[1];
+            CK(hipMemset(o2, 0xff, 12 * n));
+            launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, 1, 0, rb);
+            CK(hipStreamSynchronize(st));
+            CK(hipGetLastError());
+            CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < 3 * n; i++)
+                if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) { if (!bad) first = i; bad++; }
+            printf("age shares %d/%d/%d vs uniform strips: %zu of %zu values differ%s\n", sh[0], sh[1], 1000 - sh[0] - sh[1], bad, 3 * n, bad ? "" : " (bit-exact)");
+            if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+        }
+        for (int round = 0; round < 3; round++)
+            for (auto &sh : shares) {
+                march_age_permille[0] = sh[0]; march_age_permille[1] = sh[1];
+                char nm[64]; snprintf(nm, sizeof nm, "k_cost_march age %d/%d/%d", sh[0], sh[1], 1000 - sh[0] - sh[1]);
+                timeit(nm, [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, 1, 0, rb); });
+            }
+        march_age_permille[0] = march_age_permille[1] = 0;
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 3) {  // counter runs of the marching K-cost: kbench W H reps 3 np rows
         const int np = argc > 5 ? atoi(argv[5]) : 1, rows = argc > 6 ? atoi(argv[6]) : 0;
         for (int i = 0; i < reps; i++) launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, np, rows, rb);

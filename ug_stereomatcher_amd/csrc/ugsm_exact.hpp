@@ -14,14 +14,16 @@ struct f4 {
 // different XCDs and every halo line is fetched from HBM once per XCD (measured: 118 B read per
 // pixel-iteration against 68 requested).  Remap so that each XCD walks a contiguous band of tile rows;
 // bijective for any tile count (cdna_hip_programming.md T1).
-__device__ __forceinline__ void xcd_tile(int n_tiles, int tiles_x, int &tx, int &ty)
+// (orig: the workgroup's index in dispatch order: blockIdx.x, or its index inside a group of workgroups that starts at a multiple
+// of 8, which lands on the same XCD)
+__device__ __forceinline__ void xcd_tile_at(int orig, int n_tiles, int tiles_x, int &tx, int &ty)
 {
-    const int orig = blockIdx.x;
     const int q = n_tiles >> 3, r = n_tiles & 7, xcd = orig & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     ty = t / tiles_x;
     tx = t - ty * tiles_x;
 }
+__device__ __forceinline__ void xcd_tile(int n_tiles, int tiles_x, int &tx, int &ty) { xcd_tile_at((int)blockIdx.x, n_tiles, tiles_x, tx, ty); }
 
 // Global accesses as scalar base + 32-bit lane byte offset: the base is pinned to SGPRs (readfirstlane) and the
 // access is made in the global address space explicitly, so that the plane offset does not migrate into a 64-bit vector

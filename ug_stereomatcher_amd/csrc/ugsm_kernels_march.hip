@@ -429,22 +429,56 @@ __device__ __forceinline__ bool march_strip(const int n_strips, const int strips
     sx = strip - sy * strips_x;
     return true;
 }
+// AGE CLASSES (round 3).  A SIMD holds up to three strips' waves, and the instruction arbiter serves them oldest first: with
+// equal strips the first-dispatched wave runs at full single-wave speed and finishes at 0.57 of the launch, the second at 0.75,
+// and the last one spends the final quarter alone on its SIMD at the issue rate of one wave (round 2: 380 k / 500 k / 670 k cycles at
+// 16 MP).  Waves that are to finish TOGETHER need strips in proportion to their speed.  The launcher therefore splits the
+// workgroups into `ncls` classes by dispatch order (cls = blockIdx / cls_blocks: the dispatcher deals workgroups breadth-first, one
+// per CU and round, so class c is the c-th wave on its SIMD) and gives class c strips of hc[c] rows; a class's strips tile the
+// image in its own row bands: group g of Hg = sum(hc) rows holds one strip of every class, class c at row offset sum(hc[<c]).
+// hc[1] == 0: one class, the uniform strips of round 2.
+struct StripClasses {
+    int ncls, cls_blocks;  // classes; workgroups per class (a multiple of 8: the XCD remap works inside a class)
+    int hc[3];             // strip rows of class c
+};
+__device__ __forceinline__ bool march_strip_cls(const StripClasses &sc, const int strips_x, const int n_groups, const int H, int &sx, int &ys, int &ye)
+{
+    const int cls = (int)blockIdx.x / sc.cls_blocks;
+    const int jb = (int)blockIdx.x - cls * sc.cls_blocks;
+    int bx, by;
+    xcd_tile_at(jb, sc.cls_blocks, sc.cls_blocks, bx, by);
+    const int strip = bx * MARCH_WPB + (int)(threadIdx.x >> 6);
+    if (strip >= strips_x * n_groups) return false;
+    const int g = strip / strips_x;
+    sx = strip - g * strips_x;
+    const int Hg = sc.hc[0] + sc.hc[1] + sc.hc[2];
+    const int off = cls == 0 ? 0 : (cls == 1 ? sc.hc[0] : sc.hc[0] + sc.hc[1]);
+    ys = g * Hg + off;
+    ye = min(ys + sc.hc[cls], H);
+    return ys < H;
+}
 #ifdef UGSM_MARCH_STAMP
-__device__ long long *g_march_stamps = nullptr;  // per workgroup: delta s_memtime, delta s_memrealtime (never read by the kernel)
+__device__ long long *g_march_stamps = nullptr;  // per wave: delta s_memtime, delta s_memrealtime, start s_memrealtime, hardware ids (never read by the kernel)
 #endif
 // grid: one wave (64 threads) per strip of March<NP>::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
 template <int NP, bool FMAD>
 __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
-                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm)
+                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm, StripClasses sc)
 {
 #ifdef UGSM_MARCH_STAMP  // diagnostic build only (tools/kbench_stamp): in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
     const long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-    int sx, sy;
-    if (!march_strip(n_strips, strips_x, sx, sy)) return;
-    const int xs = sx * March<NP>::VX + March<NP>::ORG, ys = sy * Hs;
-    const int xe = min(xs + March<NP>::VX, W), ye = min(ys + Hs, H);
+    int sx, sy, ys, ye;
+    if (sc.ncls > 1) {  // (kernel-uniform) strips by age class; n_strips = strips per class group count x strips_x is passed as Hs = groups
+        if (!march_strip_cls(sc, strips_x, Hs, H, sx, ys, ye)) return;
+    } else {
+        if (!march_strip(n_strips, strips_x, sx, sy)) return;
+        ys = sy * Hs;
+        ye = min(ys + Hs, H);
+    }
+    const int xs = sx * March<NP>::VX + March<NP>::ORG;
+    const int xe = min(xs + March<NP>::VX, W);
     const int X0 = xs - 3;
     // interior: every pixel a lane holds lies inside the image, and so do the product rows ys-2 .. ye+1 (L is zero outside)
     // and the rows ys-1 .. ye of the B fetches
@@ -473,8 +507,11 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 #ifdef UGSM_MARCH_STAMP
     if (g_march_stamps && (threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * MARCH_WPB + (threadIdx.x >> 6);
-        g_march_stamps[2 * w] = (long long)__builtin_amdgcn_s_memtime() - st_t0;
-        g_march_stamps[2 * w + 1] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
+        g_march_stamps[4 * w] = (long long)__builtin_amdgcn_s_memtime() - st_t0;
+        g_march_stamps[4 * w + 1] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
+        g_march_stamps[4 * w + 2] = st_r0;  // when the wave started (100 MHz ticks)
+        // where it ran: HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE) and HW_REG_XCC_ID
+        g_march_stamps[4 * w + 3] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
     }
 #endif
 }
@@ -509,24 +546,49 @@ int march_strip_rows(int W, int H, int np)
     return Hs;
 }
 
+// Share of a strip group's rows (per mille) that the first- and the second-dispatched wave of a SIMD take; the third takes the
+// rest.  {0, 0} = uniform strips.  (tools/kbench mode 12 sweeps it; UGSM_MARCH_AGE="p0,p1" under UGSM_DEV=1.)
+// Measured (MI355X, same box, profiles/r03_kbench_age_strips.txt): 16 MP 297-303 -> 272-279 us, 8 MP 161 -> 146-150 us, 4 MP 81-84 -> 75-76 us
+// per launch, bit-identical output; wave lifetimes on a SIMD 378 k / 495 k / 645 k cycles (uniform) -> 520 k / 544 k / 562 k (the
+// clock the chip holds falls from 2.23 to 2.16 GHz with it: a denser instruction stream, MI355X_MICROARCH.md "DVFS give-back").
+// A pair alone gains 1 % (108.4 -> 109.5 pairs/s); with four pairs in flight nothing changes (161.7 -> 161.6): there the SIMD slots
+// the finished first waves leave behind are taken by the other pairs' kernels anyway.
+int march_age_permille[2] = {470, 340};
 template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
                                 int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0})
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
-    const int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP);
-    const int strips_y = (H + Hs - 1) / Hs;
-    const int n_strips = strips_x * strips_y;
-    const int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
+    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP);
+    int strips_y = (H + Hs - 1) / Hs;
+    int n_strips = strips_x * strips_y;
+    int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
+    StripClasses sc{1, 0, {Hs, 0, 0}};
+    // three waves per SIMD (the large levels: every strip resident at once, 3 x 1024 of them): strips by age class.  One dispatch
+    // round = one workgroup per CU, so a class is exactly `cus` workgroups (blockIdx / cus = the wave's rank on its SIMD); the
+    // strips of a class must fit into them (4 x cus strips), which fixes the number of strip groups and with it the group height.
+    if (NP == 1 && rows <= 0 && march_age_permille[0] > 0 && n_strips > 2 * 1024 && n_strips <= 3 * 1024 + strips_x) {
+        const int cus = 256;
+        const int n_groups = (MARCH_WPB * cus) / strips_x;
+        const int Hg = n_groups > 0 ? (H + n_groups - 1) / n_groups : 0;
+        const int h0 = (Hg * march_age_permille[0] + 500) / 1000, h1 = (Hg * march_age_permille[1] + 500) / 1000;
+        const int h2 = Hg - h0 - h1;
+        if (n_groups > 0 && h0 >= 6 && h1 >= 6 && h2 >= 6) {
+            sc = StripClasses{3, cus, {h0, h1, h2}};
+            n_blocks = 3 * cus;
+            Hs = (H + Hg - 1) / Hg;  // (the kernel's Hs argument carries the group count in class mode)
+            n_strips = 3 * strips_x * Hs;
+        }
+    }
 #ifdef UGSM_DEV_KERNELS
     if (fmad) {
-        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc);
         return;
     }
 #endif
     (void)fmad;
-    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc);
 }
 
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,

@@ -50,6 +50,8 @@ void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend);
 // `passes` (<= 5) Jacobi passes (+ box) for the coarse levels: one thread per pixel of an 18 x (rh - 14) tile + halo 7 (rh = 18, 24 or 32)
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh);
+// strips by age class (ugsm_kernels_march.hip): share (per mille) of a strip group's rows for the first / second wave of a SIMD; {0, 0} = uniform
+extern int march_age_permille[2];
 // strip height the marching K-cost picks for a W x H level (np = pixels per lane); host only
 int march_strip_rows(int W, int H, int np);
 // First iteration of a level with the seeding fused in: coarse3 = the coarser level's field (never materialised at this level's size)

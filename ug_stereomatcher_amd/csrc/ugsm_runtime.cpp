@@ -428,6 +428,13 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_FUSE_SEED", k.fuse_seed);
     geti("UGSM_COARSE_GRAPH", k.graph);
     geti("UGSM_TWO_STREAMS", k.two_streams);
+    if (const char *e = getenv("UGSM_MARCH_AGE")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
+            march_age_permille[0] = a;
+            march_age_permille[1] = b;
+        }
+    }
     int rh = 0;
     geti("UGSM_SMALL_RH", rh);
     if (rh == 18 || rh == 24 || rh == 32) k.small_rh_force = rh;
