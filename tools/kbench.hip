@@ -138,6 +138,42 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
+    if (argc > 4 && atoi(argv[4]) == 13) {  // a coarse level's 22 iterations (k_cost_small + k_smooth_small, 44 dependent launches): eager launches against one HIP graph replay: kbench W H reps 13
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        auto level = [&]() {
+            float *a = d, *b = o;
+            for (int m = 0; m < 22; m++) {
+                launch_cost_small(st, iL, iR, A, a, o2, W, H, 0.55f, 1);
+                launch_smooth_small(st, o2, b, W, H, 5, 1, 32);
+                std::swap(a, b);
+            }
+        };
+        hipGraph_t graph; hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        level();
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (int round = 0; round < 3; round++) {
+            timeit("22 iterations, 44 eager launches", level);
+            timeit("22 iterations, one graph replay", [&]() { CK(hipGraphLaunch(exec, st)); });
+        }
+        // host-side cost of issuing them (the stream is kept busy, so this is what the host pays, not what the GPU takes)
+        for (int round = 0; round < 2; round++) {
+            CK(hipStreamSynchronize(st));
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; i++) level();
+            auto t1 = std::chrono::steady_clock::now();
+            CK(hipStreamSynchronize(st));
+            auto t2 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; i++) CK(hipGraphLaunch(exec, st));
+            auto t3 = std::chrono::steady_clock::now();
+            CK(hipStreamSynchronize(st));
+            printf("host time to issue one level: eager %.1f us (%.2f us per launch), graph %.1f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count() / reps,
+                   std::chrono::duration<double, std::micro>(t1 - t0).count() / reps / 44, std::chrono::duration<double, std::micro>(t3 - t2).count() / reps);
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 12) {  // marching K-cost, strips by age class (round 3): bits against uniform strips + timing over the shares: kbench W H reps 12
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);

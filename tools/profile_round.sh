@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collects everything profiles/make_summaries.py needs, in ONE gpurun call:
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'
-#   python profiles/make_summaries.py gpurun_out/prof_r02 r02
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
+#   python profiles/make_summaries.py gpurun_out/prof_r03 r03
 # Counter passes are separate rocprofv3 runs with at most 8 counters each (--kernel-trace only beside --pmc), each
 # behind its own timeout; a line is printed after every step so that the call never looks hung.
 export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -32,7 +32,10 @@ timeout -k 10 200 ./tools/kbench 4928 3264 10 5 > $O/kbench_smooth_16mp.txt 2>&1
 { for sz in "54 36" "154 102" "436 289" "616 408"; do timeout -k 10 100 ./tools/kbench $sz 200 7 | grep -v "P=[0-4]"; done; } > $O/kbench_small.txt 2>&1; step "kbench (latency kernels of the coarse levels)"
 timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; step "kbench (pyramid base ablations, blur+decimate, seed, sqblur)"
 { for sz in "2464 1632" "1742 1154" "1232 816" "871 577"; do timeout -k 10 100 ./tools/kbench $sz 50 10; done; } > $O/kbench_strips.txt 2>&1; step "kbench (strip heights of the marching K-cost)"
+{ for sz in "4928 3264 10" "3484 2307 10" "2463 1631 20"; do timeout -k 10 100 ./tools/kbench $sz 12 | grep -v "bit-exact" ; done; } > $O/kbench_age_16mp.txt 2>&1; step "kbench (strips by age class)"
+{ for sz in "54 36" "154 102" "436 289"; do timeout -k 10 60 ./tools/kbench $sz 20 13; done; } > $O/kbench_graph.txt 2>&1; step "kbench (eager launches against a HIP graph, coarse level)"
+timeout -k 10 100 ./tools/kbench_stamp 4928 3264 10 6 > $O/census_16mp.txt 2>&1; step "wave census of the marching K-cost"
 timeout -k 10 100 python tools/level_breakdown.py > $O/level_breakdown.txt 2>&1; step "per-level breakdown of one pair"
-timeout -k 10 100 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"
+timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
 ls $O

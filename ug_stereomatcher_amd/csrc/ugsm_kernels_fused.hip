@@ -763,9 +763,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     const bool edge_e = x0 + RWID > W, edge_s = y0 + LH > H, edge_nw = x0 <= 0 || y0 <= 0;
 
     for (int p = 1; p <= P; p++) {
-        // pass p is needed (and valid) on the region shrunk to halo h-p
-        const int r_lo = HY - (h - p), r_hi = LH - (HY - (h - p));
-        const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p)));
+        // pass p is needed (and valid) on the region shrunk to halo h-p -- and inside the image: cells above / left of / below /
+        // right of it are never read by an in-image pixel (the replica row H and column W are re-established after every
+        // write-back), so the tiles on the frame skip them.  (Round 3: a 1741 x 1153 level has 33 tile rows, the last one with ONE
+        // image row -- 528 tiles on 512 workgroup slots, i.e. a second round that used to cost as much as the first.)
+        const int r_lo = max(HY - (h - p), -y0), r_hi = min(LH - (HY - (h - p)), H - y0);
+        const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p))) && (c0 + 3 >= -x0) && (c0 < W - x0);
         float nv[MAXR][3][4];
         // one quad-row: the five-point sums and the division from registers, results into nv[u].  LIT = literal
         // division per plane; otherwise the shared-reciprocal form, and the return value says whether every
