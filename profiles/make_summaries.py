@@ -70,7 +70,11 @@ def _largest(agg, prefix, counter):
         if name.startswith(prefix) and r["Counter_Name"] == counter:
             rows[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     g = max(rows)
-    return sum(rows[g]) / len(rows[g])
+    # (round 3: the marching K-cost launches 3 x 256 workgroups at every level that runs three waves per SIMD, so the largest grid no
+    # longer identifies level 0 by itself: of that grid's dispatches keep those within 25 % of the largest value -- the level-0 ones)
+    top = max(rows[g])
+    keep = [v for v in rows[g] if v >= 0.75 * top]
+    return sum(keep) / len(keep)
 valu_busy = {}
 valu_insts = {}
 for kname, prefix in (("k_cost_march", "k_cost_march"), ("k_cost_split", "k_cost_split"), ("k_smooth_fused", "k_smooth_fused<112")):

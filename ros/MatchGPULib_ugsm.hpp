@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 #include "ugsm.h"
 
@@ -27,8 +28,12 @@ public:
     {
         ugsm_config cfg;
         ugsm_default_config(&cfg);
-        for (int i = 1; i < argc; i++)
+        for (int i = 1; i < argc; i++) {
             if (argv[i] && std::strncmp(argv[i], "-device=", 8) == 0) cfg.device = std::atoi(argv[i] + 8);
+            // not in the reference: "-lrcheck=TAU" switches the optional LR-consistency check on (ugsm_config.lr_check_threshold;
+            // full mode only; off by default, and the results are the reference's only while it is off)
+            if (argv[i] && std::strncmp(argv[i], "-lrcheck=", 9) == 0) cfg.lr_check_threshold = (float)std::atof(argv[i] + 9);
+        }
         if (argc > 2) foveatelevel = std::atoi(argv[2]);
         cfg.fovea_levels = foveatelevel;
         const int st = ugsm_create(&cfg, &ctx_);
