@@ -106,7 +106,8 @@ long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
 
 /* Which kernels a W x H level runs under `cfg` (NULL = defaults), for maintainers and the host tests; results never depend on it.
  * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_cost_split / k_smooth_fused), 1 = marching (k_cost_march / k_smooth_march),
- * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1);
+ * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1),
+ * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4: the mid levels of a one-slot context);
  * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
  * seed_fused: 1 if the level's seeding rides on its first K-cost launch. */
 typedef struct ugsm_level_plan {

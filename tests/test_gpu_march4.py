@@ -1,0 +1,130 @@
+"""K-cost as the channel-parallel marching kernel (csrc/ugsm_kernels_march4.hip: three channel waves + an epilogue wave per strip)
+against the CPU oracle, bit for bit.
+
+In production it runs the mid levels (0.15 - 3 Mpx) of one-slot contexts; here UGSM_MARCH4=lo,hi (a development override, honoured
+because tests/conftest.py sets UGSM_DEV=1) forces it on for every size, so that strip seams, frame edges, the seeded first launch,
+fovea views and the range-guarded division are crossed on images the oracle finishes in seconds.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from test_gpu_march import iterate, planes
+
+pytestmark = pytest.mark.gpu
+
+MARCH4 = 4
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from ug_stereomatcher_amd import _lib
+    return _lib
+
+
+@pytest.fixture()
+def everywhere(monkeypatch):
+    monkeypatch.setenv("UGSM_MARCH4", "1,2000000000")
+
+
+def test_march4_one_iteration_sizes(lib, orc, everywhere):
+    """Two iterations of a level on sizes around the strip width (58 columns) and the minimum strip height (6 rows), down to images
+    smaller than the 5 x 5 window."""
+    rng = np.random.Generator(np.random.PCG64(177))
+    cases = [(300, 90), (123, 40), (117, 64), (116, 13), (59, 70), (58, 21), (257, 64), (31, 9), (640, 48), (64, 300), (5, 3), (3, 17)]
+    for (W, H) in cases:
+        assert lib.plan_level(W, H)["cost_kernel"] == MARCH4
+        pl, pr = planes(orc, W, H, 4000 + W)
+        d0 = np.stack([rng.normal(0, 6, (H, W)), rng.normal(0, 3, (H, W)), 0.2 + 0.8 * rng.random((H, W))]).astype(np.float32)
+        exp, _ = orc.iterate_level(pl, pr, d0, 6, 5, False, 1, 2)
+        with lib.Context(levels=1) as c:
+            got = iterate(c, pl, pr, d0, 6, 5, False, 1, 2)
+        assert_bit_equal(got, exp, f"{W}x{H}")
+
+
+def test_march4_large_disparities_top_level_and_zero_patches(lib, orc, everywhere):
+    rng = np.random.Generator(np.random.PCG64(178))
+    W, H = 200, 77
+    pl, pr = planes(orc, W, H, 4100)
+    pl[:, 10:22, 12:30] = 0  # 0/0 -> NaN correlation -> (0, 0.4) branch
+    pr[:, 40:60, 100:150] = 0
+    pl[1, 30:50, 60:90] = 0  # one channel only: the channel waves disagree about NaN, the epilogue wave sums them
+    d0 = np.stack([rng.normal(0, 60, (H, W)), rng.normal(0, 30, (H, W)), 0.2 + 0.8 * rng.random((H, W))]).astype(np.float32)
+    with lib.Context(levels=1) as c:
+        for is_top in (False, True):
+            exp, _ = orc.iterate_level(pl, pr, d0, 4, 5, is_top, 1, 3)
+            got = iterate(c, pl, pr, d0, 4, 5, is_top, 1, 3)
+            assert np.isfinite(exp).all()
+            assert_bit_equal(got, exp, f"top={is_top}")
+
+
+def test_march4_wild_disparities(lib, orc, everywhere):
+    """NaN, +-Inf, huge and denormal disparities go through the branch-free texture index exactly like tex_index (NaN -> 0, clamp
+    otherwise)."""
+    rng = np.random.Generator(np.random.PCG64(179))
+    W, H = 150, 40
+    pl, pr = planes(orc, W, H, 4200)
+    d0 = np.stack([rng.normal(0, 5, (H, W)), rng.normal(0, 5, (H, W)), 0.2 + 0.8 * rng.random((H, W))]).astype(np.float32)
+    wild = np.array([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e10, -1e10, 2147483648.0, -2147483904.0, 1e-45, -1e-45, -0.5, -0.49999997],
+                    np.float32)
+    idx = rng.integers(0, H * W, 400)
+    d0[0].ravel()[idx[:200]] = wild[rng.integers(0, len(wild), 200)]
+    d0[1].ravel()[idx[200:]] = wild[rng.integers(0, len(wild), 200)]
+    exp, _ = orc.iterate_level(pl, pr, d0, 4, 0, False, 1, 1)
+    with lib.Context(levels=1) as c:
+        got = iterate(c, pl, pr, d0, 4, 0, False, 1, 1)
+    assert_bit_equal(got, exp, "wild")
+
+
+def full_match(c, L, R):
+    H, W, _ = L.shape
+    out = np.empty((3, H, W), np.float32)
+    c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("slots", [1, 3])
+def test_march4_every_level_end_to_end(lib, orc, everywhere, slots):
+    """Whole matcher with every level's K-cost through k_cost_march4: the seeded first launch of every level, the range-guarded
+    division (the pair's pyramids are in range), full and foveated mode (views into the pyramid levels, seeding with an offset)."""
+    from ug_stereomatcher_amd import synth
+    W, H = 420, 300
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 410)
+    with lib.Context(levels=10, fovea_levels=5, slots=slots) as c:
+        assert_bit_equal(full_match(c, L, R), orc.match_full(L, R, 10), f"full, slots={slots}")
+        fw, fh = lib.fovea_dims(W, H, 10, 5)
+        st = np.empty((3, 5, fh, fw), np.float32)
+        c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], 0, 0, st[0].ctypes.data, st[1].ctypes.data,
+                                          st[2].ctypes.data, None, None))
+        exp, _, _ = orc.match_foveated(L, R, 10, 5)
+        assert_bit_equal(st, exp, f"foveated, slots={slots}")
+
+
+def test_march4_without_fused_seeding_and_with_early_exit(lib, orc, everywhere, monkeypatch):
+    from ug_stereomatcher_amd import synth
+    L, R, _, _ = synth.make_pair(260, 190, synth.BASE_SEED + 411)
+    exp = orc.match_full(L, R, 8)
+    monkeypatch.setenv("UGSM_FUSE_SEED", "0")
+    with lib.Context(levels=8) as c:
+        assert_bit_equal(full_match(c, L, R), exp, "seeded by k_seed")
+    monkeypatch.delenv("UGSM_FUSE_SEED")
+    with lib.Context(levels=8, early_exit_threshold=1e-9) as c:  # never met: every iteration runs, through the early-exit plumbing
+        assert_bit_equal(full_match(c, L, R), exp, "early exit armed")
+
+
+def test_default_policy_of_a_one_slot_context(lib, orc, monkeypatch):
+    """No override: a one-slot context runs its 0.15 - 3 Mpx levels through k_cost_march4 (levels 0 and 1 of an 800 x 600 pair), a
+    context with several slots none; both give the oracle's result, and the per-kernel statistics show which kernel ran."""
+    from ug_stereomatcher_amd import synth
+    monkeypatch.delenv("UGSM_MARCH4", raising=False)
+    W, H = 800, 600
+    assert lib.plan_level(W, H, slots=1)["cost_kernel"] == MARCH4 and lib.plan_level(W, H, slots=1)["seed_fused"] == 1
+    assert lib.plan_level(W, H, slots=4)["cost_kernel"] != MARCH4
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 412)
+    exp = orc.match_full(L, R, 9)
+    with lib.Context(levels=9, slots=1) as c:
+        assert_bit_equal(full_match(c, L, R), exp, "one slot")
+    with lib.Context(levels=9, slots=2) as c:
+        assert_bit_equal(full_match(c, L, R), exp, "two slots")

@@ -4,7 +4,7 @@ import pytest
 
 from ug_stereomatcher_amd import _lib
 
-TILED, MARCH, SMALL, STAGED = 0, 1, 2, 3
+TILED, MARCH, SMALL, STAGED, MARCH4 = 0, 1, 2, 3, 4
 
 
 def levels_16mp():
@@ -25,14 +25,19 @@ def test_default_plan_of_a_16mp_pyramid_with_several_pairs_in_flight():
 
 def test_one_slot_context_is_tuned_for_a_pair_alone():
     plans = [_lib.plan_level(w, h, slots=1) for (w, h) in levels_16mp()]
-    assert [p["cost_kernel"] for p in plans] == [MARCH] * 6 + [TILED] + [SMALL] * 7   # marching stops at 0.4 Mpx; level 6 is tiled
+    # levels 3-6 (0.25 - 2 Mpx): a launch lasts as long as one strip, so the strip's channels go side by side (k_cost_march4)
+    assert [p["cost_kernel"] for p in plans] == [MARCH] * 3 + [MARCH4] * 4 + [SMALL] * 7
+    assert [p["seed_fused"] for p in plans] == [1] * 7 + [0] * 7
+    assert all(6 <= p["strip_rows"] <= 40 for p in plans[3:7])
+    assert all(p["cost_kernel"] != MARCH4 for p in [_lib.plan_level(w, h, slots=2) for (w, h) in levels_16mp()])
     assert [p["smooth_rh"] for p in plans[7:]] == [32, 24, 18, 18, 18, 18, 18]           # the smallest tile that still fills the chip
 
 
 def test_switches():
     assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
     assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0)
-    assert _lib.plan_level(300, 200, small_max_pixels=-1)["cost_kernel"] == TILED
+    assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
+    assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=1)["cost_kernel"] == MARCH4   # a pair alone: the latency form takes over
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
     assert _lib.plan_level(300, 200, march_min_pixels=1, march_rows=17)["strip_rows"] == 17
     assert _lib.plan_level(4928, 3264, early_exit_threshold=0.1)["seed_fused"] == 0     # the field before the first iteration is needed
@@ -70,3 +75,7 @@ def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
     monkeypatch.delenv("UGSM_SMALL_RH")
     monkeypatch.setenv("UGSM_FUSE_SEED", "0")
     assert _lib.plan_level(4928, 3264)["seed_fused"] == 0
+    monkeypatch.setenv("UGSM_MARCH4", "1,100000")
+    assert _lib.plan_level(300, 200)["cost_kernel"] == MARCH4 and _lib.plan_level(400, 300)["cost_kernel"] != MARCH4
+    monkeypatch.setenv("UGSM_MARCH4", "0,0")
+    assert all(_lib.plan_level(w, h, slots=1)["cost_kernel"] != MARCH4 for (w, h) in levels_16mp())

@@ -6,6 +6,7 @@
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march.hip"
+#include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march4.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_small.hip"
 #include <algorithm>
 #include <cmath>
@@ -138,6 +139,38 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
+    if (argc > 4 && atoi(argv[4]) == 14) {  // channel-parallel marching K-cost (k_cost_march4) against k_cost_march and k_cost_split: bits + timing over strip heights: kbench W H reps 14
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        float *cz; CK(hipMalloc(&cz, 12 * n));  // a "coarser" field for the seeded form: same size / sqrt(2)
+        const int Wc = (int)(W / 1.41421356), Hc = (int)(H / 1.41421356);
+        std::vector<float> ha(3 * n), hb(3 * n);
+        const SeedMap none{0, 0, 0, 0}, smap{Wc, Hc, 0, 0};
+        for (int seeded = 0; seeded < 2; seeded++)
+            for (int blend = 0; blend < 2; blend++) {
+                CK(hipMemset(o, 0xff, 12 * n)); CK(hipMemset(o2, 0xee, 12 * n));
+                if (seeded) { launch_cost_march_seeded(st, iL, iR, A, d, smap, o, W, H, 0.55f, blend, 0, rb); launch_cost_march4(st, iL, iR, A, d, o2, W, H, 0.55f, blend, 0, rb, smap); }
+                else { launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, blend, 0, 1, 0, rb); launch_cost_march4(st, iL, iR, A, d, o2, W, H, 0.55f, blend, 0, rb, none); }
+                CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+                size_t bad = 0, first = 0;
+                for (size_t i = 0; i < 3 * n; i++)
+                    if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) { if (!bad) first = i; bad++; }
+                printf("k_cost_march4 vs k_cost_march seeded=%d blend=%d: %zu of %zu values differ%s\n", seeded, blend, bad, 3 * n, bad ? "" : " (bit-exact)");
+                if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+            }
+        for (int round = 0; round < 2; round++) {
+            timeit("k_cost_split", [&]() { launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1); });
+            timeit("k_cost_march rows=0", [&]() { launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb); });
+            if (n <= 300000) timeit("k_cost_small", [&]() { launch_cost_small(st, iL, iR, A, d, o, W, H, 0.55f, 1); });
+            for (int rows : {0, 6, 8, 10, 12, 16, 20, 24, 32, 48}) {
+                char nm[64]; snprintf(nm, sizeof nm, "k_cost_march4 rows=%d", rows);
+                timeit(nm, [&]() { launch_cost_march4(st, iL, iR, A, d, o2, W, H, 0.55f, 1, rows, rb, none); });
+            }
+            timeit("k_cost_march4 seeded rows=0", [&]() { launch_cost_march4(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, rb, smap); });
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 13) {  // a coarse level's 22 iterations (k_cost_small + k_smooth_small, 44 dependent launches): eager launches against one HIP graph replay: kbench W H reps 13
         float *o2; CK(hipMalloc(&o2, 12 * n));
         auto level = [&]() {

@@ -57,6 +57,11 @@ int march_strip_rows(int W, int H, int np);
 // First iteration of a level with the seeding fused in: coarse3 = the coarser level's field (never materialised at this level's size)
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
                               int blend, int rows, const unsigned *range_bad);
+// The same iteration with the three colour channels on three waves of a workgroup and the epilogue on a fourth (ugsm_kernels_march4.hip): the
+// latency form for levels whose launch lasts as long as one strip.  sm.Ws > 0: the level's first iteration, seeded from the coarser field d3.
+void launch_cost_march4(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int rows,
+                        const unsigned *range_bad, SeedMap sm);
+int march4_strip_rows(int W, int H);
 // range_bad (device word, may be null = unknown): 0 when every pyramid value of the pair passed range_ok (ugsm_exact.hpp),
 // which lets K-cost use the range-guarded division; launch_range_scan ORs the check of `count` floats into it.
 void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad);

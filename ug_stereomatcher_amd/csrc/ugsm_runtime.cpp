@@ -32,11 +32,11 @@ namespace {
 
 constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
-enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COUNT };
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COST_MARCH4, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
     {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_smooth_march",
-     "k_pyr_base", "k_cost_small", "k_smooth_small"},
-    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-"}};
+     "k_pyr_base", "k_cost_small", "k_smooth_small", "k_cost_march4"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-", "-"}};
 constexpr int kNoLevel = UGSM_MAX_LEVELS;  // stats cell of launches that belong to no pyramid level
 struct StatCell {
     long long launches = 0;
@@ -180,6 +180,7 @@ struct ugsm_ctx {
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
+    int march4_lo = 0, march4_hi = 0;  // levels of lo..hi pixels run K-cost as k_cost_march4 (use_march4; 0, 0 = none)
 };
 
 namespace {
@@ -407,6 +408,7 @@ struct DevKnobs {
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
+    int march4_lo = -1, march4_hi = -1;  // UGSM_MARCH4=lo,hi: pixel range of k_cost_march4 (0,0 = never; default: march4_default_range)
 };
 bool dev_env_on()
 {
@@ -433,6 +435,13 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
             march_age_permille[0] = a;
             march_age_permille[1] = b;
+        }
+    }
+    if (const char *e = getenv("UGSM_MARCH4")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) {
+            k.march4_lo = a;
+            k.march4_hi = b;
         }
     }
     int rh = 0;
@@ -493,6 +502,26 @@ bool use_march(const ugsm_config &cfg, int W, int H)
     return (long long)W * H >= thr;
 }
 
+// K-cost as the channel-parallel marching kernel (ugsm_kernels_march4.hip): a workgroup of four waves per strip, a third of the
+// instructions per row step on any one wave.  It wins where a launch lasts as long as one strip -- levels too small to give every SIMD
+// two or three waves of k_cost_march: 0.15 - 3 Mpx for a pair alone on the chip (tools/kbench mode 14: 10.9 against 16.4 us at
+// 0.25 Mpx, 24.3 / 29.8 at 1 Mpx, 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).  With several pairs in flight the chip is full anyway and
+// the kernels' total VALU-issue time decides: see march4_default_range.
+void march4_default_range(const ugsm_config &cfg, int &lo, int &hi)
+{
+    const int small_thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.small_max_pixels < 0 ? 0 : 150000);
+    if (cfg.slots == 1) {
+        lo = small_thr + 1;
+        hi = 3000000;
+    } else
+        lo = hi = 0;
+}
+bool use_march4(const ugsm_ctx *ctx, int W, int H)
+{
+    const long long px = (long long)W * H;
+    return ctx->cfg.kernel_path != 1 && ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
+}
+
 // K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
 // has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
 // (tools/kbench mode 7).  Returns the K-smooth region height to use (0 = not a small level).
@@ -518,7 +547,7 @@ int small_rh(const ugsm_ctx *ctx, int W, int H)
 bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
 {
     const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && use_march(cfg, W, H);
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(cfg, W, H) || use_march4(ctx, W, H));
 }
 
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
@@ -630,10 +659,14 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             Timer t(ctx, &s, si, KC_COST, px);
             launch_cost_ref(s.st, L, s.Rw, A3, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
+            const bool march4 = use_march4(ctx, W, H);
             const bool march = use_march(ctx->cfg, W, H);
             const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H) != 0;
-            Timer t(ctx, &s, si, march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST), px);
-            if (march && seed && m == m_from)
+            Timer t(ctx, &s, si, march4 ? KC_COST_MARCH4 : (march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST)), px);
+            if (march4)
+                launch_cost_march4(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, s.range_known ? s.range_bad : nullptr,
+                                   (seed && m == m_from) ? *seed : SeedMap{0, 0, 0, 0});
+            else if (march && seed && m == m_from)
                 launch_cost_march_seeded(s.st, L, R, A3, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else if (march) launch_cost_march(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, 1, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
             else if (small) launch_cost_small(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
@@ -1043,6 +1076,8 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->small_mask = knobs.small_mask;
     ctx->fuse_seed = knobs.fuse_seed;
     ctx->small_rh_force = knobs.small_rh_force;
+    march4_default_range(ctx->cfg, ctx->march4_lo, ctx->march4_hi);
+    if (knobs.march4_hi >= 0) ctx->march4_lo = knobs.march4_lo, ctx->march4_hi = knobs.march4_hi;
     // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
     // beside the left pyramid and the coarse levels).  With four pairs in flight it LOSES 13 % (136 against 157 pairs/s): eight
     // streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So: one-slot contexts only.
@@ -1113,6 +1148,8 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
         probe.small_mask = knobs.small_mask;
         probe.fuse_seed = knobs.fuse_seed;
         probe.small_rh_force = knobs.small_rh_force;
+        march4_default_range(probe.cfg, probe.march4_lo, probe.march4_hi);
+        if (knobs.march4_hi >= 0) probe.march4_lo = knobs.march4_lo, probe.march4_hi = knobs.march4_hi;
     }
     memset(out, 0, sizeof *out);
     if (probe.cfg.kernel_path == 1) {
@@ -1121,10 +1158,11 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     }
     const bool march = use_march(probe.cfg, W, H);
     const int rh = small_rh(&probe, W, H);
-    out->cost_kernel = march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0);
+    const bool march4 = use_march4(&probe, W, H);
+    out->cost_kernel = march4 ? 4 : (march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0));
     out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
-    out->strip_rows = march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1)) : 0;
+    out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1)) : 0);
     out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
     return UGSM_OK;
 }
