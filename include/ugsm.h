@@ -109,9 +109,10 @@ long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
  * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1),
  * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4: the mid levels of a one-slot context);
  * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
- * seed_fused: 1 if the level's seeding rides on its first K-cost launch. */
+ * seed_fused: 1 if the level's seeding rides on its first K-cost launch; smooth_tile_rows: height of k_smooth_fused's 112-column
+ * tile on a level of >= 0.5 Mpx (else 0) -- whole rounds of workgroups for a one-slot context, least halo work otherwise. */
 typedef struct ugsm_level_plan {
-    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, reserved[3];
+    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, reserved[2];
 } ugsm_level_plan;
 int ugsm_plan_level(const ugsm_config *cfg, int W, int H, ugsm_level_plan *out);
 

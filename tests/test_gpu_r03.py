@@ -130,3 +130,30 @@ def test_slot_stream_is_exported(lib):
         c.check(c.lib.ugsm_slot_stream(c.handle, 1, C.byref(b)))
         assert a.value and b.value and a.value != b.value
         assert c.lib.ugsm_slot_stream(c.handle, 2, C.byref(a)) == lib.UGSM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("rows", ["0", "16", "23", "37", "39", "-1", "-2"])
+def test_smooth_tile_heights(lib, orc, monkeypatch, rows):
+    """k_smooth_fused's 112-column tile at any height (UGSM_SMOOTH_ROWS; 0 = the context's policy, -1 / -2 = the latency / throughput
+    rule): image edges on tile edges, inside the neighbouring tile's halo and one pixel into a new tile, degenerate confidences."""
+    monkeypatch.setenv("UGSM_SMOOTH_ROWS", rows)
+    rng = np.random.Generator(np.random.PCG64(350))
+    for (W, H) in [(1007, 539), (1009, 541), (1120, 469), (690, 780)]:
+        d = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 3, (H, W)), 0.1 + 0.9 * rng.random((H, W))]).astype(np.float32)
+        d[2, 40:60, 50:90] = 0.0
+        d[2, 100:104, 100:140] = -0.25
+        d[2, 120:124, 20:60] = 1e-30
+        d[2, H - 30:H - 10, W - 80:W - 40] = 0.0
+        for passes, box in [(5, 1), (2, 0), (0, 1)]:
+            exp = d
+            with np.errstate(all="ignore"):
+                for _ in range(passes):
+                    exp = orc.smooth_pass(exp)
+                if box:
+                    exp = orc.box3(exp)
+            with lib.Context(levels=1, slots=1 if rows != "-2" else 2) as c:
+                p = c.to_device(d)
+                c.check(c.lib.ugsm_stage_smooth(c.handle, p, W, H, passes, box))
+                got = c.to_host(p, d.shape)
+                c.free(p)
+            assert_bit_equal(got, exp, f"{W}x{H} rows={rows} passes={passes} box={box}")

@@ -35,7 +35,8 @@ def test_one_slot_context_is_tuned_for_a_pair_alone():
 
 def test_switches():
     assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
-    assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0)
+    assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0,
+                                                                     smooth_tile_rows=36)
     assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
     assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=1)["cost_kernel"] == MARCH4   # a pair alone: the latency form takes over
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
@@ -57,6 +58,20 @@ def test_strip_rows_fill_the_chip_or_one_round():
     assert _lib.plan_level(871, 577, march_min_pixels=1)["strip_rows"] <= 12
 
 
+def test_smooth_tile_rows_fill_whole_rounds_for_a_pair_alone_and_are_36_otherwise():
+    """k_smooth_fused's 112-column tile (levels >= 0.5 Mpx) may be 16..39 rows high; 512 workgroups are resident at a time."""
+    lv = levels_16mp()
+    assert [_lib.plan_level(w, h, slots=4)["smooth_tile_rows"] for (w, h) in lv] == [36] * 5 + [0] * 9
+    one = [_lib.plan_level(w, h, slots=1)["smooth_tile_rows"] for (w, h) in lv]
+    assert one == [36, 36, 36, 37, 18] + [0] * 9
+    for (w, h), rows in list(zip(lv, one))[2:5]:            # the few-round levels: no partial round
+        tiles = -(-w // 112) * -(-h // rows)
+        assert tiles <= 512 * -(-tiles // 512) and tiles > 512 * (-(-tiles // 512)) - 64, (w, h, rows, tiles)
+    for (w, h) in [(1920, 1080), (1000, 600), (3000, 200), (112, 5000), (5000, 113)]:
+        for slots in (1, 4):
+            assert 16 <= _lib.plan_level(w, h, slots=slots, march_min_pixels=-1)["smooth_tile_rows"] <= 39
+
+
 def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
     """ugsm_plan_level applies the overrides ugsm_create applies: none without UGSM_DEV=1, all of them with it."""
     base = _lib.plan_level(300, 200)
@@ -75,6 +90,9 @@ def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
     monkeypatch.delenv("UGSM_SMALL_RH")
     monkeypatch.setenv("UGSM_FUSE_SEED", "0")
     assert _lib.plan_level(4928, 3264)["seed_fused"] == 0
+    monkeypatch.setenv("UGSM_SMOOTH_ROWS", "24")
+    assert _lib.plan_level(4928, 3264)["smooth_tile_rows"] == 24
+    monkeypatch.delenv("UGSM_SMOOTH_ROWS")
     monkeypatch.setenv("UGSM_MARCH4", "1,100000")
     assert _lib.plan_level(300, 200)["cost_kernel"] == MARCH4 and _lib.plan_level(400, 300)["cost_kernel"] != MARCH4
     monkeypatch.setenv("UGSM_MARCH4", "0,0")

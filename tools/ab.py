@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""A/B of development overrides on ONE box: child processes under different UGSM_* settings (UGSM_DEV=1) take turns on the same
+16 MP pairs, alternating order; rates per configuration as median / min / max over the processes.  Box-to-box differences
+(+-1.5 %) are larger than most of the effects being compared, so the comparisons quoted in DESIGN.md from round 3 on come from
+this tool, not from bench.py runs on different boxes.
+
+usage: python tools/ab.py [--slots S] [--pairs P] [--rounds R] [--size W H] "name:VAR=val;VAR2=val" "name2:" ...
+"""
+import argparse, os, statistics, subprocess, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--slots", type=int, default=4)
+ap.add_argument("--pairs", type=int, default=48)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--levels", type=int, default=14)
+ap.add_argument("--size", type=int, nargs=2, default=(4928, 3264))
+ap.add_argument("--child", action="store_true", help="(internal) measure under the current environment, print the rate")
+ap.add_argument("configs", nargs="*")
+args = ap.parse_args()
+W, H = args.size
+
+if args.child:
+    # one context per process: HIP deals a process's streams onto its hardware queues in creation order, and a second context's
+    # streams share queues with the first one's (a context measured second in the same process ran 15 % slower whatever its settings)
+    import torch
+    from ug_stereomatcher_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    pairs = []
+    for j in range(max(args.slots, 2)):
+        L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + j)
+        pairs.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
+    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(args.slots)]
+    torch.cuda.synchronize()
+    with _lib.Context(levels=args.levels, slots=args.slots) as c:
+        lib, h = c.lib, c.handle
+
+        def run(n):
+            for i in range(n):
+                s = i % args.slots
+                if i >= args.slots:
+                    c.check(lib.ugsm_wait(h, s))
+                dL, dR = pairs[i % len(pairs)]
+                c.check(lib.ugsm_submit_full(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, outs[s].data_ptr()))
+            c.check(lib.ugsm_wait_all(h))
+
+        run(3 * args.slots)
+        best = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run(args.pairs)
+            best.append(args.pairs / (time.perf_counter() - t0))
+    print("RATE", statistics.median(best))
+    sys.exit(0)
+
+cfgs = []
+for spec in args.configs:
+    name, _, rest = spec.partition(":")
+    cfgs.append((name, dict(kv.split("=", 1) for kv in rest.split(";") if kv)))
+rates = [[] for _ in cfgs]
+for r in range(args.rounds):
+    order = list(range(len(cfgs))) if r % 2 == 0 else list(reversed(range(len(cfgs))))
+    for i in order:
+        env = dict(os.environ, UGSM_DEV="1", **cfgs[i][1])
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--slots", str(args.slots), "--pairs", str(args.pairs), "--levels",
+                              str(args.levels), "--size", str(W), str(H)], env=env, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RATE")]
+        if not line:
+            print(out.stdout[-2000:], out.stderr[-2000:])
+            sys.exit(1)
+        rates[i].append(float(line[0].split()[1]))
+        print(f"round {r} {cfgs[i][0]}: {rates[i][-1]:.2f}", flush=True)
+base = statistics.median(rates[0])
+print(f"{W}x{H}, {args.levels} levels, slots={args.slots}, {args.pairs} pairs x 3, {args.rounds} processes each (pairs/s: median  min  max  vs first)")
+for (name, env), rs in zip(cfgs, rates):
+    m = statistics.median(rs)
+    print(f"  {name:28s} {m:8.2f} {min(rs):8.2f} {max(rs):8.2f}  {100.0 * (m / base - 1.0):+6.2f} %   {env}")

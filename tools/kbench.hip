@@ -139,6 +139,35 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
+    if (argc > 4 && atoi(argv[4]) == 15) {  // tile heights of the 112-column K-smooth tile: bits against 36 rows, timing, the policy's choice: kbench W H reps 15
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        for (int P : {5, 2, 0})
+            for (int box = 0; box < 2; box++) {
+                if (P == 0 && !box) continue;
+                launch_smooth_fused(st, d, o, W, H, P, box, 36);
+                CK(hipStreamSynchronize(st)); CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
+                for (int rows : {39, 38, 37, 35, 33, 29, 24, 18, 13, 12}) {
+                    CK(hipMemset(o2, 0xee, 12 * n));
+                    launch_smooth_fused(st, d, o2, W, H, P, box, rows);
+                    CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                    CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+                    size_t bad = 0;
+                    for (size_t i = 0; i < 3 * n; i++) bad += memcmp(&ha[i], &hb[i], 4) != 0;
+                    if (bad) printf("k_smooth_fused P=%d box=%d rows=%d vs rows=36: %zu of %zu values differ\n", P, box, rows, bad, 3 * n);
+                }
+            }
+        printf("k_smooth_fused tile heights 12..37 against 36, P = 5 / 2 / 0, with and without the box: compared\n");
+        printf("policy: latency %d rows, throughput %d rows\n", smooth_tile_rows(W, H, 1), smooth_tile_rows(W, H, 0));
+        for (int round = 0; round < 2; round++)
+            for (int rows = 39; rows >= 18; rows--) {
+                const int tiles = ((W + 111) / 112) * ((H + rows - 1) / rows);
+                char nm[64]; snprintf(nm, sizeof nm, "smooth p5+box rows=%d (%d tiles)", rows, tiles);
+                timeit(nm, [&]() { launch_smooth_fused(st, d, o2, W, H, 5, 1, rows); });
+            }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 14) {  // channel-parallel marching K-cost (k_cost_march4) against k_cost_march and k_cost_split: bits + timing over strip heights: kbench W H reps 14
         float *o2; CK(hipMalloc(&o2, 12 * n));
         float *cz; CK(hipMalloc(&cz, 12 * n));  // a "coarser" field for the seeded form: same size / sqrt(2)
@@ -435,18 +464,18 @@ int main(int argc, char **argv)
     }
     {
         auto run = [&](auto kern, int stx, int sty, int nt, const char *nm, int P = 5, int box = 1) {
-            const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 20) * sizeof(float);
+            const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 16 + UGSM_SMOOTH_PAD(stx)) * sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             const int stxn = (W + stx - 1) / stx, stn = stxn * ((H + sty - 1) / sty);
-            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn); });
+            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn, sty); });
         };
         for (int round = 0; round < 2; round++) {
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
-            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
+            run((k_smooth_fused<112, 39, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
+            run((k_smooth_fused<112, 39, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
+            run((k_smooth_fused<112, 39, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
+            run((k_smooth_fused<112, 39, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
+            run((k_smooth_fused<112, 39, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
+            run((k_smooth_fused<112, 39, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });

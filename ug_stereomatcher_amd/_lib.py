@@ -51,7 +51,7 @@ class Config(C.Structure):
 
 class LevelPlan(C.Structure):
     _fields_ = [("cost_kernel", C.c_int), ("smooth_kernel", C.c_int), ("smooth_rh", C.c_int), ("strip_rows", C.c_int), ("seed_fused", C.c_int),
-                ("reserved", C.c_int * 3)]
+                ("smooth_tile_rows", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class KernelStat(C.Structure):
@@ -309,7 +309,7 @@ def plan_level(W: int, H: int, **cfg_fields):
     st = lib.ugsm_plan_level(C.byref(cfg), W, H, C.byref(out))
     if st != 0:
         raise UgsmError(st, "ugsm_plan_level")
-    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused")}
+    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows")}
 
 
 def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):

@@ -691,26 +691,32 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 // VAR (development switches, tools/kbench.hip): bit 0 = literal per-plane division, bit 1 = per-pixel border selects
 // instead of the replica / repair scheme, bit 2 = west/east neighbours from LDS instead of the neighbouring lanes,
 // bit 3 = the box's halo without the box.  Product: VAR = 0.
+#ifndef UGSM_SMOOTH_PAD
+#define UGSM_SMOOTH_PAD(STX) ((STX) == 112 ? 0 : 4)
+#endif
 template <int STX, int STY, int NT, int VAR = 0>
 __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
-                                                  int tiles_x, int n_tiles)
+                                                  int tiles_x, int n_tiles, int sty)
 {
     constexpr int HX = 8, HY = 7;
     constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
-    constexpr int LW = RWID + 4;             // LDS row stride: +4 keeps rows 16-B aligned and off a 32-bank multiple
-    constexpr int LH = STY + 2 * HY;
+    constexpr int LW = RWID + UGSM_SMOOTH_PAD(STX);  // LDS row stride (rows 16-B aligned)
+    constexpr int LH = STY + 2 * HY;         // region rows of the TALLEST tile (register arrays and unrolled loops are sized for it)
     constexpr int QW = RWID / 4;             // quad columns
     constexpr int RPW = 64 / QW;             // whole region rows per wave: lane -> (row lane / QW, quad lane % QW), so
                                              // that a quad's west / east neighbours sit in the neighbouring lanes
     constexpr int RG = (NT / 64) * RPW;      // row groups
     constexpr int MAXR = (LH + RG - 1) / RG; // rows per thread per pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *f0 = smem, *f1 = smem + LH * LW, *f2 = smem + 2 * LH * LW;
+    // A tile is `sty` <= STY rows high (the host picks the height that fills whole rounds of workgroups: smooth_tile_rows);
+    // the region is LHr rows, the LDS planes are that long.
+    const int LHr = sty + 2 * HY;
+    float *f0 = smem, *f1 = smem + LHr * LW, *f2 = smem + 2 * LHr * LW;
 
     const int tid = threadIdx.x;
     int tile_x, tile_y;
     xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
-    const int tx0 = tile_x * STX, ty0 = tile_y * STY;
+    const int tx0 = tile_x * STX, ty0 = tile_y * sty;
     const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
     const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
@@ -718,14 +724,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
     // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
     {
-        const int r_lo = HY - h, r_hi = LH - (HY - h);
+        const int r_lo = HY - h, r_hi = LHr - (HY - h);
         constexpr int NLD = (LH * RWID + NT - 1) / NT;
         float v[NLD][3];
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
             const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            const bool need = it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
+            const bool need = r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
             const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
             // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
             // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
         for (int u = 0; u < NLD; u++) {
             const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            if (it < LH * RWID && r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
                 f0[r * LW + c] = v[u][0];
                 f1[r * LW + c] = v[u][1];
                 f2[r * LW + c] = v[u][2];
@@ -760,14 +766,14 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
     //  * pass-through of row 0 / column 0: their results are replaced by the old values (edge_nw).
     // Cells outside the image otherwise hold whatever the pass produces; no in-image pixel reads them.
     // (VAR & 2, development: the earlier per-pixel selects.)
-    const bool edge_e = x0 + RWID > W, edge_s = y0 + LH > H, edge_nw = x0 <= 0 || y0 <= 0;
+    const bool edge_e = x0 + RWID > W, edge_s = y0 + LHr > H, edge_nw = x0 <= 0 || y0 <= 0;
 
     for (int p = 1; p <= P; p++) {
         // pass p is needed (and valid) on the region shrunk to halo h-p -- and inside the image: cells above / left of / below /
         // right of it are never read by an in-image pixel (the replica row H and column W are re-established after every
         // write-back), so the tiles on the frame skip them.  (Round 3: a 1741 x 1153 level has 33 tile rows, the last one with ONE
         // image row -- 528 tiles on 512 workgroup slots, i.e. a second round that used to cost as much as the first.)
-        const int r_lo = max(HY - (h - p), -y0), r_hi = min(LH - (HY - (h - p)), H - y0);
+        const int r_lo = max(HY - (h - p), -y0), r_hi = min(LHr - (HY - (h - p)), H - y0);
         const bool col_on = lane_on && (c0 + 3 >= HX - (h - p)) && (c0 < RWID - (HX - (h - p))) && (c0 + 3 >= -x0) && (c0 < W - x0);
         float nv[MAXR][3][4];
         // one quad-row: the five-point sums and the division from registers, results into nv[u].  LIT = literal
@@ -888,7 +894,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
         if (!(VAR & 2) && (edge_e || edge_s)) {  // re-establish the east / south replicas
             if (edge_e) {
                 const int cW = W - x0;
-                for (int r = tid; r < LH; r += NT) {
+                for (int r = tid; r < LHr; r += NT) {
                     f0[r * LW + cW] = f0[r * LW + cW - 1]; f1[r * LW + cW] = f1[r * LW + cW - 1]; f2[r * LW + cW] = f2[r * LW + cW - 1];
                 }
             }
@@ -904,8 +910,8 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
 
     if (do_box) {
         // refresh the clamped replicas of out-of-image cells within tile+-2 (only edge tiles have any)
-        if (tx0 - 2 < 0 || ty0 - 2 < 0 || tx0 + STX + 2 > W || ty0 + STY + 2 > H) {
-            for (int it = tid; it < (STY + 4) * (STX + 4); it += NT) {
+        if (tx0 - 2 < 0 || ty0 - 2 < 0 || tx0 + STX + 2 > W || ty0 + sty + 2 > H) {
+            for (int it = tid; it < (sty + 4) * (STX + 4); it += NT) {
                 const int r = HY - 2 + it / (STX + 4), c = HX - 2 + it % (STX + 4);
                 const int gx = x0 + c, gy = y0 + r;
                 if (gx < 0 || gx >= W || gy < 0 || gy >= H) {
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
 #pragma unroll
         for (int u = 0; u < BMAXR; u++) {
             const int r = HY - 2 + brg + u * BRG;
-            if (brg < BRG && r < HY + STY + 2) {
+            if (brg < BRG && r < HY + sty + 2) {
                 const int at = r * LW + bc0;
 #pragma unroll
                 for (int f = 0; f < 3; f++) {
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
 #pragma unroll
         for (int u = 0; u < BMAXR; u++) {
             const int r = HY - 2 + brg + u * BRG;
-            if (brg < BRG && r < HY + STY + 2) {
+            if (brg < BRG && r < HY + sty + 2) {
                 const int at = r * LW + bc0;
                 st4(f0 + at, bv[u][0]); st4(f1 + at, bv[u][1]); st4(f2 + at, bv[u][2]);
             }
@@ -953,7 +959,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
             const int r = HY + brg + u * BRG;
-            if (brg < BRG && r < HY + STY) {
+            if (brg < BRG && r < HY + sty) {
                 const int at = r * LW + bc0;
 #pragma unroll
                 for (int f = 0; f < 3; f++) {
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             for (int u = 0; u < CMAXR; u++) {
                 const int r = HY + brg + u * BRG;
                 const int gx = tx0 + bq * 4, gy = y0 + r;
-                if (brg < BRG && r < HY + STY && gx < W && gy < H) {
+                if (brg < BRG && r < HY + sty && gx < W && gy < H) {
                     const size_t at = (size_t)gy * W + gx;
 #pragma unroll
                     for (int f = 0; f < 3; f++)
@@ -983,13 +989,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
 #pragma unroll
         for (int u = 0; u < CMAXR; u++) {
             const int r = HY + brg + u * BRG;
-            if (brg < BRG && r < HY + STY) {
+            if (brg < BRG && r < HY + sty) {
                 const int at = r * LW + bc0;
                 st4(f0 + at, cv[u][0]); st4(f1 + at, cv[u][1]); st4(f2 + at, cv[u][2]);
             }
         }
         __syncthreads();
-        for (int it = tid; it < STX * STY; it += NT) {
+        for (int it = tid; it < STX * sty; it += NT) {
             const int r = it / STX, c = it - r * STX;
             const int gx = tx0 + c, gy = ty0 + r;
             if (gx < W && gy < H) {
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
     } else {
-        for (int it = tid; it < STX * STY; it += NT) {
+        for (int it = tid; it < STX * sty; it += NT) {
             const int r = it / STX, c = it - r * STX;
             const int gx = tx0 + c, gy = ty0 + r;
             if (gx < W && gy < H) {
@@ -1220,10 +1226,10 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 #define UGSM_SMOOTH_SMALL_NT 512
 #endif
 template <int STX, int STY, int NT>
-static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
+static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int sty = 0)
 {
-    constexpr int LW = STX + 20, LH = STY + 14;
-    constexpr size_t bytes = 3 * (size_t)LH * LW * sizeof(float);
+    constexpr int LW = STX + 16 + UGSM_SMOOTH_PAD(STX), LH = STY + 14;
+    constexpr size_t max_bytes = 3 * (size_t)LH * LW * sizeof(float);
     // the attribute is per device: a process may hold contexts on several devices (the launch is made with the context's
     // device current); std::atomic so that contexts driven from different host threads do not race on the mask
     static std::atomic<unsigned long long> attr_mask{0};
@@ -1231,22 +1237,55 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_fused<STX, STY, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
         attr_mask.fetch_or(bit, std::memory_order_relaxed);
     }
-    const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + STY - 1) / STY);
-    hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles);
+    if (sty < 1 || sty > STY) sty = STY;
+    const size_t bytes = 3 * (size_t)(sty + 14) * LW * sizeof(float);
+    const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + sty - 1) / sty);
+    hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty);
 }
 
-void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
+// Tile height of the 112-column K-smooth tile for a W x H level.  The kernel's tile may be any height up to kSmoothTileRowsMax; two
+// workgroups are resident per CU, 512 in all.
+//  * Several pairs in flight (`latency` = 0), or a level of many rounds of workgroups (> 3): 36 rows, as always.  (Taller tiles do
+//    less halo work, and on random fields tools/kbench mode 15 has 39 rows 6 % faster at 16 MP; on real pairs in the pipeline the
+//    level-0 launch is 212 us at 39 rows against 208 at 36, and tools/ab.py has four slots at -0.2 %.)
+//  * A level of a few rounds with the chip to itself: a launch lasts (whole rounds) x (region rows), so a level whose tiles at full
+//    height need a few workgroups more than a whole number of rounds pays a round for them (1742 x 1154: 16 x 33 tiles of 36 rows
+//    = 1.03 rounds, 51 us in the pipeline; 16 x 32 tiles of 37 rows = one round, 42 us).  The height that minimises
+//    rounds x region rows; among equals the fewest tiles.  Worth 0.3 % of a 16 MP pair alone on the chip (tools/ab.py).
+int smooth_tile_rows(int W, int H, int latency)
 {
-    // big levels: 112x36 tiles, 512 threads, 79 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
+    constexpr int STX = 112, HMAX = kSmoothTileRowsMax, HDEF = 36, HMIN = 16, SLOTS = 2 * 256;
+    const int tiles_x = (W + STX - 1) / STX;
+    const int rows_min = (H + HMAX - 1) / HMAX;
+    if (!latency || (long long)tiles_x * ((H + HDEF - 1) / HDEF) > 3 * SLOTS) return HDEF;
+    int best = 0;
+    long long best_cost = 0, best_tiles = 0;
+    for (int n_rows = rows_min; n_rows <= (H + HMIN - 1) / HMIN; n_rows++) {
+        const int sty = (H + n_rows - 1) / n_rows;
+        if (sty > HMAX || sty < HMIN) continue;
+        const long long tiles = (long long)tiles_x * ((H + sty - 1) / sty);
+        const long long cost = ((tiles + SLOTS - 1) / SLOTS) * (sty + 14);
+        if (!best || cost < best_cost || (cost == best_cost && tiles < best_tiles)) {
+            best = sty;
+            best_cost = cost;
+            best_tiles = tiles;
+        }
+    }
+    return best ? best : std::min(HMAX, std::max(H, 1));
+}
+
+void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows)
+{
+    // big levels: 112 x (up to 39) tiles, 512 threads, <= 81 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
     // the other's passes; measured, the two phases still nearly add up: DESIGN.md section 4).  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
     // columns every pass recomputes are 12.5 % of the row instead of 20 % (at 16 MP: 5 passes 227 us against 266 us for
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (px >= ((size_t)1 << 19)) launch_smooth_t<112, 36, 512>(st, s3, o3, W, H, passes, do_box);
+    if (px >= ((size_t)1 << 19)) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36);
     else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }

@@ -68,7 +68,10 @@ void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *r
 // Five Jacobi passes (+ the box when do_box) as a marching kernel (ugsm_kernels_march.hip); np / rows as for launch_cost_march.
 void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
-void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box);
+// tile_rows: height of the 112-column tile of the large levels (>= 0.5 Mpx), 1..kSmoothTileRowsMax; 0 = 36.  smooth_tile_rows picks it.
+constexpr int kSmoothTileRowsMax = 39;  // 3 x 53 x 128 floats = 81 408 B of LDS: two workgroups still fit a CU's 160 KB
+void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows = 0);
+int smooth_tile_rows(int W, int H, int latency);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad);

@@ -181,6 +181,7 @@ struct ugsm_ctx {
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
     int march4_lo = 0, march4_hi = 0;  // levels of lo..hi pixels run K-cost as k_cost_march4 (use_march4; 0, 0 = none)
+    int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
 };
 
 namespace {
@@ -408,6 +409,7 @@ struct DevKnobs {
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
+    int smooth_rows = 0;     // UGSM_SMOOTH_ROWS: tile height of the large levels' K-smooth (1..39), -1 / -2 = the latency / throughput rule whatever the slots
     int march4_lo = -1, march4_hi = -1;  // UGSM_MARCH4=lo,hi: pixel range of k_cost_march4 (0,0 = never; default: march4_default_range)
 };
 bool dev_env_on()
@@ -430,6 +432,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_FUSE_SEED", k.fuse_seed);
     geti("UGSM_COARSE_GRAPH", k.graph);
     geti("UGSM_TWO_STREAMS", k.two_streams);
+    geti("UGSM_SMOOTH_ROWS", k.smooth_rows);
     if (const char *e = getenv("UGSM_MARCH_AGE")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
@@ -550,6 +553,15 @@ bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
     return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(cfg, W, H) || use_march4(ctx, W, H));
 }
 
+// Height of the 112-column tile of k_smooth_fused on a W x H level (smooth_tile_rows, ugsm_kernels_fused.hip): a pair alone on the
+// chip (one-slot context) wants whole rounds of workgroups, several pairs in flight want the least total work.
+int smooth_rows_for(const ugsm_ctx *ctx, int W, int H)
+{
+    if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
+    const int latency = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
+    return smooth_tile_rows(W, H, latency);
+}
+
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
 // result and `b` is scratch.
 // final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
@@ -581,7 +593,7 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
             if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, 1, ctx->cfg.march_rows);
             else if (rh) launch_smooth_small(s.st, a, dst, W, H, p, box_now, rh);
-            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now);
+            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H));
             if (dst == final_out) a = final_out;
             else std::swap(a, b);
         } while (left > 0);
@@ -1076,6 +1088,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->small_mask = knobs.small_mask;
     ctx->fuse_seed = knobs.fuse_seed;
     ctx->small_rh_force = knobs.small_rh_force;
+    ctx->smooth_rows = knobs.smooth_rows;
     march4_default_range(ctx->cfg, ctx->march4_lo, ctx->march4_hi);
     if (knobs.march4_hi >= 0) ctx->march4_lo = knobs.march4_lo, ctx->march4_hi = knobs.march4_hi;
     // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
@@ -1148,6 +1161,7 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
         probe.small_mask = knobs.small_mask;
         probe.fuse_seed = knobs.fuse_seed;
         probe.small_rh_force = knobs.small_rh_force;
+        probe.smooth_rows = knobs.smooth_rows;
         march4_default_range(probe.cfg, probe.march4_lo, probe.march4_hi);
         if (knobs.march4_hi >= 0) probe.march4_lo = knobs.march4_lo, probe.march4_hi = knobs.march4_hi;
     }
@@ -1164,6 +1178,7 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
     out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1)) : 0);
     out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
+    out->smooth_tile_rows = (out->smooth_kernel == 0 && (long long)W * H >= (1ll << 19)) ? smooth_rows_for(&probe, W, H) : 0;
     return UGSM_OK;
 }
 int ugsm_threshold_schedule(int mi, float *out)
