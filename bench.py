@@ -178,8 +178,8 @@ def spawn_ranks(args) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=96, help="pairs of the timed region (a short region under-reports: filling and draining the slots is a larger share of it)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="full16mp", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU (HIP streams)")
     ap.add_argument("--kernel-path", type=int, default=0)

@@ -14,13 +14,15 @@ def levels_16mp():
 
 def test_default_plan_of_a_16mp_pyramid_with_several_pairs_in_flight():
     plans = [_lib.plan_level(w, h, slots=4) for (w, h) in levels_16mp()]
-    # levels 0-6 (>= 0.2 Mpx) march and carry their own seeding; levels 7-13 (<= 0.15 Mpx) run the latency kernels on 18 x 18 tiles
-    assert [p["cost_kernel"] for p in plans] == [MARCH] * 7 + [SMALL] * 7
-    assert [p["smooth_kernel"] for p in plans] == [TILED] * 7 + [SMALL] * 7
-    assert [p["seed_fused"] for p in plans] == [1] * 7 + [0] * 7
-    assert all(p["smooth_rh"] == 32 for p in plans[7:]) and all(p["smooth_rh"] == 0 for p in plans[:7])
-    rows = [p["strip_rows"] for p in plans[:7]]
-    assert rows[0] == 91 and all(6 <= r <= 100 for r in rows) and all(p["strip_rows"] == 0 for p in plans[7:])
+    # the chip is full anyway, so the kernel with the least work per pixel runs every level it can: levels 0-8 (>= 50 k pixels) march
+    # and carry their own seeding, K-smooth runs its 112 x 36 tile down to 0.1 Mpx; levels 9-13 run the latency kernels on 18 x 18 tiles
+    assert [p["cost_kernel"] for p in plans] == [MARCH] * 9 + [SMALL] * 5
+    assert [p["smooth_kernel"] for p in plans] == [TILED] * 9 + [SMALL] * 5
+    assert [p["seed_fused"] for p in plans] == [1] * 9 + [0] * 5
+    assert all(p["smooth_rh"] == 32 for p in plans[9:]) and all(p["smooth_rh"] == 0 for p in plans[:9])
+    assert [p["smooth_tile_rows"] for p in plans] == [36] * 8 + [0] * 6
+    rows = [p["strip_rows"] for p in plans[:9]]
+    assert rows[0] == 91 and all(6 <= r <= 100 for r in rows) and all(p["strip_rows"] == 0 for p in plans[9:])
 
 
 def test_one_slot_context_is_tuned_for_a_pair_alone():
@@ -37,7 +39,7 @@ def test_switches():
     assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
     assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0,
                                                                      smooth_tile_rows=36)
-    assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
+    assert _lib.plan_level(200, 150, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
     assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=1)["cost_kernel"] == MARCH4   # a pair alone: the latency form takes over
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
     assert _lib.plan_level(300, 200, march_min_pixels=1, march_rows=17)["strip_rows"] == 17
@@ -61,7 +63,7 @@ def test_strip_rows_fill_the_chip_or_one_round():
 def test_smooth_tile_rows_fill_whole_rounds_for_a_pair_alone_and_are_36_otherwise():
     """k_smooth_fused's 112-column tile (levels >= 0.5 Mpx) may be 16..39 rows high; 512 workgroups are resident at a time."""
     lv = levels_16mp()
-    assert [_lib.plan_level(w, h, slots=4)["smooth_tile_rows"] for (w, h) in lv] == [36] * 5 + [0] * 9
+    assert [_lib.plan_level(w, h, slots=4)["smooth_tile_rows"] for (w, h) in lv] == [36] * 8 + [0] * 6
     one = [_lib.plan_level(w, h, slots=1)["smooth_tile_rows"] for (w, h) in lv]
     assert one == [36, 36, 36, 37, 18] + [0] * 9
     for (w, h), rows in list(zip(lv, one))[2:5]:            # the few-round levels: no partial round

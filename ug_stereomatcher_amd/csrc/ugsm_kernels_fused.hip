@@ -1285,7 +1285,7 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
     // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (px >= ((size_t)1 << 19)) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36);
+    if (tile_rows > 0 || px >= ((size_t)1 << 19)) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36);
     else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }

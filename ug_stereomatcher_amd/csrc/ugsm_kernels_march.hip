@@ -522,7 +522,9 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 // 4.3 extra steps at one wave per SIMD, 1.83 us and 7.3 at two, 2.6 us and 6.5 at three.  Take the shortest strips that fit for each w
 // and keep the w that finishes first: large levels end up at the full occupancy with tall strips (6 halo rows recomputed per strip
 // matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
-int march_strip_rows(int W, int H, int np)
+// `throughput` (several pairs in flight: other pairs' kernels share the SIMDs whatever this launch does): the tallest strips that
+// are still all resident -- the fewest halo rows.
+int march_strip_rows(int W, int H, int np, int throughput)
 {
 #ifndef UGSM_DEV_KERNELS
     np = 1;
@@ -533,12 +535,12 @@ int march_strip_rows(int W, int H, int np)
     const int max_w = np == 2 ? MARCH_WAVES(2) : MARCH_WAVES(1);
     float best = 0.0f;
     int Hs = 6;
-    for (int w = 1; w <= max_w && w <= 3; w++) {
+    for (int w = throughput ? (max_w < 3 ? max_w : 3) : 1; w <= max_w && w <= 3; w++) {
         const int sy = (256 * 4 * w / strips_x) > 0 ? (256 * 4 * w / strips_x) : 1;  // strips per column of strips that still fit
         int h = (H + sy - 1) / sy;
         if (h < 6) h = 6;
         const float t = t_step[w - 1] * ((float)h + extra[w - 1]);
-        if (w == 1 || t < best) {
+        if (best == 0.0f || t < best) {
             best = t;
             Hs = h;
         }
@@ -560,7 +562,10 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
 {
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
-    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP);
+    // rows: > 0 a fixed strip height; 0 the latency heights and strips by age class; -1 the latency heights, no age classes; -2 the
+    // throughput heights, no age classes; -3 the throughput heights and age classes
+    const bool age = rows == 0 || rows == -3, tput = rows == -2 || rows == -3;
+    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP, tput);
     int strips_y = (H + Hs - 1) / Hs;
     int n_strips = strips_x * strips_y;
     int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
@@ -568,7 +573,7 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     // three waves per SIMD (the large levels: every strip resident at once, 3 x 1024 of them): strips by age class.  One dispatch
     // round = one workgroup per CU, so a class is exactly `cus` workgroups (blockIdx / cus = the wave's rank on its SIMD); the
     // strips of a class must fit into them (4 x cus strips), which fixes the number of strip groups and with it the group height.
-    if (NP == 1 && rows <= 0 && march_age_permille[0] > 0 && n_strips > 2 * 1024 && n_strips <= 3 * 1024 + strips_x) {
+    if (NP == 1 && age && march_age_permille[0] > 0 && n_strips > 2 * 1024 && n_strips <= 3 * 1024 + strips_x) {
         const int cus = 256;
         const int n_groups = (MARCH_WPB * cus) / strips_x;
         const int Hg = n_groups > 0 ? (H + n_groups - 1) / n_groups : 0;

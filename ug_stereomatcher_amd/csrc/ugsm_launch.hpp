@@ -53,7 +53,7 @@ void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int 
 // strips by age class (ugsm_kernels_march.hip): share (per mille) of a strip group's rows for the first / second wave of a SIMD; {0, 0} = uniform
 extern int march_age_permille[2];
 // strip height the marching K-cost picks for a W x H level (np = pixels per lane); host only
-int march_strip_rows(int W, int H, int np);
+int march_strip_rows(int W, int H, int np, int throughput = 0);
 // First iteration of a level with the seeding fused in: coarse3 = the coarser level's field (never materialised at this level's size)
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
                               int blend, int rows, const unsigned *range_bad);
@@ -68,7 +68,8 @@ void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *r
 // Five Jacobi passes (+ the box when do_box) as a marching kernel (ugsm_kernels_march.hip); np / rows as for launch_cost_march.
 void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
-// tile_rows: height of the 112-column tile of the large levels (>= 0.5 Mpx), 1..kSmoothTileRowsMax; 0 = 36.  smooth_tile_rows picks it.
+// tile_rows: > 0 = the 112-column tile at this height (1..kSmoothTileRowsMax; smooth_tile_rows picks it); 0 = the tile class by the
+// level's size (112 x 36 from 0.5 Mpx, 64 x 32 from 0.13 Mpx, else 32 x 16).
 constexpr int kSmoothTileRowsMax = 39;  // 3 x 53 x 128 floats = 81 408 B of LDS: two workgroups still fit a CU's 160 KB
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows = 0);
 int smooth_tile_rows(int W, int H, int latency);

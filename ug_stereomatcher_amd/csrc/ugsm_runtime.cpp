@@ -181,6 +181,8 @@ struct ugsm_ctx {
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
     int march4_lo = 0, march4_hi = 0;  // levels of lo..hi pixels run K-cost as k_cost_march4 (use_march4; 0, 0 = none)
+    int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
+    int smooth_big_min = 1 << 19;  // levels of at least this many pixels run k_smooth_fused on its 112-column tile
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
 };
 
@@ -409,6 +411,10 @@ struct DevKnobs {
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
+    char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
+    char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
+    int march_mode = 1;      // UGSM_MARCH_MODE=0,-1,-2,-3: launch_cost_march's strip-height / age-class mode (default: by the slots)
+    int smooth_big_min = 0;  // UGSM_SMOOTH_BIG_MIN: pixel count from which K-smooth uses the 112-column tile (default 2^19)
     int smooth_rows = 0;     // UGSM_SMOOTH_ROWS: tile height of the large levels' K-smooth (1..39), -1 / -2 = the latency / throughput rule whatever the slots
     int march4_lo = -1, march4_hi = -1;  // UGSM_MARCH4=lo,hi: pixel range of k_cost_march4 (0,0 = never; default: march4_default_range)
 };
@@ -433,6 +439,10 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_COARSE_GRAPH", k.graph);
     geti("UGSM_TWO_STREAMS", k.two_streams);
     geti("UGSM_SMOOTH_ROWS", k.smooth_rows);
+    geti("UGSM_MARCH_MODE", k.march_mode);
+    if (const char *e = getenv("UGSM_STREAM_PRIO")) snprintf(k.stream_prio, sizeof k.stream_prio, "%s", e);
+    if (const char *e = getenv("UGSM_SIDE_PRIO")) k.side_prio = e[0];
+    geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
     if (const char *e = getenv("UGSM_MARCH_AGE")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
@@ -494,16 +504,21 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
 
 // K-cost / K-smooth as the marching kernels (ugsm_kernels_march.hip) or the LDS-tiled ones: a strip of a marching kernel is one wave
 // working down >= 16 rows, so a level must be large enough to fill the chip with strips.
-// Default threshold (tools/sweep of UGSM_MARCH_MIN_PIXELS, 16 MP pairs): with several pairs in flight the marching kernel pays down
-// to the 0.25 Mpx level (it does less work per pixel than the tiles with their halos: 159.9 against 157.3 pairs/s); a pair alone on the
-// chip is a little faster with the LDS-tiled kernel there (106.4 against 105.4 pairs/s), so a one-slot context stops at 0.5 Mpx.
-constexpr int kMarchDefaultMinPixels = 200000, kMarchDefaultMinPixelsOneSlot = 400000;
+// Default threshold (tools/ab.py on UGSM_MARCH_MIN_PIXELS, 16 MP pairs): with several pairs in flight the chip is full whatever a
+// launch looks like and the kernel that does the least work per pixel wins -- the marching kernel (6 halo rows per strip) against the
+// tiles and their halos, down to the 63 k-pixel level: 163.2 pairs/s at a threshold of 50 000, 162.7 at 100 000, 160.4 at 200 000
+// (round 2's value), 159.1 at 400 000; below 50 000 the coarse-level latency kernels win again (161.4 with everything marching).  A
+// pair alone on the chip is a little faster with the LDS-tiled kernel at 0.25 Mpx (106.4 against 105.4 pairs/s), so a one-slot context
+// stops at 0.5 Mpx -- and runs its levels of 0.15 - 3 Mpx through k_cost_march4 anyway (use_march4).
+constexpr int kMarchDefaultMinPixels = 50000, kMarchDefaultMinPixelsOneSlot = 400000;
 bool use_march(const ugsm_config &cfg, int W, int H)
 {
     if (cfg.march_min_pixels < 0) return false;
     const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (cfg.slots > 1 ? kMarchDefaultMinPixels : kMarchDefaultMinPixelsOneSlot);
     return (long long)W * H >= thr;
 }
+
+int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
 
 // K-cost as the channel-parallel marching kernel (ugsm_kernels_march4.hip): a workgroup of four waves per strip, a third of the
 // instructions per row step on any one wave.  It wins where a launch lasts as long as one strip -- levels too small to give every SIMD
@@ -524,6 +539,26 @@ bool use_march4(const ugsm_ctx *ctx, int W, int H)
     const long long px = (long long)W * H;
     return ctx->cfg.kernel_path != 1 && ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
 }
+
+// The per-level kernel choices of a context that are not in ugsm_config: defaults by the number of slots -- a pair alone on the chip
+// wants every launch short, several pairs in flight want every launch to do the least work (the chip is full anyway; tools/ab.py,
+// four slots, 16 MP, same box: 160.4 pairs/s with the one-slot choices, 166.5 with these) -- then the development overrides.
+void set_policy(ugsm_ctx *c, const DevKnobs &k)
+{
+    const bool alone = c->cfg.slots == 1;
+    c->small_mask = k.small_mask;
+    c->fuse_seed = k.fuse_seed;
+    c->small_rh_force = k.small_rh_force;
+    c->smooth_rows = k.smooth_rows;
+    // K-smooth on the 112 x 36 tile (1.39 x the tile in halo work) instead of 64 x 32 (1.8 x) from 0.1 Mpx on: +1.7 % with four slots
+    c->smooth_big_min = k.smooth_big_min > 0 ? k.smooth_big_min : (alone ? (1 << 19) : 100000);
+    // strips by age class, every context: +8 % on a level-0 launch alone on the chip, +1.2 % on a pair alone; with four pairs in
+    // flight it costs 0.4 % (163.2 against 163.7 pairs/s) -- kept on there too, so that a kernel measured alone is the kernel that ran
+    c->march_mode = k.march_mode <= 0 ? k.march_mode : 0;
+    march4_default_range(c->cfg, c->march4_lo, c->march4_hi);
+    if (k.march4_hi >= 0) c->march4_lo = k.march4_lo, c->march4_hi = k.march4_hi;
+}
+
 
 // K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
 // has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
@@ -557,6 +592,7 @@ bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
 // chip (one-slot context) wants whole rounds of workgroups, several pairs in flight want the least total work.
 int smooth_rows_for(const ugsm_ctx *ctx, int W, int H)
 {
+    if ((long long)W * H < ctx->smooth_big_min) return 0;  // (the smaller tile classes)
     if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
     const int latency = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
     return smooth_tile_rows(W, H, latency);
@@ -679,8 +715,8 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
                 launch_cost_march4(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, s.range_known ? s.range_bad : nullptr,
                                    (seed && m == m_from) ? *seed : SeedMap{0, 0, 0, 0});
             else if (march && seed && m == m_from)
-                launch_cost_march_seeded(s.st, L, R, A3, cur, *seed, other, W, H, thr[m - 1], blend, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
-            else if (march) launch_cost_march(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, 1, ctx->cfg.march_rows, s.range_known ? s.range_bad : nullptr);
+                launch_cost_march_seeded(s.st, L, R, A3, cur, *seed, other, W, H, thr[m - 1], blend, march_rows_arg(ctx), s.range_known ? s.range_bad : nullptr);
+            else if (march) launch_cost_march(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, 1, march_rows_arg(ctx), s.range_known ? s.range_bad : nullptr);
             else if (small) launch_cost_small(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
             else launch_cost_fused(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
         }
@@ -1085,20 +1121,27 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (hipSetDevice(cfg.device) != hipSuccess) return UGSM_ERR_NO_DEVICE;
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
-    ctx->small_mask = knobs.small_mask;
-    ctx->fuse_seed = knobs.fuse_seed;
-    ctx->small_rh_force = knobs.small_rh_force;
-    ctx->smooth_rows = knobs.smooth_rows;
-    march4_default_range(ctx->cfg, ctx->march4_lo, ctx->march4_hi);
-    if (knobs.march4_hi >= 0) ctx->march4_lo = knobs.march4_lo, ctx->march4_hi = knobs.march4_hi;
+    set_policy(ctx, knobs);
     // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
     // beside the left pyramid and the coarse levels).  With four pairs in flight it LOSES 13 % (136 against 157 pairs/s): eight
     // streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So: one-slot contexts only.
     ctx->two_streams = knobs.two_streams >= 0 ? knobs.two_streams : (cfg.slots == 1 ? 1 : 0);
     ctx->slots.resize(cfg.slots);
-    for (Slot &s : ctx->slots) {
-        bool ok = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&s.range_bad, 64) == hipSuccess &&
-                  hipStreamCreateWithFlags(&s.st2, hipStreamNonBlocking) == hipSuccess;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    for (int si = 0; si < cfg.slots; si++) {
+        Slot &s = ctx->slots[si];
+        // Every slot's stream on a hardware queue of its own.  HIP deals a process's streams onto GPU_MAX_HW_QUEUES (4) hardware
+        // queues PER PRIORITY LEVEL, least-used first, and two streams that share a queue run their kernels strictly one after
+        // the other (tools/queue_probe).  At the default priority the host application's streams -- the null stream any hipMemcpy
+        // uses, for a start -- hold queues of the same pool, and four slots then land on three queues: 128 pairs/s instead of 165
+        // at 16 MP (tools/ab.py; round 2 measured 161 only because its idle side streams happened to push the slots apart).  So:
+        // slots 0-3 at the greatest priority (a pool the application is unlikely to use), slots 4-7 at the least, the rest at the
+        // default.  Equal priority among the first four; the side stream of a one-slot context rides in the same pool.
+        const char pc = knobs.stream_prio[0] ? (si < (int)strlen(knobs.stream_prio) ? knobs.stream_prio[si] : 'n') : (si < 4 ? 'h' : (si < 8 ? 'l' : 'n'));
+        const int prio = pc == 'h' ? prio_greatest : (pc == 'l' ? prio_least : 0);
+        bool ok = hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess && hipMalloc((void **)&s.range_bad, 64) == hipSuccess &&
+                  (!ctx->two_streams || hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : prio))) == hipSuccess);
         for (hipEvent_t *e : {&s.ev_in, &s.ev_L, &s.ev_R}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < cfg.levels; i++) ok = ok && hipEventCreateWithFlags(&s.ev_A[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
@@ -1158,12 +1201,7 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     {   // ... under the same development overrides ugsm_create would apply in this process (none unless UGSM_DEV=1)
         DevKnobs knobs;
         apply_dev_env(probe.cfg, knobs);
-        probe.small_mask = knobs.small_mask;
-        probe.fuse_seed = knobs.fuse_seed;
-        probe.small_rh_force = knobs.small_rh_force;
-        probe.smooth_rows = knobs.smooth_rows;
-        march4_default_range(probe.cfg, probe.march4_lo, probe.march4_hi);
-        if (knobs.march4_hi >= 0) probe.march4_lo = knobs.march4_lo, probe.march4_hi = knobs.march4_hi;
+        set_policy(&probe, knobs);
     }
     memset(out, 0, sizeof *out);
     if (probe.cfg.kernel_path == 1) {
@@ -1176,9 +1214,9 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
     out->cost_kernel = march4 ? 4 : (march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0));
     out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
-    out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1)) : 0);
+    out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1, probe.march_mode <= -2)) : 0);
     out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
-    out->smooth_tile_rows = (out->smooth_kernel == 0 && (long long)W * H >= (1ll << 19)) ? smooth_rows_for(&probe, W, H) : 0;
+    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H) : 0;
     return UGSM_OK;
 }
 int ugsm_threshold_schedule(int mi, float *out)
