@@ -105,16 +105,21 @@ int ugsm_fovea_dims(int W, int H, int levels, int fovea_levels, int *fovW, int *
 long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
 
 /* Which kernels a W x H level runs under `cfg` (NULL = defaults), for maintainers and the host tests; results never depend on it.
+ * The choice depends on what is in flight: `frame_w` x `frame_h` is what the call matches at its finest level (the image in full
+ * mode, the fovea window in foveated mode); ugsm_plan_level takes the level itself as the frame.
+ * latency_policy: 1 = the call has the chip to itself at least some of the time (one slot, or frames below 6 Mpx): every launch as
+ * short as possible; 0 = several large pairs in flight: every launch does the least work.
  * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_cost_split / k_smooth_fused), 1 = marching (k_cost_march / k_smooth_march),
  * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1),
- * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4: the mid levels of a one-slot context);
+ * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4);
  * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
  * seed_fused: 1 if the level's seeding rides on its first K-cost launch; smooth_tile_rows: height of k_smooth_fused's 112-column
- * tile on a level of >= 0.5 Mpx (else 0) -- whole rounds of workgroups for a one-slot context, least halo work otherwise. */
+ * tile where that tile is used (else 0). */
 typedef struct ugsm_level_plan {
-    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, reserved[2];
+    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, latency_policy, reserved[1];
 } ugsm_level_plan;
 int ugsm_plan_level(const ugsm_config *cfg, int W, int H, ugsm_level_plan *out);
+int ugsm_plan_level_in_frame(const ugsm_config *cfg, int frame_w, int frame_h, int W, int H, ugsm_level_plan *out);
 
 /* ---- the service path: host buffers in, host buffers out ------------------------ */
 

@@ -7,13 +7,17 @@ from ug_stereomatcher_amd import _lib
 TILED, MARCH, SMALL, STAGED, MARCH4 = 0, 1, 2, 3, 4
 
 
+FRAME = (4928, 3264)
+
+
 def levels_16mp():
-    w, h = _lib.level_dims(4928, 3264, 14)
+    w, h = _lib.level_dims(*FRAME, 14)
     return list(zip(w, h))
 
 
 def test_default_plan_of_a_16mp_pyramid_with_several_pairs_in_flight():
-    plans = [_lib.plan_level(w, h, slots=4) for (w, h) in levels_16mp()]
+    plans = [_lib.plan_level(w, h, frame=FRAME, slots=4) for (w, h) in levels_16mp()]
+    assert all(p["latency_policy"] == 0 for p in plans)
     # the chip is full anyway, so the kernel with the least work per pixel runs every level it can: levels 0-8 (>= 50 k pixels) march
     # and carry their own seeding, K-smooth runs its 112 x 36 tile down to 0.1 Mpx; levels 9-13 run the latency kernels on 18 x 18 tiles
     assert [p["cost_kernel"] for p in plans] == [MARCH] * 9 + [SMALL] * 5
@@ -26,20 +30,36 @@ def test_default_plan_of_a_16mp_pyramid_with_several_pairs_in_flight():
 
 
 def test_one_slot_context_is_tuned_for_a_pair_alone():
-    plans = [_lib.plan_level(w, h, slots=1) for (w, h) in levels_16mp()]
+    plans = [_lib.plan_level(w, h, frame=FRAME, slots=1) for (w, h) in levels_16mp()]
+    assert all(p["latency_policy"] == 1 for p in plans)
     # levels 3-6 (0.25 - 2 Mpx): a launch lasts as long as one strip, so the strip's channels go side by side (k_cost_march4)
     assert [p["cost_kernel"] for p in plans] == [MARCH] * 3 + [MARCH4] * 4 + [SMALL] * 7
     assert [p["seed_fused"] for p in plans] == [1] * 7 + [0] * 7
     assert all(6 <= p["strip_rows"] <= 40 for p in plans[3:7])
-    assert all(p["cost_kernel"] != MARCH4 for p in [_lib.plan_level(w, h, slots=2) for (w, h) in levels_16mp()])
     assert [p["smooth_rh"] for p in plans[7:]] == [32, 24, 18, 18, 18, 18, 18]           # the smallest tile that still fills the chip
+    assert all(p["cost_kernel"] != MARCH4 for p in [_lib.plan_level(w, h, frame=FRAME, slots=2) for (w, h) in levels_16mp()])
+
+
+def test_several_slots_with_small_frames_keep_the_latency_choices():
+    """The chip is full only if the frames are: four slots of 4 MP frames, 1080p frames or 0.25 Mpx fovea windows run the one-slot
+    kernels (tools/ab.py: +3.9 % at 4 MP, +16 % on the foveated stack against the throughput choices), 8 MP frames do not."""
+    for frame, lat in [((2464, 1632), 1), ((1920, 1080), 1), ((615, 407), 1), ((3484, 2308), 0), ((4928, 3264), 0)]:
+        w, h = _lib.level_dims(*frame, 14)
+        plans = [_lib.plan_level(a, b, frame=frame, slots=4) for (a, b) in zip(w, h)]
+        assert all(p["latency_policy"] == lat for p in plans), frame
+        mid = [p for (a, b), p in zip(zip(w, h), plans) if 150000 < a * b <= 3000000]
+        assert mid and all((p["cost_kernel"] == MARCH4) == bool(lat) for p in mid), frame
+        assert all(p["smooth_rh"] in (0, 32) for p in plans)                       # several slots: never the short K-smooth regions
+    # a level on its own is taken as a frame of its size
+    assert _lib.plan_level(615, 407, slots=4) == _lib.plan_level(615, 407, frame=(615, 407), slots=4)
+    assert _lib.plan_level(615, 407, slots=4)["cost_kernel"] == MARCH4 and _lib.plan_level(615, 407, frame=FRAME, slots=4)["cost_kernel"] == MARCH
 
 
 def test_switches():
     assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
     assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0,
-                                                                     smooth_tile_rows=36)
-    assert _lib.plan_level(200, 150, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
+                                                                     smooth_tile_rows=36, latency_policy=1)
+    assert _lib.plan_level(200, 150, frame=FRAME, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
     assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=1)["cost_kernel"] == MARCH4   # a pair alone: the latency form takes over
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
     assert _lib.plan_level(300, 200, march_min_pixels=1, march_rows=17)["strip_rows"] == 17
@@ -54,7 +74,7 @@ def test_strip_rows_fill_the_chip_or_one_round():
     """The strips of a marching level never need more than three waves per SIMD (3 072 strips of 58 columns), and small levels get
     short strips (a launch lasts as long as one strip)."""
     for (w, h) in levels_16mp()[:7] + [(1920, 1080), (615, 407), (871, 577)]:
-        rows = _lib.plan_level(w, h, slots=4, march_min_pixels=1)["strip_rows"]
+        rows = _lib.plan_level(w, h, frame=FRAME, slots=4, march_min_pixels=1)["strip_rows"]
         strips = -(-w // 58) * -(-h // rows)
         assert rows >= 6 and strips <= 3072 + (-(-w // 58)), (w, h, rows, strips)
     assert _lib.plan_level(871, 577, march_min_pixels=1)["strip_rows"] <= 12
@@ -63,8 +83,8 @@ def test_strip_rows_fill_the_chip_or_one_round():
 def test_smooth_tile_rows_fill_whole_rounds_for_a_pair_alone_and_are_36_otherwise():
     """k_smooth_fused's 112-column tile (levels >= 0.5 Mpx) may be 16..39 rows high; 512 workgroups are resident at a time."""
     lv = levels_16mp()
-    assert [_lib.plan_level(w, h, slots=4)["smooth_tile_rows"] for (w, h) in lv] == [36] * 8 + [0] * 6
-    one = [_lib.plan_level(w, h, slots=1)["smooth_tile_rows"] for (w, h) in lv]
+    assert [_lib.plan_level(w, h, frame=FRAME, slots=4)["smooth_tile_rows"] for (w, h) in lv] == [36] * 8 + [0] * 6
+    one = [_lib.plan_level(w, h, frame=FRAME, slots=1)["smooth_tile_rows"] for (w, h) in lv]
     assert one == [36, 36, 36, 37, 18] + [0] * 9
     for (w, h), rows in list(zip(lv, one))[2:5]:            # the few-round levels: no partial round
         tiles = -(-w // 112) * -(-h // rows)
@@ -97,5 +117,10 @@ def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
     monkeypatch.delenv("UGSM_SMOOTH_ROWS")
     monkeypatch.setenv("UGSM_MARCH4", "1,100000")
     assert _lib.plan_level(300, 200)["cost_kernel"] == MARCH4 and _lib.plan_level(400, 300)["cost_kernel"] != MARCH4
+    monkeypatch.setenv("UGSM_POLICY", "throughput")
+    assert _lib.plan_level(300, 200, slots=1)["latency_policy"] == 0
+    monkeypatch.setenv("UGSM_POLICY", "latency")
+    assert _lib.plan_level(4928, 3264, slots=4)["latency_policy"] == 1
+    monkeypatch.delenv("UGSM_POLICY")
     monkeypatch.setenv("UGSM_MARCH4", "0,0")
     assert all(_lib.plan_level(w, h, slots=1)["cost_kernel"] != MARCH4 for (w, h) in levels_16mp())

@@ -15,6 +15,7 @@ ap.add_argument("--pairs", type=int, default=48)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--levels", type=int, default=14)
 ap.add_argument("--size", type=int, nargs=2, default=(4928, 3264))
+ap.add_argument("--fovea", type=int, default=0, help="foveated mode with this many fovea levels (0 = full mode)")
 ap.add_argument("--child", action="store_true", help="(internal) measure under the current environment, print the rate")
 ap.add_argument("configs", nargs="*")
 args = ap.parse_args()
@@ -30,9 +31,11 @@ if args.child:
     for j in range(max(args.slots, 2)):
         L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + j)
         pairs.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
-    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(args.slots)]
+    F = args.fovea
+    fw, fh = _lib.fovea_dims(W, H, args.levels, F) if F else (W, H)
+    outs = [torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(args.slots)]
     torch.cuda.synchronize()
-    with _lib.Context(levels=args.levels, slots=args.slots) as c:
+    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F) as c:
         lib, h = c.lib, c.handle
 
         def run(n):
@@ -41,7 +44,10 @@ if args.child:
                 if i >= args.slots:
                     c.check(lib.ugsm_wait(h, s))
                 dL, dR = pairs[i % len(pairs)]
-                c.check(lib.ugsm_submit_full(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, outs[s].data_ptr()))
+                if F:
+                    c.check(lib.ugsm_submit_foveated(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, 0, 0, outs[s].data_ptr(), None, None))
+                else:
+                    c.check(lib.ugsm_submit_full(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, outs[s].data_ptr()))
             c.check(lib.ugsm_wait_all(h))
 
         run(3 * args.slots)
@@ -63,7 +69,7 @@ for r in range(args.rounds):
     for i in order:
         env = dict(os.environ, UGSM_DEV="1", **cfgs[i][1])
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--slots", str(args.slots), "--pairs", str(args.pairs), "--levels",
-                              str(args.levels), "--size", str(W), str(H)], env=env, capture_output=True, text=True, timeout=300)
+                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RATE")]
         if not line:
             print(out.stdout[-2000:], out.stderr[-2000:])
@@ -71,7 +77,7 @@ for r in range(args.rounds):
         rates[i].append(float(line[0].split()[1]))
         print(f"round {r} {cfgs[i][0]}: {rates[i][-1]:.2f}", flush=True)
 base = statistics.median(rates[0])
-print(f"{W}x{H}, {args.levels} levels, slots={args.slots}, {args.pairs} pairs x 3, {args.rounds} processes each (pairs/s: median  min  max  vs first)")
+print(f"{W}x{H}, {args.levels} levels{', fovea levels ' + str(args.fovea) if args.fovea else ''}, slots={args.slots}, {args.pairs} pairs x 3, {args.rounds} processes each (pairs/s: median  min  max  vs first)")
 for (name, env), rs in zip(cfgs, rates):
     m = statistics.median(rs)
     print(f"  {name:28s} {m:8.2f} {min(rs):8.2f} {max(rs):8.2f}  {100.0 * (m / base - 1.0):+6.2f} %   {env}")

@@ -27,7 +27,7 @@ UGSM_MAX_LEVELS = 32
 EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
-    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_match_full",
+    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full",
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
@@ -51,7 +51,7 @@ class Config(C.Structure):
 
 class LevelPlan(C.Structure):
     _fields_ = [("cost_kernel", C.c_int), ("smooth_kernel", C.c_int), ("smooth_rh", C.c_int), ("strip_rows", C.c_int), ("seed_fused", C.c_int),
-                ("smooth_tile_rows", C.c_int), ("reserved", C.c_int * 2)]
+                ("smooth_tile_rows", C.c_int), ("latency_policy", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class KernelStat(C.Structure):
@@ -90,6 +90,7 @@ def load():
     lib.ugsm_pixel_iterations.argtypes = [i, i, i, i]
     lib.ugsm_pixel_iterations.restype = C.c_longlong
     lib.ugsm_plan_level.argtypes = [C.POINTER(Config), i, i, C.POINTER(LevelPlan)]
+    lib.ugsm_plan_level_in_frame.argtypes = [C.POINTER(Config), i, i, i, i, C.POINTER(LevelPlan)]
     lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_match_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
     lib.ugsm_match_foveated_full.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp]
@@ -298,18 +299,20 @@ class Context:
         self.check(self.lib.ugsm_reset_kernel_stats(self._h))
 
 
-def plan_level(W: int, H: int, **cfg_fields):
-    """Which kernels a W x H level runs (host only): dict of ugsm_level_plan; cfg_fields override the default ugsm_config."""
+def plan_level(W: int, H: int, frame=None, **cfg_fields):
+    """Which kernels a W x H level runs (host only): dict of ugsm_level_plan; cfg_fields override the default ugsm_config.
+    frame = (w, h) of what the call matches at its finest level (default: the level itself)."""
     lib = load()
     cfg = Config()
     lib.ugsm_default_config(C.byref(cfg))
     for k, v in cfg_fields.items():
         setattr(cfg, k, v)
     out = LevelPlan()
-    st = lib.ugsm_plan_level(C.byref(cfg), W, H, C.byref(out))
+    fw, fh = frame if frame else (W, H)
+    st = lib.ugsm_plan_level_in_frame(C.byref(cfg), fw, fh, W, H, C.byref(out))
     if st != 0:
         raise UgsmError(st, "ugsm_plan_level")
-    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows")}
+    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "latency_policy")}
 
 
 def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):

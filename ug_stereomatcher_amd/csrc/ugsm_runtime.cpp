@@ -63,6 +63,7 @@ struct Slot {
     // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
     // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
     hipStream_t st2 = nullptr;
+    bool lat = true;  // the kernel choices of the call in flight: latency (launches short) or throughput (least work); latency_mode()
     hipEvent_t ev_in = nullptr, ev_L = nullptr, ev_R = nullptr, ev_A[UGSM_MAX_LEVELS] = {};
     float *lr = nullptr;     // LR check: the right-to-left field of level 0 (3 planes) + one 8-byte counter behind it
     size_t lr_cap = 0;
@@ -180,9 +181,10 @@ struct ugsm_ctx {
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
-    int march4_lo = 0, march4_hi = 0;  // levels of lo..hi pixels run K-cost as k_cost_march4 (use_march4; 0, 0 = none)
+    int march4_lo = -1, march4_hi = -1;  // development override of k_cost_march4's pixel range (use_march4; -1 = by the mode; 0, 0 = never)
+    int force_mode = -1;  // development override of latency_mode(): 1 latency, 0 throughput
     int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
-    int smooth_big_min = 1 << 19;  // levels of at least this many pixels run k_smooth_fused on its 112-column tile
+    int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
 };
 
@@ -410,6 +412,7 @@ struct DevKnobs {
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
+    int force_mode = -1;     // UGSM_POLICY=latency|throughput: the kernel choices of every call, whatever the slots and the frame size
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
     char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
     char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
@@ -442,6 +445,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_MARCH_MODE", k.march_mode);
     if (const char *e = getenv("UGSM_STREAM_PRIO")) snprintf(k.stream_prio, sizeof k.stream_prio, "%s", e);
     if (const char *e = getenv("UGSM_SIDE_PRIO")) k.side_prio = e[0];
+    if (const char *e = getenv("UGSM_POLICY")) k.force_mode = e[0] == 'l' ? 1 : (e[0] == 't' ? 0 : -1);
     geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
     if (const char *e = getenv("UGSM_MARCH_AGE")) {
         int a = 0, b = 0;
@@ -502,19 +506,32 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
     return UGSM_OK;
 }
 
-// K-cost / K-smooth as the marching kernels (ugsm_kernels_march.hip) or the LDS-tiled ones: a strip of a marching kernel is one wave
-// working down >= 16 rows, so a level must be large enough to fill the chip with strips.
-// Default threshold (tools/ab.py on UGSM_MARCH_MIN_PIXELS, 16 MP pairs): with several pairs in flight the chip is full whatever a
-// launch looks like and the kernel that does the least work per pixel wins -- the marching kernel (6 halo rows per strip) against the
-// tiles and their halos, down to the 63 k-pixel level: 163.2 pairs/s at a threshold of 50 000, 162.7 at 100 000, 160.4 at 200 000
-// (round 2's value), 159.1 at 400 000; below 50 000 the coarse-level latency kernels win again (161.4 with everything marching).  A
-// pair alone on the chip is a little faster with the LDS-tiled kernel at 0.25 Mpx (106.4 against 105.4 pairs/s), so a one-slot context
-// stops at 0.5 Mpx -- and runs its levels of 0.15 - 3 Mpx through k_cost_march4 anyway (use_march4).
-constexpr int kMarchDefaultMinPixels = 50000, kMarchDefaultMinPixelsOneSlot = 400000;
-bool use_march(const ugsm_config &cfg, int W, int H)
+// ---- per-level kernel choices ---------------------------------------------------------------------------------------
+// Two sets of thresholds over the same kernels ("Two policies"; every number from tools/ab.py, same box):
+//   latency     a call that has the chip to itself at least some of the time wants every launch SHORT;
+//   throughput  calls that keep the chip full whatever a launch looks like want every launch to do the LEAST WORK.
+// Which one a call gets depends on what is in flight: a one-slot context is always alone; with several slots the chip is full only if
+// the frames are large enough that a pair spends most of its time in levels that fill the chip by themselves.  Four slots: 16 MP and
+// 8 MP frames are 3.8 % / 1.8 % faster under the throughput choices, 4 MP frames 3.9 % SLOWER, the foveated stack (0.25 Mpx windows)
+// 16 % slower.  The frame is what the call matches at its finest level: W x H in full mode, the fovea window in foveated mode.
+constexpr long long kBusyFramePixels = 6000000;
+bool latency_mode(const ugsm_ctx *ctx, long long frame_px)
 {
+    if (ctx->force_mode >= 0) return ctx->force_mode == 1;
+    return ctx->cfg.slots == 1 || frame_px < kBusyFramePixels;
+}
+
+// K-cost as the marching kernel (ugsm_kernels_march.hip): a strip is one wave working down >= 6 rows.  Throughput: it does the least
+// work per pixel (6 halo rows per strip against the tiles' halos) down to the 63 k-pixel level -- four slots at 16 MP: 163.2 pairs/s at
+// a threshold of 50 000, 162.7 at 100 000, 160.4 at 200 000 (round 2's value), 159.1 at 400 000; below 50 000 the coarse-level latency
+// kernels win again (161.4 with everything marching).  Latency: from 0.4 Mpx -- but the levels of 0.15 - 3 Mpx go to k_cost_march4
+// first (use_march4), so in effect from 3 Mpx.
+constexpr int kMarchMinPixelsThroughput = 50000, kMarchMinPixelsLatency = 400000;
+bool use_march(const ugsm_ctx *ctx, int W, int H, bool lat)
+{
+    const ugsm_config &cfg = ctx->cfg;
     if (cfg.march_min_pixels < 0) return false;
-    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (cfg.slots > 1 ? kMarchDefaultMinPixels : kMarchDefaultMinPixelsOneSlot);
+    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (lat ? kMarchMinPixelsLatency : kMarchMinPixelsThroughput);
     return (long long)W * H >= thr;
 }
 
@@ -522,80 +539,74 @@ int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->
 
 // K-cost as the channel-parallel marching kernel (ugsm_kernels_march4.hip): a workgroup of four waves per strip, a third of the
 // instructions per row step on any one wave.  It wins where a launch lasts as long as one strip -- levels too small to give every SIMD
-// two or three waves of k_cost_march: 0.15 - 3 Mpx for a pair alone on the chip (tools/kbench mode 14: 10.9 against 16.4 us at
-// 0.25 Mpx, 24.3 / 29.8 at 1 Mpx, 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).  With several pairs in flight the chip is full anyway and
-// the kernels' total VALU-issue time decides: see march4_default_range.
-void march4_default_range(const ugsm_config &cfg, int &lo, int &hi)
+// two or three waves of k_cost_march: 0.15 - 3 Mpx (tools/kbench mode 14: 10.9 against 16.4 us at 0.25 Mpx, 24.3 / 29.8 at 1 Mpx,
+// 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).  Latency only: four waves per strip are more instructions in total (-1.3 % with four
+// 16 MP pairs in flight).
+constexpr int kSmallDefaultMaxPixels = 150000, kMarch4MaxPixels = 3000000;
+bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
-    const int small_thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.small_max_pixels < 0 ? 0 : 150000);
-    if (cfg.slots == 1) {
-        lo = small_thr + 1;
-        hi = 3000000;
-    } else
-        lo = hi = 0;
-}
-bool use_march4(const ugsm_ctx *ctx, int W, int H)
-{
+    const ugsm_config &cfg = ctx->cfg;
     const long long px = (long long)W * H;
-    return ctx->cfg.kernel_path != 1 && ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
+    if (cfg.kernel_path == 1) return false;
+    if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
+    const int small_thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.small_max_pixels < 0 ? 0 : kSmallDefaultMaxPixels);
+    return lat && px > small_thr && px <= kMarch4MaxPixels;
 }
 
-// The per-level kernel choices of a context that are not in ugsm_config: defaults by the number of slots -- a pair alone on the chip
-// wants every launch short, several pairs in flight want every launch to do the least work (the chip is full anyway; tools/ab.py,
-// four slots, 16 MP, same box: 160.4 pairs/s with the one-slot choices, 166.5 with these) -- then the development overrides.
+// The choices of a context that are not in ugsm_config: the development overrides (the defaults are in the functions around here).
 void set_policy(ugsm_ctx *c, const DevKnobs &k)
 {
-    const bool alone = c->cfg.slots == 1;
     c->small_mask = k.small_mask;
     c->fuse_seed = k.fuse_seed;
     c->small_rh_force = k.small_rh_force;
     c->smooth_rows = k.smooth_rows;
-    // K-smooth on the 112 x 36 tile (1.39 x the tile in halo work) instead of 64 x 32 (1.8 x) from 0.1 Mpx on: +1.7 % with four slots
-    c->smooth_big_min = k.smooth_big_min > 0 ? k.smooth_big_min : (alone ? (1 << 19) : 100000);
+    c->smooth_big_min = k.smooth_big_min > 0 ? k.smooth_big_min : 0;
     // strips by age class, every context: +8 % on a level-0 launch alone on the chip, +1.2 % on a pair alone; with four pairs in
     // flight it costs 0.4 % (163.2 against 163.7 pairs/s) -- kept on there too, so that a kernel measured alone is the kernel that ran
     c->march_mode = k.march_mode <= 0 ? k.march_mode : 0;
-    march4_default_range(c->cfg, c->march4_lo, c->march4_hi);
-    if (k.march4_hi >= 0) c->march4_lo = k.march4_lo, c->march4_hi = k.march4_hi;
+    c->march4_lo = k.march4_lo;
+    c->march4_hi = k.march4_hi;
+    c->force_mode = k.force_mode;
 }
-
 
 // K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
 // has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
 // (tools/kbench mode 7).  Returns the K-smooth region height to use (0 = not a small level).
-constexpr int kSmallDefaultMaxPixels = 150000;
-int small_rh(const ugsm_ctx *ctx, int W, int H)
+int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
     const long long thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : kSmallDefaultMaxPixels;
     const long long px = (long long)W * H;
-    if (px > thr || use_march(cfg, W, H)) return 0;
+    if (px > thr || use_march(ctx, W, H, lat)) return 0;
     if (ctx->small_rh_force) return ctx->small_rh_force;
     // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other slots' pairs share the chip -- the 18 x 4 / 18 x 10 tiles
-    // redo 8 x / 4.6 x the work, free on an idle chip, 3.5 % of the throughput with three pairs in flight (tools/sweep_small.sh).
+    // redo 8 x / 4.6 x the work, free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight (tools/ab.py).
     // A one-slot context has nothing to overlap with: the smallest tile that still gives every workgroup a CU of its own, or nearly.
     if (cfg.slots > 1) return 32;
     return px <= 36000 ? 18 : (px <= 80000 ? 24 : 32);
 }
 
-// Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is the marching
-// kernel in its default one-pixel-per-lane form: the seeded field is then never written (launch_cost_march_seeded).  Not with the early
+// Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is a marching
+// kernel: the seeded field is then never written (launch_cost_march_seeded, launch_cost_march4).  Not with the early
 // exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
-bool fuse_seed(const ugsm_ctx *ctx, int W, int H)
+bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
     const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(cfg, W, H) || use_march4(ctx, W, H));
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, lat) || use_march4(ctx, W, H, lat));
 }
 
-// Height of the 112-column tile of k_smooth_fused on a W x H level (smooth_tile_rows, ugsm_kernels_fused.hip): a pair alone on the
-// chip (one-slot context) wants whole rounds of workgroups, several pairs in flight want the least total work.
-int smooth_rows_for(const ugsm_ctx *ctx, int W, int H)
+// k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.13 Mpx, else 32 x 16), > 0 = the
+// 112-column tile at this height (smooth_tile_rows, ugsm_kernels_fused.hip).  Throughput: the 112 x 36 tile (1.39 x the tile in halo
+// work, against 1.8 x for 64 x 32) from 0.1 Mpx on, +1.7 % with four 16 MP pairs in flight.  Latency: from 0.5 Mpx, and a one-slot
+// context picks the height that fills whole rounds of workgroups.
+int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
-    if ((long long)W * H < ctx->smooth_big_min) return 0;  // (the smaller tile classes)
+    const int big_min = ctx->smooth_big_min > 0 ? ctx->smooth_big_min : (lat ? (1 << 19) : 100000);
+    if ((long long)W * H < big_min) return 0;
     if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
-    const int latency = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
-    return smooth_tile_rows(W, H, latency);
+    const int rounds_rule = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
+    return smooth_tile_rows(W, H, rounds_rule);
 }
 
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
@@ -621,15 +632,15 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             int p = std::min(left, 5);
             left -= p;
             if (p == 0 && !do_box) break;
-            const bool march = p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx->cfg, W, H);
-            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H) : 0;
+            const bool march = p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx, W, H, s.lat);
+            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H, s.lat) : 0;
             Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : (rh ? KC_SMOOTH_SMALL : KC_SMOOTH), px);
             const bool box_now = do_box && left == 0;
             float *dst = (left == 0 && final_out) ? final_out : b;
             // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
             if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, 1, ctx->cfg.march_rows);
             else if (rh) launch_smooth_small(s.st, a, dst, W, H, p, box_now, rh);
-            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H));
+            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H, s.lat));
             if (dst == final_out) a = final_out;
             else std::swap(a, b);
         } while (left > 0);
@@ -707,9 +718,9 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             Timer t(ctx, &s, si, KC_COST, px);
             launch_cost_ref(s.st, L, s.Rw, A3, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
-            const bool march4 = use_march4(ctx, W, H);
-            const bool march = use_march(ctx->cfg, W, H);
-            const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H) != 0;
+            const bool march4 = use_march4(ctx, W, H, s.lat);
+            const bool march = use_march(ctx, W, H, s.lat);
+            const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H, s.lat) != 0;
             Timer t(ctx, &s, si, march4 ? KC_COST_MARCH4 : (march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST)), px);
             if (march4)
                 launch_cost_march4(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, s.range_known ? s.range_bad : nullptr,
@@ -808,6 +819,7 @@ const float *level_A(ugsm_ctx *ctx, Slot &s, int i)
 int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out, bool swap = false)
 {
     const int levels = s.levels;
+    s.lat = latency_mode(ctx, (long long)s.W * s.H);
     const float *const pL = swap ? s.pyrR : s.pyrL, *const pR = swap ? s.pyrL : s.pyrR;
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
@@ -825,7 +837,7 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out, bool swap = false
         if (direct) return UGSM_OK;
         seeded = false;
         if (i > 0) {
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1])) {  // the next level's first K-cost launch reads `cur` through the seeding map
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat)) {  // the next level's first K-cost launch reads `cur` through the seeding map
                 sm = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
@@ -868,6 +880,7 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
 {
     const int levels = s.levels, F = ctx->cfg.fovea_levels;
     if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
+    s.lat = latency_mode(ctx, (long long)s.w[F - 1] * s.h[F - 1]);  // (the fovea window is as large as level F-1)
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
     HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
@@ -880,7 +893,7 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
                        level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr, level_A(ctx, s, i)));
         seeded = false;
         if (i > F - 1) {
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1])) {
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat)) {
                 sm = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
@@ -902,6 +915,7 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
     if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
     FoveaGeom g;
     fovea_geometry(s.w, s.h, F, off_x, off_y, g);
+    s.lat = latency_mode(ctx, (long long)g.fw * g.fh);
     const size_t fn = (size_t)g.fw * g.fh;
     float *cur = s.d0, *other = s.d1;
     HIPCHK(ctx, hipMemcpyAsync(cur, d_state, sizeof(float) * 3 * fn, hipMemcpyDeviceToDevice, s.st));
@@ -911,7 +925,7 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
         s.cur_level = i;
         // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
         const SeedMap sm{g.fw, g.fh, g.cx[i], g.cy[i]};
-        const bool seeded = fuse_seed(ctx, g.fw, g.fh);
+        const bool seeded = fuse_seed(ctx, g.fw, g.fh, s.lat);
         if (!seeded) {
             Timer t(ctx, &s, si, KC_SEED, (double)fn);
             launch_seed(s.st, cur, g.fw, g.fh, other, g.fw, g.fh, g.cx[i], g.cy[i]);
@@ -1192,9 +1206,11 @@ int ugsm_level_dims(int W, int H, int levels, int *w, int *h)
 int ugsm_level_iterations(int level) { return level < 0 ? 0 : level_iterations(level); }
 int ugsm_level_smooth_passes(int level) { return level < 0 ? 0 : level_smooth(level); }
 
-int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *out)
+int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *out) { return ugsm_plan_level_in_frame(cfg_in, W, H, W, H, out); }
+
+int ugsm_plan_level_in_frame(const ugsm_config *cfg_in, int frame_w, int frame_h, int W, int H, ugsm_level_plan *out)
 {
-    if (!out || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    if (!out || W < 1 || H < 1 || frame_w < 1 || frame_h < 1) return UGSM_ERR_BAD_ARG;
     ugsm_ctx probe;  // host-only: the same policy functions the launch path calls, on a context that owns no device state
     if (cfg_in) probe.cfg = *cfg_in;
     else ugsm_default_config(&probe.cfg);
@@ -1208,15 +1224,17 @@ int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *ou
         out->cost_kernel = out->smooth_kernel = 3;
         return UGSM_OK;
     }
-    const bool march = use_march(probe.cfg, W, H);
-    const int rh = small_rh(&probe, W, H);
-    const bool march4 = use_march4(&probe, W, H);
+    const bool lat = latency_mode(&probe, (long long)frame_w * frame_h);
+    out->latency_policy = lat ? 1 : 0;
+    const bool march = use_march(&probe, W, H, lat);
+    const int rh = small_rh(&probe, W, H, lat);
+    const bool march4 = use_march4(&probe, W, H, lat);
     out->cost_kernel = march4 ? 4 : (march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0));
     out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
     out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1, probe.march_mode <= -2)) : 0);
-    out->seed_fused = fuse_seed(&probe, W, H) ? 1 : 0;
-    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H) : 0;
+    out->seed_fused = fuse_seed(&probe, W, H, lat) ? 1 : 0;
+    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H, lat) : 0;
     return UGSM_OK;
 }
 int ugsm_threshold_schedule(int mi, float *out)
@@ -1433,6 +1451,7 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
         launch_range_scan(s->st, d_L3, 3 * n, s->range_bad);
         launch_range_scan(s->st, d_R3, 3 * n, s->range_bad);
     }
+    s->lat = latency_mode(ctx, (long long)W * H);
     UCHK(run_level(ctx, *s, 0, Img3{d_L3, W, n}, Img3{d_R3, W, n}, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
     HIPCHK(ctx, hipMemcpyAsync(d_d3, cur, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     return ugsm_wait(ctx, 0);
@@ -1462,6 +1481,7 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
     UCHK(ensure_level_bufs(ctx, *s, lvl));
     float *a = s->d0, *b = s->d1;
     HIPCHK(ctx, hipMemcpyAsync(a, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    s->lat = latency_mode(ctx, (long long)W * H);
     UCHK(enqueue_smooth(ctx, *s, 0, a, b, W, H, passes, do_box != 0));
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(d_d3, a, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
