@@ -18,8 +18,8 @@ python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_f
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
-# (UGSM_MARCH_MIN_PIXELS: a one-slot context would otherwise stop the marching kernel one level earlier than the 4-slot bench line does)
-pmc() { name=$1; shift; UGSM_MARCH_MIN_PIXELS=200000 timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
+# (UGSM_POLICY: a one-slot context would otherwise make the latency choices, not the ones of the 4-slot bench line)
+pmc() { name=$1; shift; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 pmc pmc_write WRITE_SIZE
 pmc pmc_fetch FETCH_SIZE
@@ -34,6 +34,9 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 { for sz in "2464 1632" "1742 1154" "1232 816" "871 577"; do timeout -k 10 100 ./tools/kbench $sz 50 10; done; } > $O/kbench_strips.txt 2>&1; step "kbench (strip heights of the marching K-cost)"
 { for sz in "4928 3264 10" "3484 2307 10" "2463 1631 20"; do timeout -k 10 100 ./tools/kbench $sz 12 | grep -v "bit-exact" ; done; } > $O/kbench_age_16mp.txt 2>&1; step "kbench (strips by age class)"
 { for sz in "54 36" "154 102" "436 289"; do timeout -k 10 60 ./tools/kbench $sz 20 13; done; } > $O/kbench_graph.txt 2>&1; step "kbench (eager launches against a HIP graph, coarse level)"
+{ for sz in "436 289" "615 407" "870 576" "1231 815" "1741 1153" "2463 1631"; do echo "== $sz"; timeout -k 10 60 ./tools/kbench $sz 100 14 | grep -v "rows=[1-9]"; done; } > $O/kbench_march4.txt 2>&1; step "kbench (k_cost_march4 against k_cost_march / split / small)"
+{ for sz in "3 1" "4 1" "8 1" "4 0" "4 1 hhhh" "8 1 hhhhllll"; do timeout -k 5 60 ./tools/queue_probe $sz; done; } > $O/queue_probe.txt 2>&1; step "queue probe"
+{ timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "default:" "latency choices:UGSM_POLICY=latency" "default-priority streams:UGSM_STREAM_PRIO=nnnn" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 160 --rounds 2 "default:" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; } > $O/ab_policies.txt 2>&1; step "same-box A/B of the policies"
 timeout -k 10 100 ./tools/kbench_stamp 4928 3264 10 6 > $O/census_16mp.txt 2>&1; step "wave census of the marching K-cost"
 timeout -k 10 100 python tools/level_breakdown.py > $O/level_breakdown.txt 2>&1; step "per-level breakdown of one pair"
 timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"

@@ -89,8 +89,9 @@ def classify(op, text):
     return "slow32"  # compares, selects, min/max/med3, floor, conversions, div_fmas/div_fixup, readlane ...
 
 
-def loops_of(asm_path, name_re):
-    """{kernel symbol: {loop header label: [instruction text]}} for innermost loops.  Basic blocks that hold a binary64
+def loops_of(asm_path, name_re, all_loops=False):
+    """{kernel symbol: {loop header label: [instruction text]}} for innermost loops (all_loops: loops of any depth, each block counted
+    under the innermost loop that holds it -- for kernels whose hot loop contains small rarely-taken loops).  Basic blocks that hold a binary64
     division (v_rcp_f64: the literal fallbacks of PolyDisparity's quotients, entered only by the lanes that need them and
     skipped by s_cbranch_execz otherwise) are left out: they are not on the hot path."""
     out = {}
@@ -124,7 +125,7 @@ def loops_of(asm_path, name_re):
             flush()
             block = []
             lab, com = m.group(1), m.group(2)
-            if "Inner Loop Header" in com:
+            if "Inner Loop Header" in com or (all_loops and "Loop Header" in com):
                 header = lab
                 out[cur].setdefault(header, [])
             else:
@@ -181,13 +182,14 @@ def main():
     for k, v in sorted(costs.items()):
         md.append(f"| {k} | {v:.2f} | {what.get(k, '')} |")
     jobs = [("ugsm_kernels_march.hip", r"k_cost_marchILi1ELb0", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
-            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi37ELi512ELi0E", "k_smooth_fused", None),
-            ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None)]
+            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi39ELi512ELi0E", "k_smooth_fused", None),
+            ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None),
+            ("ugsm_kernels_march4.hip", r"k_cost_march4", "k_cost_march4", None)]
     for src, name_re, short, geom in jobs:
         asm = os.path.join(tmp, src.replace(".hip", ".s"))
         if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(CSRC, src)):
             subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(CSRC, src), "-o", asm], stderr=subprocess.DEVNULL)
-        lp = loops_of(asm, name_re)
+        lp = loops_of(asm, name_re, all_loops=geom is None)
         for sym, loops in lp.items():
             if not loops:
                 continue
