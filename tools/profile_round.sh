@@ -39,6 +39,7 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 { timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "default:" "latency choices:UGSM_POLICY=latency" "default-priority streams:UGSM_STREAM_PRIO=nnnn" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 160 --rounds 2 "default:" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; } > $O/ab_policies.txt 2>&1; step "same-box A/B of the policies"
 timeout -k 10 100 ./tools/kbench_stamp 4928 3264 10 6 > $O/census_16mp.txt 2>&1; step "wave census of the marching K-cost"
 timeout -k 10 100 python tools/level_breakdown.py > $O/level_breakdown.txt 2>&1; step "per-level breakdown of one pair"
-timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"
+# (7 minutes; the instruction costs do not change with the kernels: only with VALUBENCH=1)
+if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"; fi
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
 ls $O

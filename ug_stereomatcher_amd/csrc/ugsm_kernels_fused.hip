@@ -1246,15 +1246,15 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty);
 }
 
-// Tile height of the 112-column K-smooth tile for a W x H level.  The kernel's tile may be any height up to kSmoothTileRowsMax; two
+// Tile height of the 112-column K-smooth tile for a W x H level.  The kernel's tile may be any height up to kSmoothTileRowsMax (36); two
 // workgroups are resident per CU, 512 in all.
-//  * Several pairs in flight (`latency` = 0), or a level of many rounds of workgroups (> 3): 36 rows, as always.  (Taller tiles do
-//    less halo work, and on random fields tools/kbench mode 15 has 39 rows 6 % faster at 16 MP; on real pairs in the pipeline the
-//    level-0 launch is 212 us at 39 rows against 208 at 36, and tools/ab.py has four slots at -0.2 %.)
+//  * Several pairs in flight (`latency` = 0), or a level of many rounds of workgroups (> 3): 36 rows, as always.
 //  * A level of a few rounds with the chip to itself: a launch lasts (whole rounds) x (region rows), so a level whose tiles at full
 //    height need a few workgroups more than a whole number of rounds pays a round for them (1742 x 1154: 16 x 33 tiles of 36 rows
-//    = 1.03 rounds, 51 us in the pipeline; 16 x 32 tiles of 37 rows = one round, 42 us).  The height that minimises
-//    rounds x region rows; among equals the fewest tiles.  Worth 0.3 % of a 16 MP pair alone on the chip (tools/ab.py).
+//    = 1.03 rounds, 51 us in the pipeline; 16 x 58 tiles of 20 rows = two rounds of shorter tiles, 48 us; with a 39-row kernel 16 x 32
+//    tiles of 37 rows = one round, 42 us -- but that kernel's unrolled loops cost every 36-row launch 7.7 % more instructions:
+//    212 against 208 us at level 0, so the tallest tile stays 36).  The height that minimises rounds x region rows; among equals the
+//    fewest tiles.  Worth 0.3 % of a 16 MP pair alone on the chip (tools/ab.py).
 int smooth_tile_rows(int W, int H, int latency)
 {
     constexpr int STX = 112, HMAX = kSmoothTileRowsMax, HDEF = 36, HMIN = 16, SLOTS = 2 * 256;
@@ -1279,7 +1279,7 @@ int smooth_tile_rows(int W, int H, int latency)
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows)
 {
-    // big levels: 112 x (up to 39) tiles, 512 threads, <= 81 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
+    // big levels: 112 x (up to 36) tiles, 512 threads, <= 77 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
     // the other's passes; measured, the two phases still nearly add up: DESIGN.md section 4).  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
     // columns every pass recomputes are 12.5 % of the row instead of 20 % (at 16 MP: 5 passes 227 us against 266 us for
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);

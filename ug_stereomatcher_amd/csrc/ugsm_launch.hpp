@@ -70,7 +70,8 @@ void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int 
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
 // tile_rows: > 0 = the 112-column tile at this height (1..kSmoothTileRowsMax; smooth_tile_rows picks it); 0 = the tile class by the
 // level's size (112 x 36 from 0.5 Mpx, 64 x 32 from 0.13 Mpx, else 32 x 16).
-constexpr int kSmoothTileRowsMax = 39;  // 3 x 53 x 128 floats = 81 408 B of LDS: two workgroups still fit a CU's 160 KB
+constexpr int kSmoothTileRowsMax = 36;  // (39 rows still fit two workgroups per CU -- 3 x 53 x 128 floats = 81 408 B of LDS -- but the kernel's
+                                        // unrolled load / box loops, sized for the tallest tile, then cost every 36-row launch 7.7 % more instructions)
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows = 0);
 int smooth_tile_rows(int W, int H, int latency);
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
