@@ -470,12 +470,12 @@ int main(int argc, char **argv)
             timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn, sty); });
         };
         for (int round = 0; round < 2; round++) {
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5+box");
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
-            run((k_smooth_fused<112, 36, 512, 2>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
-            run((k_smooth_fused<112, 36, 512, 0>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5+box");
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 2, true>), 112, 36, 512, "smooth<112,36,512> selects p5+box");
+            run((k_smooth_fused<112, 36, 512, 2, true>), 112, 36, 512, "smooth<112,36,512> selects p5", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });

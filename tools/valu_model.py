@@ -182,7 +182,7 @@ def main():
     for k, v in sorted(costs.items()):
         md.append(f"| {k} | {v:.2f} | {what.get(k, '')} |")
     jobs = [("ugsm_kernels_march.hip", r"k_cost_marchILi1ELb0", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
-            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0E", "k_smooth_fused", None),
+            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0ELb1E", "k_smooth_fused", None),
             ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None),
             ("ugsm_kernels_march4.hip", r"k_cost_march4", "k_cost_march4", None)]
     for src, name_re, short, geom in jobs:
