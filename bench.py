@@ -435,11 +435,34 @@ def main():
             pl[...] = L
             pr[...] = R
             t_pin = call(pl, pr, po)
+            # several pairs in flight from page-locked host memory ("end-to-end from pinned host memory"): every slot has its own
+            # pinned image pair and result planes; uploads, match and downloads of a pair are enqueued on the slot's stream
+            hb = [(pl, pr, po)] + [(ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W)))
+                                   for _ in range(slots - 1)]
+            for (a_, b_, _) in hb[1:]:
+                a_[...] = L
+                b_[...] = R
+
+            def piped(n):
+                t0 = time.perf_counter()
+                for k in range(n):
+                    sl = k % slots
+                    ctx.check(ctx.lib.ugsm_wait(ctx.handle, sl))
+                    a_, b_, o_ = hb[sl]
+                    ctx.check(ctx.lib.ugsm_submit_full_host(ctx.handle, sl, a_.ctypes.data, b_.ctypes.data, W, H, stride, o_[0].ctypes.data,
+                                                            o_[1].ctypes.data, o_[2].ctypes.data))
+                ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
+                return (time.perf_counter() - t0) / n
+            piped(2 * slots)
+            t_piped = min(piped(12 * slots) for _ in range(2))
             result["pcie_inclusive"] = {"pageable_ms_per_pair": 1e3 * t_page, "pageable_pairs_per_s": 1.0 / t_page,
                                         "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
+                                        "pinned_in_flight_pairs_per_s": 1.0 / t_piped, "pinned_in_flight_slots": slots,
+                                        "pinned_in_flight_GBps_over_pcie": (2 * H * stride + 12 * W * H) / t_piped / 1e9,
                                         "note": "ugsm_match_full, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
                                                 "(193 MB); median of 3 calls; pageable = fresh result planes for every call, as the reference "
-                                                "node allocates them (UG_GPU_matcher.cpp:414-418); the caller's free() is not in the call"}
+                                                "node allocates them (UG_GPU_matcher.cpp:414-418); the caller's free() is not in the call; "
+                                                "pinned_in_flight = ugsm_submit_full_host on every slot in turn, page-locked images and planes"}
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -157,6 +157,12 @@ int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8
 int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR,
                          int W, int H, int stride, int off_x, int off_y, float *d_stack,
                          float *d_pyrL, float *d_pyrR);
+/* ugsm_match_full without the wait, on any slot: for a host that keeps several pairs in flight from PAGE-LOCKED memory (SURVEY 8d:
+ * "end-to-end from pinned host memory").  Every buffer -- both images and the three result planes -- must be page-locked
+ * (ugsm_host_alloc, hipHostMalloc or hipHostRegister), else UGSM_ERR_BAD_ARG; the uploads, the match and the three downloads are
+ * enqueued on the slot's stream and the call returns; ugsm_wait(slot) before the planes are read or the slot is used again. */
+int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
+                          int stride, float *dispH, float *dispV, float *dispC);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
 int ugsm_wait_all(ugsm_ctx *ctx);
 /* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the

@@ -157,3 +157,36 @@ def test_smooth_tile_heights(lib, orc, monkeypatch, rows):
                 got = c.to_host(p, d.shape)
                 c.free(p)
             assert_bit_equal(got, exp, f"{W}x{H} rows={rows} passes={passes} box={box}")
+
+
+def test_submit_full_host_keeps_several_pairs_in_flight_from_pinned_memory(lib, orc):
+    """ugsm_submit_full_host: the service call without the wait, on any slot, from page-locked buffers (SURVEY 8d "end-to-end from
+    pinned host memory"); pageable buffers are refused."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv = 360, 250, 9
+    pairs = [synth.make_pair(W, H, synth.BASE_SEED + 360 + j)[:2] for j in range(3)]
+    refs = [orc.match_full(L, R, lv) for (L, R) in pairs]
+    with lib.Context(levels=lv, slots=3) as c:
+        hin = [(c.host_array((H, W, 3), np.uint8), c.host_array((H, W, 3), np.uint8)) for _ in range(3)]
+        hout = [c.host_array((3, H, W)) for _ in range(3)]
+        for rep in range(2):                       # the second round reuses every slot and every buffer
+            for j in range(3):
+                k = (j + rep) % 3
+                hin[j][0][:] = pairs[k][0]
+                hin[j][1][:] = pairs[k][1]
+                hout[j][:] = np.nan
+                c.check(c.lib.ugsm_submit_full_host(c.handle, j, hin[j][0].ctypes.data, hin[j][1].ctypes.data, W, H, 3 * W,
+                                                    hout[j][0].ctypes.data, hout[j][1].ctypes.data, hout[j][2].ctypes.data))
+            for j in range(3):
+                c.check(c.lib.ugsm_wait(c.handle, j))
+                assert_bit_equal(hout[j], refs[(j + rep) % 3], f"round {rep} slot {j}")
+        pageable = np.empty((3, H, W), np.float32)
+        st = c.lib.ugsm_submit_full_host(c.handle, 0, hin[0][0].ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, pageable[0].ctypes.data,
+                                         pageable[1].ctypes.data, pageable[2].ctypes.data)
+        assert st == lib.UGSM_ERR_BAD_ARG
+        L = np.ascontiguousarray(pairs[0][0])
+        st = c.lib.ugsm_submit_full_host(c.handle, 0, L.ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, hout[0][0].ctypes.data,
+                                         hout[0][1].ctypes.data, hout[0][2].ctypes.data)
+        assert st == lib.UGSM_ERR_BAD_ARG
+        assert c.lib.ugsm_submit_full_host(c.handle, 5, hin[0][0].ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, hout[0][0].ctypes.data,
+                                           hout[0][1].ctypes.data, hout[0][2].ctypes.data) == lib.UGSM_ERR_BAD_ARG

@@ -1336,22 +1336,40 @@ int ugsm_wait_all(ugsm_ctx *ctx)
     return UGSM_OK;
 }
 
-int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
-                    float *dispV, float *dispC)
+// The service call on a slot: upload, pyramids, match, results into caller memory.  `sync` = the reference's call (returns when the
+// planes are in place; pageable or page-locked memory); otherwise everything is only enqueued and every buffer must be page-locked.
+static int match_full_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
+                              float *dispV, float *dispC, bool sync)
 {
     Slot *s;
-    UCHK(get_slot(ctx, 0, &s));
+    UCHK(get_slot(ctx, slot, &s));
     if (!dispH || !dispV || !dispC) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (!sync && !(is_pinned(rgbL) && is_pinned(rgbR) && is_pinned(dispH) && is_pinned(dispV) && is_pinned(dispC))) {
+        ctx->err = "ugsm_submit_full_host: every host buffer must be page-locked (ugsm_host_alloc, hipHostMalloc or hipHostRegister)";
+        return UGSM_ERR_BAD_ARG;
+    }
     UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
     const size_t n = (size_t)W * H;
     UCHK(grow(ctx, s->hout, s->hout_cap, 3 * n));
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, 0));
-    UCHK(enqueue_full_lr(ctx, *s, 0, s->hout));
+    UCHK(enqueue_pyramids(ctx, *s, slot, s->rgbL, s->rgbR, W, H, stride, 0));
+    UCHK(enqueue_full_lr(ctx, *s, slot, s->hout));
     float *const dst[3] = {dispH, dispV, dispC};
-    prefault_planes(ctx, dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
+    if (sync) prefault_planes(ctx, dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
     UCHK(copy_out_planes(ctx, *s, s->hout, n, dst));
-    return ugsm_wait(ctx, 0);
+    return sync ? ugsm_wait(ctx, slot) : UGSM_OK;
+}
+
+int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
+                    float *dispV, float *dispC)
+{
+    return match_full_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, dispH, dispV, dispC, true);
+}
+
+int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
+                          float *dispV, float *dispC)
+{
+    return match_full_on_slot(ctx, slot, rgbL, rgbR, W, H, stride, dispH, dispV, dispC, false);
 }
 
 int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
