@@ -420,14 +420,16 @@ def main():
         del a, b
         if mode == "full":
             L, R = host_pair
+            # one call at a time = the reference node's pattern: on a ONE-SLOT context, as that node would create it
+            ctx_s = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=1, kernel_path=args.kernel_path, profile_events=0)
 
             def call(Lh, Rh, oh):
                 ts = []
                 for _ in range(4):
                     o = oh if oh is not None else np.empty((3, H, W), np.float32)  # fresh, untouched result planes per call
                     t0 = time.perf_counter()
-                    ctx.check(ctx.lib.ugsm_match_full(ctx.handle, Lh.ctypes.data, Rh.ctypes.data, W, H, stride,
-                                                      o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
+                    ctx_s.check(ctx_s.lib.ugsm_match_full(ctx_s.handle, Lh.ctypes.data, Rh.ctypes.data, W, H, stride,
+                                                          o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
                     ts.append(time.perf_counter() - t0)
                 return sorted(ts[1:])[1]  # median of the last three
             t_page = call(L, R, None)
@@ -435,6 +437,7 @@ def main():
             pl[...] = L
             pr[...] = R
             t_pin = call(pl, pr, po)
+            ctx_s.close()
             # several pairs in flight from page-locked host memory ("end-to-end from pinned host memory"): every slot has its own
             # pinned image pair and result planes; uploads, match and downloads of a pair are enqueued on the slot's stream
             hb = [(pl, pr, po)] + [(ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W)))
@@ -459,7 +462,7 @@ def main():
                                         "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
                                         "pinned_in_flight_pairs_per_s": 1.0 / t_piped, "pinned_in_flight_slots": slots,
                                         "pinned_in_flight_GBps_over_pcie": (2 * H * stride + 12 * W * H) / t_piped / 1e9,
-                                        "note": "ugsm_match_full, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
+                                        "note": "ugsm_match_full on a one-slot context, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
                                                 "(193 MB); median of 3 calls; pageable = fresh result planes for every call, as the reference "
                                                 "node allocates them (UG_GPU_matcher.cpp:414-418); the caller's free() is not in the call; "
                                                 "pinned_in_flight = ugsm_submit_full_host on every slot in turn, page-locked images and planes"}
