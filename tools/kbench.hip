@@ -302,6 +302,36 @@ int main(int argc, char **argv)
         CK(hipGetLastError());
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 16) {  // k_iter_small (smoothing of iteration m + cost step of iteration m+1, one launch) against k_smooth_small + k_cost_small: kbench W H reps 16
+        float *o2, *f1; CK(hipMalloc(&o2, 12 * n)); CK(hipMalloc(&f1, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        for (int P : {5, 3, 1})
+            for (int blend = 0; blend < 2; blend++) {
+                CK(hipMemset(o, 0xff, 12 * n)); CK(hipMemset(o2, 0xee, 12 * n));
+                launch_smooth_small(st, d, f1, W, H, P, 1, 32);
+                launch_cost_small(st, iL, iR, A, f1, o, W, H, 0.55f, blend);
+                launch_iter_small(st, iL, iR, A, d, o2, W, H, 0.55f, blend, P);
+                CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+                size_t bad = 0, first = 0;
+                for (size_t i = 0; i < 3 * n; i++)
+                    if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) { if (!bad) first = i; bad++; }
+                printf("k_iter_small vs k_smooth_small + k_cost_small P=%d blend=%d: %zu of %zu values differ%s\n", P, blend, bad, 3 * n, bad ? "" : " (bit-exact)");
+                if (bad) printf("  first at plane %zu y %zu x %zu: %g vs %g\n", first / n, (first % n) / W, first % W, ha[first], hb[first]);
+            }
+        for (int round = 0; round < 2; round++) {
+            for (int rh : {18, 24, 32}) {
+                char nm[96]; snprintf(nm, sizeof nm, "smooth_small rh=%d + cost_small", rh);
+                timeit(nm, [&]() { launch_smooth_small(st, d, f1, W, H, 5, 1, rh); launch_cost_small(st, iL, iR, A, f1, o, W, H, 0.55f, 1); });
+            }
+            timeit("k_iter_small", [&]() { launch_iter_small(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 5); });
+            for (int P = 0; P <= 4; P++) { char nm[64]; snprintf(nm, sizeof nm, "k_iter_small P=%d", P); timeit(nm, [&]() { launch_iter_small(st, iL, iR, A, d, o2, W, H, 0.55f, 1, P); }); }
+            timeit("k_cost_small", [&]() { launch_cost_small(st, iL, iR, A, d, o, W, H, 0.55f, 1); });
+            timeit("k_smooth_small rh=18", [&]() { launch_smooth_small(st, d, f1, W, H, 5, 1, 18); });
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 7) {  // latency kernels of the coarse levels against the LDS-tiled ones: kbench W H reps 7
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);

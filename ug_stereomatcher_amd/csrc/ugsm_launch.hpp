@@ -48,6 +48,8 @@ void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 // The same iteration for the coarse levels (ugsm_kernels_small.hip): the three channels of a 16 x 12 tile side by side, built for the
 // latency of one tile rather than for throughput.
 void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend);
+// the smoothing (passes <= 5, + box) of the previous cost step's output c3, then the next cost step on it, one launch (coarse levels)
+void launch_iter_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *c3, float *nd3, int W, int H, float thr, int blend, int passes);
 // `passes` (<= 5) Jacobi passes (+ box) for the coarse levels: one thread per pixel of an 18 x (rh - 14) tile + halo 7 (rh = 18, 24 or 32)
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh);
 // strips by age class (ugsm_kernels_march.hip): share (per mille) of a strip group's rows for the first / second wave of a SIMD; {0, 0} = uniform

@@ -32,11 +32,11 @@ namespace {
 
 constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
-enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COST_MARCH4, KC_COUNT };
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COST_MARCH4, KC_ITER_SMALL, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
     {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_smooth_march",
-     "k_pyr_base", "k_cost_small", "k_smooth_small", "k_cost_march4"},
-    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-", "-"}};
+     "k_pyr_base", "k_cost_small", "k_smooth_small", "k_cost_march4", "k_iter_small"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-", "-", "-"}};
 constexpr int kNoLevel = UGSM_MAX_LEVELS;  // stats cell of launches that belong to no pyramid level
 struct StatCell {
     long long launches = 0;
@@ -183,6 +183,7 @@ struct ugsm_ctx {
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
     int march4_lo = -1, march4_hi = -1;  // development override of k_cost_march4's pixel range (use_march4; -1 = by the mode; 0, 0 = never)
     int force_mode = -1;  // development override of latency_mode(): 1 latency, 0 throughput
+    int iter_small = 0;   // coarse levels: smoothing of iteration m + cost step of iteration m+1 in one launch (k_iter_small)
     int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
     int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
@@ -412,6 +413,7 @@ struct DevKnobs {
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
+    int iter_small = -1;     // UGSM_ITER_SMALL=0 / 1: k_iter_small on the coarse levels (default: off -- measured equal)
     int force_mode = -1;     // UGSM_POLICY=latency|throughput: the kernel choices of every call, whatever the slots and the frame size
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
     char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
@@ -447,6 +449,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     if (const char *e = getenv("UGSM_SIDE_PRIO")) k.side_prio = e[0];
     if (const char *e = getenv("UGSM_POLICY")) k.force_mode = e[0] == 'l' ? 1 : (e[0] == 't' ? 0 : -1);
     geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
+    geti("UGSM_ITER_SMALL", k.iter_small);
     if (const char *e = getenv("UGSM_MARCH_AGE")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
@@ -567,6 +570,7 @@ void set_policy(ugsm_ctx *c, const DevKnobs &k)
     c->march4_lo = k.march4_lo;
     c->march4_hi = k.march4_hi;
     c->force_mode = k.force_mode;
+    c->iter_small = k.iter_small > 0 ? 1 : 0;
 }
 
 // K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
@@ -704,9 +708,15 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
         if (ref) launch_sqblur_clamp_ref(s.st, L, W, H, s.A);
         else launch_sqblur_clamp(s.st, L, W, H, s.A);
     }
+    // coarse levels, optional: the smoothing of iteration m and the cost step of iteration m + 1 in one launch (k_iter_small); the level is
+    // then  cost, (mi - 1) x [smooth + cost], smooth.  `other` carries the cost step's output from one launch to the next.
+    const bool fuse_iter = ctx->iter_small && !ref && !early && S == 5 && (ctx->small_mask & 3) == 3 && small_rh(ctx, W, H, s.lat) != 0 &&
+                           !use_march4(ctx, W, H, s.lat);
     for (int m = m_from; m <= m_to; m++) {
         const int blend = !(is_top && m == 1);  // MatchGPULib.cpp:2223
-        if (ref) {
+        if (fuse_iter && m > m_from) {
+            // (this iteration's cost step ran in the previous launch)
+        } else if (ref) {
             {
                 Timer t(ctx, &s, si, KC_WARP, px);
                 launch_warp_ref(s.st, R, cur, W, H, s.Rw);
@@ -742,6 +752,12 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
             other = b;
             third = old;
             if (m < m_to && dif[0] < eps && dif[1] < eps) break;  // differenceIterations: both below the threshold
+            continue;
+        }
+        if (fuse_iter && m < m_to) {
+            Timer t(ctx, &s, si, KC_ITER_SMALL, px);
+            launch_iter_small(s.st, L, R, A3, other, cur, W, H, thr[m], 1, S);  // iteration m + 1 >= 2 always blends (MatchGPULib.cpp:2223)
+            std::swap(cur, other);
             continue;
         }
         float *a = other, *b = cur;
