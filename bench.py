@@ -178,8 +178,9 @@ def spawn_ranks(args) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96, help="pairs of the timed region (a short region under-reports: filling and draining the slots is a larger share of it)")
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=384, help="pairs of the timed region (a short region under-reports: filling and draining the four slots costs about "
+                    "one pair's in-flight time, 24 ms at 16 MP -- 4 %% of 96 steps, 1 %% of 384; 4000 steps: 171 pairs/s where 96 give 167)")
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="full16mp", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU (HIP streams)")
     ap.add_argument("--kernel-path", type=int, default=0)
