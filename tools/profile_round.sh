@@ -16,8 +16,9 @@ python bench.py --slots 1 --no-cpu-baseline --no-service > $O/bench_slots1.json 
 python bench.py --workload 1080p --no-cpu-baseline --no-service > $O/bench_1080p.json 2>> $O/bench_default.err; step "bench 1080p"
 python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp"
 cd /tmp && export TMPDIR=/tmp
-# the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
+# the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours; 96 steps instead of
+# 384: the kernel trace of the longer region does not fit gpurun's 64 MiB of returned files)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
 # (UGSM_POLICY: a one-slot context would otherwise make the latency choices, not the ones of the 4-slot bench line)
 pmc() { name=$1; shift; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
