@@ -190,3 +190,19 @@ def test_submit_full_host_keeps_several_pairs_in_flight_from_pinned_memory(lib, 
         assert st == lib.UGSM_ERR_BAD_ARG
         assert c.lib.ugsm_submit_full_host(c.handle, 5, hin[0][0].ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, hout[0][0].ctypes.data,
                                            hout[0][1].ctypes.data, hout[0][2].ctypes.data) == lib.UGSM_ERR_BAD_ARG
+
+
+def test_pageable_result_planes_in_pieces_equal_page_locked_ones(lib):
+    """ugsm_match_full into pageable planes of more than 16 MB goes out in four pieces per plane (a piece's copy into the caller's pages
+    runs under the next piece's transfer); same bits as into page-locked planes, at a size whose plane is not a multiple of the piece."""
+    from ug_stereomatcher_amd import synth
+    W, H = 2300, 1900
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 380)
+    with lib.Context(levels=12) as c:
+        a = np.full((3, H, W), np.nan, np.float32)
+        b = c.host_array((3, H, W))
+        b[:] = np.nan
+        for o in (a, b):
+            c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
+        assert np.isfinite(a).all()
+        assert_bit_equal(a, b, "pageable in pieces vs page-locked")
