@@ -163,6 +163,10 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
  * enqueued on the slot's stream and the call returns; ugsm_wait(slot) before the planes are read or the slot is used again. */
 int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
                           int stride, float *dispH, float *dispV, float *dispC);
+/* The same for ugsm_match_foveated (pyrL / pyrR may be NULL; page-locked if given). */
+int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
+                              int stride, int off_x, int off_y, float *stackH, float *stackV,
+                              float *stackC, float *pyrL, float *pyrR);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
 int ugsm_wait_all(ugsm_ctx *ctx);
 /* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the

@@ -206,3 +206,28 @@ def test_pageable_result_planes_in_pieces_equal_page_locked_ones(lib):
             c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, o[0].ctypes.data, o[1].ctypes.data, o[2].ctypes.data))
         assert np.isfinite(a).all()
         assert_bit_equal(a, b, "pageable in pieces vs page-locked")
+
+
+def test_submit_foveated_host_from_pinned_memory(lib, orc):
+    """ugsm_submit_foveated_host: ugsm_match_foveated without the wait, on two slots, page-locked buffers; pageable ones are refused."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv, F = 420, 300, 10, 5
+    pairs = [synth.make_pair(W, H, synth.BASE_SEED + 390 + j)[:2] for j in range(2)]
+    fw, fh = lib.fovea_dims(W, H, lv, F)
+    with lib.Context(levels=lv, fovea_levels=F, slots=2) as c:
+        hin = [(c.host_array((H, W, 3), np.uint8), c.host_array((H, W, 3), np.uint8)) for _ in range(2)]
+        st = [c.host_array((3, F, fh, fw)) for _ in range(2)]
+        pyr = [c.host_array((2, F, 3, fh, fw)) for _ in range(2)]
+        for j in range(2):
+            hin[j][0][:], hin[j][1][:] = pairs[j]
+            c.check(c.lib.ugsm_submit_foveated_host(c.handle, j, hin[j][0].ctypes.data, hin[j][1].ctypes.data, W, H, 3 * W, 0, 0, st[j][0].ctypes.data,
+                                                    st[j][1].ctypes.data, st[j][2].ctypes.data, pyr[j][0].ctypes.data, pyr[j][1].ctypes.data))
+        for j in range(2):
+            c.check(c.lib.ugsm_wait(c.handle, j))
+            exp, pl, pr = orc.match_foveated(pairs[j][0], pairs[j][1], lv, F, want_pyr=True)
+            assert_bit_equal(st[j], exp, f"stack, slot {j}")
+            assert_bit_equal(pyr[j][0], pl, f"left pyramid stack, slot {j}")
+            assert_bit_equal(pyr[j][1], pr, f"right pyramid stack, slot {j}")
+        bad = np.empty((F, fh, fw), np.float32)
+        assert c.lib.ugsm_submit_foveated_host(c.handle, 0, hin[0][0].ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, 0, 0, bad.ctypes.data,
+                                               st[0][1].ctypes.data, st[0][2].ctypes.data, None, None) == lib.UGSM_ERR_BAD_ARG

@@ -27,7 +27,7 @@ UGSM_MAX_LEVELS = 32
 EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
-    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full", "ugsm_submit_full_host",
+    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full", "ugsm_submit_full_host", "ugsm_submit_foveated_host",
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
@@ -93,6 +93,7 @@ def load():
     lib.ugsm_plan_level_in_frame.argtypes = [C.POINTER(Config), i, i, i, i, C.POINTER(LevelPlan)]
     lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_submit_full_host.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp]
+    lib.ugsm_submit_foveated_host.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
     lib.ugsm_match_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
     lib.ugsm_match_foveated_full.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp]
     lib.ugsm_submit_full.argtypes = [vp, i, vp, vp, i, i, i, vp]

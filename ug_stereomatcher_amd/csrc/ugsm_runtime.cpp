@@ -1403,15 +1403,24 @@ int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const ui
     return match_full_on_slot(ctx, slot, rgbL, rgbR, W, H, stride, dispH, dispV, dispC, false);
 }
 
-int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
-                        int off_y, float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR)
+static int match_foveated_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                                  float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR, bool sync)
 {
     Slot *s;
-    UCHK(get_slot(ctx, 0, &s));
+    UCHK(get_slot(ctx, slot, &s));
     if (!stackH || !stackV || !stackC) return UGSM_ERR_BAD_ARG;
     const int F = ctx->cfg.fovea_levels;
     if (F < 2) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (!sync) {
+        bool pinned = is_pinned(rgbL) && is_pinned(rgbR) && is_pinned(stackH) && is_pinned(stackV) && is_pinned(stackC);
+        if (pyrL) pinned = pinned && is_pinned(pyrL);
+        if (pyrR) pinned = pinned && is_pinned(pyrR);
+        if (!pinned) {
+            ctx->err = "ugsm_submit_foveated_host: every host buffer must be page-locked (ugsm_host_alloc, hipHostMalloc or hipHostRegister)";
+            return UGSM_ERR_BAD_ARG;
+        }
+    }
     int fw, fh;
     UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
     UCHK(stage_in(ctx, *s, rgbL, rgbR, W, H, stride));
@@ -1422,15 +1431,27 @@ int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR,
     float *d_state = s->hout, *d_stack = d_state + 3 * fn;
     float *d_pl = pyrL ? d_stack + 3 * stackn : nullptr;
     float *d_pr = pyrR ? d_stack + 3 * stackn + (pyrL ? 3 * stackn : 0) : nullptr;
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, F - 1));
-    UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
-    UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, d_pl, d_pr));
+    UCHK(enqueue_pyramids(ctx, *s, slot, s->rgbL, s->rgbR, W, H, stride, F - 1));
+    UCHK(enqueue_fovea_coarse(ctx, *s, slot, d_state));
+    UCHK(enqueue_fovea_fine(ctx, *s, slot, d_state, off_x, off_y, d_stack, d_pl, d_pr));
     HIPCHK(ctx, hipMemcpyAsync(stackH, d_stack, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     HIPCHK(ctx, hipMemcpyAsync(stackV, d_stack + stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     HIPCHK(ctx, hipMemcpyAsync(stackC, d_stack + 2 * stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrL) HIPCHK(ctx, hipMemcpyAsync(pyrL, d_pl, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrR) HIPCHK(ctx, hipMemcpyAsync(pyrR, d_pr, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    return ugsm_wait(ctx, 0);
+    return sync ? ugsm_wait(ctx, slot) : UGSM_OK;
+}
+
+int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
+                        int off_y, float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR)
+{
+    return match_foveated_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, off_x, off_y, stackH, stackV, stackC, pyrL, pyrR, true);
+}
+
+int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
+                              int off_y, float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR)
+{
+    return match_foveated_on_slot(ctx, slot, rgbL, rgbR, W, H, stride, off_x, off_y, stackH, stackV, stackC, pyrL, pyrR, false);
 }
 
 // match(L, R, fov == 1), MatchGPULib.cpp:354-360: foveated matching, then hierarchicalDisparity on the stacks
