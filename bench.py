@@ -364,6 +364,13 @@ def main():
                 "per_level": [{"level": lv, "launches_per_pair": st["launches"] / n_pairs, "avg_us": 1e3 * st["total_ms"] / st["launches"],
                                "frac": BYTES_PER_PIXEL_ITER * st["pixel_launches"] / (st["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                               for lv, st in sorted(e["levels"].items()) if st["launches"]],
+                # the same launch-weighted figure over the levels of >= 0.2 Mpx only (levels 0-6 at 16 MP: the launches rounds 1-2 ran through
+                # this kernel; from round 3 on the throughput choices also send the 50-200 k-pixel levels through it, 44 launches of
+                # ~19 us that move 1.5-3 MB each and pull the all-launch average down while the pairs/s go up)
+                "frac_levels_of_200k_pixels_and_more": (
+                    (lambda big: (BYTES_PER_PIXEL_ITER * sum(st["pixel_launches"] for st in big) / (sum(st["total_ms"] for st in big) * 1e-3) / 1e9
+                                  / HBM_PEAK_GBS) if big else None)(
+                        [st for lv, st in e["levels"].items() if st["launches"] and st["pixel_launches"] / st["launches"] >= 200000])),
                 "traffic_source": (f"profiles/pmc_traffic.json ({prof.get('_tag', '?')}: PMC passes of tools/profile_round.sh, not measured in this run)"
                                    if traffic is not None else None),
                 "note": "algorithmic bytes (48 B per pixel-iteration x pixels of the launch) / HIP-event duration on the launching stream, "
