@@ -182,7 +182,8 @@ def main():
                     "one pair's in-flight time, 24 ms at 16 MP -- 4 %% of 96 steps, 1 %% of 384; 4000 steps: 171 pairs/s where 96 give 167)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="full16mp", choices=sorted(WORKLOADS))
-    ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU (HIP streams)")
+    ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams the slots are dealt onto (ugsm_config.streams; 0 = one per slot)")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-pairs", type=int, default=3, help="pairs of the single-pair event pass after the timed region (0 = skip)")
@@ -224,7 +225,7 @@ def main():
     W, H, mode = wl["W"], wl["H"], wl["mode"]
     slots = max(1, args.slots)
     F = 7
-    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0)
+    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0, streams=args.streams)
     fw, fh = _lib.fovea_dims(W, H, 14, F)
 
     # synthetic inputs: two distinct pairs per rank, resident in HBM before the timed region
@@ -296,7 +297,7 @@ def main():
         "vs_baseline": (value / REFERENCE_PAIRS_PER_S[args.workload]) if args.workload in REFERENCE_PAIRS_PER_S else None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl["desc"], "pairs_in_flight_per_gpu": slots, "kernel_path": args.kernel_path,
+        "config": {"workload": wl["desc"], "pairs_in_flight_per_gpu": slots, "streams_per_gpu": args.streams or slots, "kernel_path": args.kernel_path,
                    "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}"},
         "value_repeats": repeats,
         "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),

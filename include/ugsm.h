@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define UGSM_ABI_VERSION 3  /* 3: ugsm_config grew (lr_check_threshold), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked */
+#define UGSM_ABI_VERSION 3  /* 3: ugsm_config grew (lr_check_threshold, streams), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked,
+                               ugsm_submit_full_host, ugsm_submit_foveated_host, ugsm_plan_level_in_frame */
 
 /* status codes */
 #define UGSM_OK                0
@@ -76,6 +77,11 @@ typedef struct ugsm_config {
                              exchanged, and the confidence of every left pixel whose match (x + dx, y + dy) in the right-to-left
                              field does not point back within this many pixels, in x or in y, is set to 0 (dx, dy unchanged).
                              Doubles the matching work of a call. */
+    int streams;          /* HIP streams the slots' work is dealt onto; 0 (default) = one per slot.  With fewer streams than slots, slot i
+                             enqueues on the stream of slot i % streams: several pairs QUEUED per stream.  The chip runs four hardware
+                             queues well and no more, so a throughput host uses streams = 4 and slots = 8: a
+                             stream's next pair is already enqueued when the one before it ends.  ugsm_wait(slot) still waits for
+                             that slot's pair only. */
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);

@@ -231,3 +231,33 @@ def test_submit_foveated_host_from_pinned_memory(lib, orc):
         bad = np.empty((F, fh, fw), np.float32)
         assert c.lib.ugsm_submit_foveated_host(c.handle, 0, hin[0][0].ctypes.data, hin[0][1].ctypes.data, W, H, 3 * W, 0, 0, bad.ctypes.data,
                                                st[0][1].ctypes.data, st[0][2].ctypes.data, None, None) == lib.UGSM_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("slots,streams", [(4, 2), (3, 1), (5, 4)])
+def test_several_slots_queued_on_one_stream(lib, orc, slots, streams):
+    """ugsm_config.streams < slots: slot i enqueues on the stream of slot i % streams; ugsm_wait(slot) waits for that slot's pair only
+    (waits in the reverse order of submission), every slot re-used, full and foveated submits."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv, F = 300, 220, 9, 4
+    pairs = [synth.make_pair(W, H, synth.BASE_SEED + 400 + j)[:2] for j in range(slots)]
+    refs = [orc.match_full(L, R, lv) for (L, R) in pairs]
+    fw, fh = lib.fovea_dims(W, H, lv, F)
+    with lib.Context(levels=lv, fovea_levels=F, slots=slots, streams=streams) as c:
+        d_in = [(c.to_device(L), c.to_device(R)) for (L, R) in pairs]
+        outs = [c.alloc(3 * W * H * 4) for _ in range(slots)]
+        for rep in range(2):
+            for j in range(slots):
+                c.check(c.lib.ugsm_submit_full(c.handle, j, d_in[(j + rep) % slots][0], d_in[(j + rep) % slots][1], W, H, 3 * W, outs[j]))
+            for j in reversed(range(slots)):
+                c.check(c.lib.ugsm_wait(c.handle, j))
+                assert_bit_equal(c.to_host(outs[j], (3, H, W)), refs[(j + rep) % slots], f"slot {j} of {slots} on {streams} streams, round {rep}")
+        stack = c.alloc(3 * F * fh * fw * 4)
+        c.check(c.lib.ugsm_submit_foveated(c.handle, slots - 1, d_in[0][0], d_in[0][1], W, H, 3 * W, 0, 0, stack, None, None))
+        c.check(c.lib.ugsm_submit_full(c.handle, 0, d_in[1][0], d_in[1][1], W, H, 3 * W, outs[0]))  # (queued behind it when the stream is shared)
+        c.check(c.lib.ugsm_wait(c.handle, slots - 1))
+        exp, _, _ = orc.match_foveated(pairs[0][0], pairs[0][1], lv, F)
+        assert_bit_equal(c.to_host(stack, (3, F, fh, fw)), exp, "foveated on a shared stream")
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        assert_bit_equal(c.to_host(outs[0], (3, H, W)), refs[1], "full behind foveated")
+        with pytest.raises(lib.UgsmError):
+            lib.Context(levels=lv, slots=2, streams=-1)

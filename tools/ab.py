@@ -15,6 +15,7 @@ ap.add_argument("--pairs", type=int, default=48)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--levels", type=int, default=14)
 ap.add_argument("--size", type=int, nargs=2, default=(4928, 3264))
+ap.add_argument("--streams", type=int, default=0, help="ugsm_config.streams (0 = one per slot)")
 ap.add_argument("--fovea", type=int, default=0, help="foveated mode with this many fovea levels (0 = full mode)")
 ap.add_argument("--child", action="store_true", help="(internal) measure under the current environment, print the rate")
 ap.add_argument("configs", nargs="*")
@@ -35,7 +36,7 @@ if args.child:
     fw, fh = _lib.fovea_dims(W, H, args.levels, F) if F else (W, H)
     outs = [torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(args.slots)]
     torch.cuda.synchronize()
-    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F) as c:
+    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams) as c:
         lib, h = c.lib, c.handle
 
         def run(n):
@@ -69,7 +70,7 @@ for r in range(args.rounds):
     for i in order:
         env = dict(os.environ, UGSM_DEV="1", **cfgs[i][1])
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--slots", str(args.slots), "--pairs", str(args.pairs), "--levels",
-                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea)], env=env, capture_output=True, text=True, timeout=300)
+                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea), "--streams", str(args.streams)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RATE")]
         if not line:
             print(out.stdout[-2000:], out.stderr[-2000:])
@@ -77,7 +78,7 @@ for r in range(args.rounds):
         rates[i].append(float(line[0].split()[1]))
         print(f"round {r} {cfgs[i][0]}: {rates[i][-1]:.2f}", flush=True)
 base = statistics.median(rates[0])
-print(f"{W}x{H}, {args.levels} levels{', fovea levels ' + str(args.fovea) if args.fovea else ''}, slots={args.slots}, {args.pairs} pairs x 3, {args.rounds} processes each (pairs/s: median  min  max  vs first)")
+print(f"{W}x{H}, {args.levels} levels{', fovea levels ' + str(args.fovea) if args.fovea else ''}, slots={args.slots}{' on ' + str(args.streams) + ' streams' if args.streams else ''}, {args.pairs} pairs x 3, {args.rounds} processes each (pairs/s: median  min  max  vs first)")
 for (name, env), rs in zip(cfgs, rates):
     m = statistics.median(rs)
     print(f"  {name:28s} {m:8.2f} {min(rs):8.2f} {max(rs):8.2f}  {100.0 * (m / base - 1.0):+6.2f} %   {env}")

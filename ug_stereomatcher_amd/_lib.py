@@ -46,7 +46,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("levels", C.c_int), ("fovea_levels", C.c_int), ("slots", C.c_int),
                 ("kernel_path", C.c_int), ("profile_events", C.c_int), ("march_min_pixels", C.c_int), ("march_np", C.c_int),
                 ("march_rows", C.c_int), ("march_smooth", C.c_int), ("early_exit_threshold", C.c_float), ("small_max_pixels", C.c_int),
-                ("lr_check_threshold", C.c_float)]
+                ("lr_check_threshold", C.c_float), ("streams", C.c_int)]
 
 
 class LevelPlan(C.Structure):
@@ -184,7 +184,7 @@ class Context:
     def __init__(self, device: int = 0, levels: int = 14, fovea_levels: int = 7, slots: int = 1,
                  kernel_path: int = 0, profile_events: int = 0, march_min_pixels: int = 0, march_np: int = 0,
                  march_rows: int = 0, march_smooth: int = 0, early_exit_threshold: float = 0.0, small_max_pixels: int = 0,
-                 lr_check_threshold: float = 0.0):
+                 lr_check_threshold: float = 0.0, streams: int = 0):
         lib = load()
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))
@@ -196,6 +196,7 @@ class Context:
         cfg.early_exit_threshold = float(early_exit_threshold)
         cfg.small_max_pixels = int(small_max_pixels)
         cfg.lr_check_threshold = float(lr_check_threshold)
+        cfg.streams = int(streams)
         self.cfg = cfg
         self._pinned = []
         self._h = C.c_void_p()

@@ -63,6 +63,9 @@ struct Slot {
     // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
     // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
     hipStream_t st2 = nullptr;
+    bool owns_st = true;           // false: `st` is the stream of slot (index % streams): several slots queue their pairs on one stream
+    hipEvent_t ev_done = nullptr;  // recorded at the end of every ugsm_submit_*: what ugsm_wait waits for when the stream is shared
+    bool done_recorded = false;
     bool lat = true;  // the kernel choices of the call in flight: latency (launches short) or throughput (least work); latency_mode()
     hipEvent_t ev_in = nullptr, ev_L = nullptr, ev_R = nullptr, ev_A[UGSM_MAX_LEVELS] = {};
     float *lr = nullptr;     // LR check: the right-to-left field of level 0 (3 planes) + one 8-byte counter behind it
@@ -183,6 +186,7 @@ struct ugsm_ctx {
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
     int march4_lo = -1, march4_hi = -1;  // development override of k_cost_march4's pixel range (use_march4; -1 = by the mode; 0, 0 = never)
     int force_mode = -1;  // development override of latency_mode(): 1 latency, 0 throughput
+    int streams = 1;      // streams the slots' work is dealt onto: slot i enqueues on the stream of slot i % streams (ugsm_config.streams)
     int iter_small = 0;   // coarse levels: smoothing of iteration m + cost step of iteration m+1 in one launch (k_iter_small)
     int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
     int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
@@ -962,7 +966,7 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
     return UGSM_OK;
 }
 
-int get_slot(ugsm_ctx *ctx, int slot, Slot **out)
+int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
 {
     if (!ctx) return UGSM_ERR_BAD_ARG;
     if (slot < 0 || slot >= (int)ctx->slots.size()) {
@@ -970,6 +974,17 @@ int get_slot(ugsm_ctx *ctx, int slot, Slot **out)
         return UGSM_ERR_BAD_ARG;
     }
     *out = &ctx->slots[slot];
+    if (enqueues) (*out)->done_recorded = false;  // whatever this call enqueues comes after the slot's last completion mark
+    return UGSM_OK;
+}
+
+// End of a ugsm_submit_*: the slot's completion mark.  With several slots on one stream (ugsm_config.streams < slots) ugsm_wait waits for
+// this event, not for the pairs other slots have queued behind it on the same stream.
+int mark_done(ugsm_ctx *ctx, Slot &s)
+{
+    if (ctx->streams >= (int)ctx->slots.size()) return UGSM_OK;
+    HIPCHK(ctx, hipEventRecord(s.ev_done, s.st));
+    s.done_recorded = true;
     return UGSM_OK;
 }
 
@@ -1158,7 +1173,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         if (memcmp(g, k, sizeof g) != 0) return UGSM_ERR_STATE;
     }
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
-        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f))
+        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f) || cfg.streams < 0)
         return UGSM_ERR_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return UGSM_ERR_NO_DEVICE;
@@ -1174,8 +1189,16 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->slots.resize(cfg.slots);
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // ugsm_config.streams: fewer streams than slots = several pairs QUEUED per stream (slot i on the stream of slot i % streams): the
+    // next pair of a stream is already enqueued when the one before it ends, where a slot of its own stream idles while the host
+    // notices the end and enqueues ~600 launches (1.6 ms of a pair's 24 ms in flight at 16 MP)
+    ctx->streams = cfg.streams > 0 ? std::min(cfg.streams, cfg.slots) : cfg.slots;
     for (int si = 0; si < cfg.slots; si++) {
         Slot &s = ctx->slots[si];
+        if (si >= ctx->streams) {
+            s.st = ctx->slots[si % ctx->streams].st;
+            s.owns_st = false;
+        }
         // Every slot's stream on a hardware queue of its own.  HIP deals a process's streams onto GPU_MAX_HW_QUEUES (4) hardware
         // queues PER PRIORITY LEVEL, least-used first, and two streams that share a queue run their kernels strictly one after
         // the other (tools/queue_probe).  At the default priority the host application's streams -- the null stream any hipMemcpy
@@ -1185,7 +1208,8 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         // default.  Equal priority among the first four; the side stream of a one-slot context rides in the same pool.
         const char pc = knobs.stream_prio[0] ? (si < (int)strlen(knobs.stream_prio) ? knobs.stream_prio[si] : 'n') : (si < 4 ? 'h' : (si < 8 ? 'l' : 'n'));
         const int prio = pc == 'h' ? prio_greatest : (pc == 'l' ? prio_least : 0);
-        bool ok = hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess && hipMalloc((void **)&s.range_bad, 64) == hipSuccess &&
+        bool ok = (!s.owns_st || hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess) &&
+                  hipMalloc((void **)&s.range_bad, 64) == hipSuccess && hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
                   (!ctx->two_streams || hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : prio))) == hipSuccess);
         for (hipEvent_t *e : {&s.ev_in, &s.ev_L, &s.ev_R}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < cfg.levels; i++) ok = ok && hipEventCreateWithFlags(&s.ev_A[i], hipEventDisableTiming) == hipSuccess;
@@ -1222,7 +1246,8 @@ void ugsm_destroy(ugsm_ctx *ctx)
         if (s.lr) (void)hipFree(s.lr);
         if (s.lr_host) (void)hipHostFree(s.lr_host);
         if (s.st2) (void)hipStreamDestroy(s.st2);
-        if (s.st) (void)hipStreamDestroy(s.st);
+        if (s.st && s.owns_st) (void)hipStreamDestroy(s.st);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     delete ctx;
 }
@@ -1300,7 +1325,8 @@ int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     Slot *s;
     UCHK(get_slot(ctx, slot, &s));
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    return enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, ctx->cfg.fovea_levels >= 2 ? ctx->cfg.fovea_levels - 1 : -1);
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, ctx->cfg.fovea_levels >= 2 ? ctx->cfg.fovea_levels - 1 : -1));
+    return mark_done(ctx, *s);
 }
 
 int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, float *d_out)
@@ -1310,7 +1336,8 @@ int ugsm_submit_full(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8
     if (!d_out) return UGSM_ERR_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, 0));
-    return enqueue_full_lr(ctx, *s, slot, d_out);
+    UCHK(enqueue_full_lr(ctx, *s, slot, d_out));
+    return mark_done(ctx, *s);
 }
 
 int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state)
@@ -1320,7 +1347,8 @@ int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state)
     if (!d_state) return UGSM_ERR_BAD_ARG;
     if (!s->have_pyr) return UGSM_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    return enqueue_fovea_coarse(ctx, *s, slot, d_state);
+    UCHK(enqueue_fovea_coarse(ctx, *s, slot, d_state));
+    return mark_done(ctx, *s);
 }
 
 int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int off_x, int off_y, float *d_stack)
@@ -1330,7 +1358,8 @@ int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int of
     if (!d_state || !d_stack) return UGSM_ERR_BAD_ARG;
     if (!s->have_pyr) return UGSM_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    return enqueue_fovea_fine(ctx, *s, slot, d_state, off_x, off_y, d_stack, nullptr, nullptr);
+    UCHK(enqueue_fovea_fine(ctx, *s, slot, d_state, off_x, off_y, d_stack, nullptr, nullptr));
+    return mark_done(ctx, *s);
 }
 
 int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride,
@@ -1348,14 +1377,16 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     const size_t fn3 = 3 * (size_t)s->w[F - 1] * s->h[F - 1];
     UCHK(grow(ctx, s->hout, s->hout_cap, std::max(fn3, s->hout_cap)));
     UCHK(enqueue_fovea_coarse(ctx, *s, slot, s->hout));
-    return enqueue_fovea_fine(ctx, *s, slot, s->hout, off_x, off_y, d_stack, d_pyrL, d_pyrR);
+    UCHK(enqueue_fovea_fine(ctx, *s, slot, s->hout, off_x, off_y, d_stack, d_pyrL, d_pyrR));
+    return mark_done(ctx, *s);
 }
 
 int ugsm_wait(ugsm_ctx *ctx, int slot)
 {
     Slot *s;
-    UCHK(get_slot(ctx, slot, &s));
-    HIPCHK(ctx, hipStreamSynchronize(s->st));
+    UCHK(get_slot(ctx, slot, &s, false));
+    if (s->done_recorded) HIPCHK(ctx, hipEventSynchronize(s->ev_done));  // (shared stream: this slot's pair, not the ones queued behind it)
+    else HIPCHK(ctx, hipStreamSynchronize(s->st));
     harvest(ctx, *s);
     return UGSM_OK;
 }
@@ -1388,7 +1419,7 @@ static int match_full_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, cons
     float *const dst[3] = {dispH, dispV, dispC};
     if (sync) prefault_planes(ctx, dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
     UCHK(copy_out_planes(ctx, *s, s->hout, n, dst));
-    return sync ? ugsm_wait(ctx, slot) : UGSM_OK;
+    return sync ? ugsm_wait(ctx, slot) : mark_done(ctx, *s);
 }
 
 int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
@@ -1439,7 +1470,7 @@ static int match_foveated_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, 
     HIPCHK(ctx, hipMemcpyAsync(stackC, d_stack + 2 * stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrL) HIPCHK(ctx, hipMemcpyAsync(pyrL, d_pl, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrR) HIPCHK(ctx, hipMemcpyAsync(pyrR, d_pr, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
-    return sync ? ugsm_wait(ctx, slot) : UGSM_OK;
+    return sync ? ugsm_wait(ctx, slot) : mark_done(ctx, *s);
 }
 
 int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
