@@ -1282,16 +1282,21 @@ int smooth_tile_rows(int W, int H, int latency)
     return best ? best : std::min(HMAX, std::max(H, 1));
 }
 
+// levels of at least this many pixels (and below the 112-column tile's range): 64 x 32 tiles, else 32 x 16.  2^18 since the end of round 3: a
+// 615 x 407 level (16 MP's level 6, the fovea windows) is 130 tiles of 64 x 32 on 256 CUs, 520 of 32 x 16 -- one pair alone +0.5 %, the
+// foveated stack with four slots +1.5 % (tools/ab.py; 2^19: -0.2 %, 2^16: -0.4 %)
+int smooth_mid_min_pixels = 1 << 18;
+
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows)
 {
     // big levels: 112 x (up to 36) tiles, 512 threads, <= 77 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
     // the other's passes; measured, the two phases still nearly add up: DESIGN.md section 4).  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
     // columns every pass recomputes are 12.5 % of the row instead of 20 % (at 16 MP: 5 passes 227 us against 266 us for
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
-    // mid levels: 64x32; small levels: 32x16 so that the launch is short and the chip still fills
+    // mid levels (from smooth_mid_min_pixels): 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
     if (tile_rows > 0 || px >= ((size_t)1 << 19)) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36);
-    else if (px >= ((size_t)1 << 17)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
+    else if (px >= (size_t)smooth_mid_min_pixels) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
     else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
 }
 

@@ -71,11 +71,12 @@ void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *r
 void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows);
 // `passes` Jacobi smoothing passes (+ the 3x3 box when do_box) in one LDS-tiled launch.
 // tile_rows: > 0 = the 112-column tile at this height (1..kSmoothTileRowsMax; smooth_tile_rows picks it); 0 = the tile class by the
-// level's size (112 x 36 from 0.5 Mpx, 64 x 32 from 0.13 Mpx, else 32 x 16).
+// level's size (112 x 36 from 0.5 Mpx, 64 x 32 from 0.26 Mpx, else 32 x 16).
 constexpr int kSmoothTileRowsMax = 36;  // (39 rows still fit two workgroups per CU -- 3 x 53 x 128 floats = 81 408 B of LDS -- but the kernel's
                                         // unrolled load / box loops, sized for the tallest tile, then cost every 36-row launch 7.7 % more instructions)
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows = 0);
 int smooth_tile_rows(int W, int H, int latency);
+extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad);

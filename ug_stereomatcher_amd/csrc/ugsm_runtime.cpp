@@ -454,6 +454,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     if (const char *e = getenv("UGSM_POLICY")) k.force_mode = e[0] == 'l' ? 1 : (e[0] == 't' ? 0 : -1);
     geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
     geti("UGSM_ITER_SMALL", k.iter_small);
+    geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);  // (a process-wide tuning variable, like UGSM_MARCH_AGE)
     if (const char *e = getenv("UGSM_MARCH_AGE")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
@@ -604,7 +605,7 @@ bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool lat)
     return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, lat) || use_march4(ctx, W, H, lat));
 }
 
-// k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.13 Mpx, else 32 x 16), > 0 = the
+// k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.26 Mpx, else 32 x 16), > 0 = the
 // 112-column tile at this height (smooth_tile_rows, ugsm_kernels_fused.hip).  Throughput: the 112 x 36 tile (1.39 x the tile in halo
 // work, against 1.8 x for 64 x 32) from 0.1 Mpx on, +1.7 % with four 16 MP pairs in flight.  Latency: from 0.5 Mpx, and a one-slot
 // context picks the height that fills whole rounds of workgroups.
