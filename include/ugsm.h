@@ -70,7 +70,7 @@ typedef struct ugsm_config {
                              reference, whose results this option therefore leaves; one host round trip per iteration) */
     int small_max_pixels; /* levels of at most this many pixels run K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip:
                              channel-parallel 16 x 12 tiles, one thread per pixel; same results bit for bit); 0 = default
-                             threshold, < 0 = never */
+                             threshold (0.15 Mpx in a one-slot context, 50 k pixels with several slots), < 0 = never */
     float lr_check_threshold; /* LR-consistency check, OFF at 0 (default).  Named by the north star; THE REFERENCE HAS NONE (no
                              right-to-left pass in MatchLib.cu / MatchGPULib.cpp), so any value > 0 leaves the reference's results:
                              full mode only (ugsm_match_full / ugsm_submit_full), the pair is matched a second time with the images

@@ -550,15 +550,23 @@ int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->
 // two or three waves of k_cost_march: 0.15 - 3 Mpx (tools/kbench mode 14: 10.9 against 16.4 us at 0.25 Mpx, 24.3 / 29.8 at 1 Mpx,
 // 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).  Latency only: four waves per strip are more instructions in total (-1.3 % with four
 // 16 MP pairs in flight).
-constexpr int kSmallDefaultMaxPixels = 150000, kMarch4MaxPixels = 3000000;
+// Levels of at most this many pixels run the coarse-level latency kernels (0 = none): 0.15 Mpx for a pair alone -- above it the other
+// kernels are as fast or faster (tools/kbench modes 7, 14) -- and 50 k pixels with several slots, whatever the frames: there the levels
+// of 50-150 k pixels are better off with k_cost_march4 / k_cost_march and the tiled K-smooth, which redo less (four slots: the foveated
+// stack +4.5 %, 4 MP frames +2.0 %, 1080p +10-18 %; one pair alone -1.4 %; tools/ab.py)
+constexpr int kSmallMaxPixelsAlone = 150000, kSmallMaxPixelsShared = 50000, kMarch4MaxPixels = 3000000;
+int small_max_px(const ugsm_config &cfg)
+{
+    if (cfg.small_max_pixels < 0) return 0;
+    return cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.slots == 1 ? kSmallMaxPixelsAlone : kSmallMaxPixelsShared);
+}
 bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
     const ugsm_config &cfg = ctx->cfg;
     const long long px = (long long)W * H;
     if (cfg.kernel_path == 1) return false;
     if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
-    const int small_thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.small_max_pixels < 0 ? 0 : kSmallDefaultMaxPixels);
-    return lat && px > small_thr && px <= kMarch4MaxPixels;
+    return lat && px > small_max_px(cfg) && px <= kMarch4MaxPixels;
 }
 
 // The choices of a context that are not in ugsm_config: the development overrides (the defaults are in the functions around here).
@@ -585,7 +593,7 @@ int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat)
 {
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
-    const long long thr = cfg.small_max_pixels > 0 ? cfg.small_max_pixels : kSmallDefaultMaxPixels;
+    const long long thr = small_max_px(cfg);
     const long long px = (long long)W * H;
     if (px > thr || use_march(ctx, W, H, lat)) return 0;
     if (ctx->small_rh_force) return ctx->small_rh_force;
