@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define UGSM_ABI_VERSION 3  /* 3: ugsm_config grew (lr_check_threshold, streams), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked,
+#define UGSM_ABI_VERSION 4  /* 4: ugsm_config grew (batch, stream_priority), ugsm_submit_full_batch, ugsm_submit_foveated_batch; kernel_path 1,
+                               march_smooth and the probe entry points moved to libugsm_dev.so (include/ugsm_dev.h)
+                               3: ugsm_config grew (lr_check_threshold, streams), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked,
                                ugsm_submit_full_host, ugsm_submit_foveated_host, ugsm_plan_level_in_frame */
 
 /* status codes */
@@ -39,6 +41,7 @@ extern "C" {
 #define UGSM_ERR_STATE         7  /* e.g. fine phase without coarse phase */
 
 #define UGSM_MAX_LEVELS 32
+#define UGSM_MAX_BATCH 8   /* pairs per ugsm_submit_*_batch call */
 
 typedef struct ugsm_ctx ugsm_ctx;
 
@@ -47,8 +50,9 @@ typedef struct ugsm_ctx ugsm_ctx;
  *   levels        <- MAX_LEVEL, MatchLib_common.h:13 (14)
  *   fovea_levels  <- foveatelevel = argv[2] or 7, MatchGPULib.cpp:259-264
  *   slots         <- pairs in flight (one HIP stream each); the reference has 1
- *   kernel_path   <- 0: fused gfx950 kernels (default); 1: one-stage-per-kernel
- *                    path kept for A/B parity checks (same results bit for bit)
+ *   kernel_path   <- 0: fused gfx950 kernels (default, and the only path of libugsm.so); 1: one-stage-per-kernel
+ *                    path kept for A/B parity checks (same results bit for bit) -- in libugsm_dev.so only since ABI 4,
+ *                    libugsm.so answers UGSM_ERR_BAD_ARG
  *   march_*       <- which levels run the marching form of the cost kernel (same results bit for bit) */
 typedef struct ugsm_config {
     int device;
@@ -62,8 +66,8 @@ typedef struct ugsm_config {
     int march_np;         /* ignored since ABI 3 (kept for layout): the two-pixels-per-lane development form of the marching kernel
                              is no longer in the library (tools/kbench.hip instantiates it) */
     int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
-    int march_smooth;     /* 1: those levels also run K-smooth (five passes at a time) as a marching kernel; 0 (default): the
-                             LDS-tiled K-smooth everywhere -- the marching form is bit-identical but no faster */
+    int march_smooth;     /* libugsm_dev.so only (ignored by libugsm.so since ABI 4): 1: those levels also run K-smooth (five passes at a
+                             time) as a marching kernel -- bit-identical, measured slower than the LDS-tiled K-smooth */
     float early_exit_threshold; /* SURVEY 8f row f-4, OFF at 0 (default): when > 0, a level stops iterating as soon as the
                              confidence-weighted mean change of dx and of dy between two iterations is below it
                              (differenceIterations / weightedDifference, MatchGPULib.cpp:1323-1437 -- dead code in the
@@ -82,10 +86,23 @@ typedef struct ugsm_config {
                              queues well and no more, so a throughput host uses streams = 4 and slots = 8: a
                              stream's next pair is already enqueued when the one before it ends.  ugsm_wait(slot) still waits for
                              that slot's pair only. */
+    int batch;            /* pairs per ugsm_submit_*_batch call the context expects (1 .. UGSM_MAX_BATCH; 0 = 1).  A hint: buffers grow on
+                             demand to whatever a call brings; ugsm_plan_level reports the kernels of a call of this many pairs. */
+    int stream_priority;  /* HIP priority of the slots' streams.  0 (default): a pool of their own -- slots 0-3 at the GREATEST priority,
+                             4-7 at the least, the rest at the process default: HIP deals streams onto 4 hardware queues PER PRIORITY
+                             LEVEL, and two streams on one queue run strictly one after the other, so slots that share the default
+                             pool with the host application's streams (the null stream any hipMemcpy uses, for a start) end up three
+                             to a queue: 129 instead of 165 pairs/s at 16 MP.  The price: the library's kernels
+                             are scheduled ahead of the host application's other GPU work, and a second context in the process (or
+                             another process on the card) that does the same shares those four queues.  1: every slot at the
+                             process default -- opt out, for a host whose own GPU work must not be outranked, or that runs several
+                             contexts; 2: every slot at the greatest priority; 3: every slot at the least. */
 } ugsm_config;
 
 void ugsm_default_config(ugsm_config *cfg);
 int ugsm_abi_version(void);
+/* 0 in libugsm.so; 1 in libugsm_dev.so, the same sources built with the development kernels (include/ugsm_dev.h) */
+int ugsm_is_dev_library(void);
 const char *ugsm_status_string(int status);
 
 /* MatchGPULib::MatchGPULib(argc, argv), MatchGPULib.cpp:251-265.  Owns all device
@@ -173,6 +190,20 @@ int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const ui
 int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H,
                               int stride, int off_x, int off_y, float *stackH, float *stackV,
                               float *stackC, float *pyrL, float *pyrR);
+/* B pairs per call (round 4) -- BASELINE configs[4] is "a batch of 8 x 16 MP foveated pairs"; the reference's loop is 176 strictly
+ * sequential iterations per pair (MatchGPULib.cpp:1741-1743), and on every level of 615 x 407 pixels and below each of them is a launch
+ * that lasts as long as ONE tile's or strip's chain whatever the rest of the chip could do.  The n pairs of a batch (1 <= n <=
+ * UGSM_MAX_BATCH, all W x H) march through the levels in lockstep on the slot's stream: every level of at most ~2 Mpx is ONE launch
+ * for all of them (a pair index in every kernel's grid), larger levels fill the chip pair by pair and are launched so.  Same
+ * arithmetic, same results bit for bit as n single calls.  d_rgbL / d_rgbR / d_out (d_stack, d_pyrL, d_pyrR): HOST arrays of n
+ * DEVICE pointers, buffers laid out as for ugsm_submit_full / ugsm_submit_foveated; off_x / off_y: n window offsets (NULL = centred);
+ * d_pyrL / d_pyrR may be NULL.  The slot holds the whole batch: ugsm_wait(slot) waits for all n pairs.  Contexts with
+ * early_exit_threshold or lr_check_threshold set (and kernel_path 1) run the pairs one after the other. */
+int ugsm_submit_full_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR,
+                           int W, int H, int stride, float *const *d_out);
+int ugsm_submit_foveated_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR,
+                               int W, int H, int stride, const int *off_x, const int *off_y, float *const *d_stack,
+                               float *const *d_pyrL, float *const *d_pyrR);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
 int ugsm_wait_all(ugsm_ctx *ctx);
 /* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the
@@ -223,6 +254,8 @@ int ugsm_reconstruct_full(ugsm_ctx *ctx, int slot, const float *d_stackH, const 
                           const float *d_stackC, int W, int H, int off_x, int off_y, float *d_out3);
 
 /* ---- stage-level entry points (tests only; device pointers; synchronous) -------- */
+/* (the probes of the kernels' exact arithmetic shortcuts -- ugsm_stage_poly_probe, ugsm_stage_div3_probe, ugsm_stage_div_probe -- are
+ * declared in include/ugsm_dev.h and exported by libugsm_dev.so only) */
 
 /* CreatePyramidFromImage, MatchGPULib.cpp:1033-1125: builds the pyramid of one rgb8
  * image in `slot`'s left pyramid and copies level `level` (3 planes) to d_out3. */
@@ -239,18 +272,6 @@ int ugsm_stage_seed(ugsm_ctx *ctx, const float *d_src3, int W, int H, float *d_d
 /* S smoothing passes (+ box if do_box), MatchGPULib.cpp:2257-2412, in place */
 int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int do_box);
 
-/* The fused kernels' exact arithmetic shortcuts (f32 first quotient of PolyDisparity, x/3 by two
- * FMAs) evaluated on caller-supplied operands: delta/corr = PolyDisparity(c,l,r,thr)
- * (MatchLib.cu:805-836), third = c/3.0f for c >= 0.  Lets tests force the rare fallback branches. */
-int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r,
-                          const float *d_thr, float *d_delta, float *d_corr, float *d_third, int n);
-
-/* K-smooth's shared-reciprocal division (three weighted sums over one sumCorr, MatchLib.cu:1131-1139)
- * on caller-supplied operands, with the kernel's own range test and literal fallback:
- * q_f[i] must equal the IEEE binary32 quotient a_f[i] / s[i] bit for bit. */
-int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2,
-                          const float *d_s, float *d_q0, float *d_q1, float *d_q2, int n);
-
 /* Row f-4: weightedDifference (MatchGPULib.cpp:1336-1437) of two device (dx, dy, conf) fields, weights = the new field's
  * conf: out2[0] = dx, out2[1] = dy (host).  Fixed-order binary64 sums, identical to the CPU restatement. */
 int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const float *d_old3, int W, int H, float *out2);
@@ -262,11 +283,6 @@ long long ugsm_last_lr_marked(ugsm_ctx *ctx, int slot);
 /* Iterations each level of the last call on `slot` actually ran (early_exit_threshold > 0 can stop a level early);
  * per_level[UGSM_MAX_LEVELS], -1 for levels not run.  ugsm_stage_iterate records its count at index 0. */
 int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level);
-
-/* K-cost's range-guarded division (the compiler's binary32 division sequence without v_div_scale / v_div_fixup, used when
- * every pyramid value of the pair is 0 or in [2^-12, 2^9]; csrc/ugsm_exact.hpp) on caller-supplied operands:
- * q[i] must equal the IEEE binary32 quotient n[i] / d[i] bit for bit for operands that are 0 or in [2^-62, 2^37]. */
-int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n);
 
 /* ---- instrumentation ------------------------------------------------------------ */
 

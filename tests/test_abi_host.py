@@ -26,7 +26,44 @@ def test_header_symbols_are_exported(lib):
     so = C.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
-    assert lib.load().ugsm_abi_version() == 3
+    assert lib.load().ugsm_abi_version() == 4
+    assert lib.load().ugsm_is_dev_library() == 0
+
+
+def test_dev_header_symbols_are_exported_by_the_dev_library_only(lib):
+    """include/ugsm_dev.h: libugsm_dev.so = everything ugsm.h declares + the probe entry points; libugsm.so has none of those."""
+    hdr = open(os.path.join(ROOT, "include", "ugsm_dev.h")).read()
+    declared = sorted(set(re.findall(r"\b(ugsm_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(lib.DEV_EXPORTS)
+    dev, prod = C.CDLL(lib.DEV_LIB_PATH), C.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dev, name), f"{name} declared in ugsm_dev.h but not exported by libugsm_dev.so"
+        assert not hasattr(prod, name), f"{name} is a development entry point but libugsm.so exports it"
+    for name in lib.EXPORTS:
+        assert hasattr(dev, name)
+    assert lib.load(dev=True).ugsm_is_dev_library() == 1 and lib.load(dev=True).ugsm_abi_version() == 4
+
+
+def test_product_library_holds_no_development_kernel(lib):
+    """the measured negatives (k_smooth_march, k_iter_small), the one-kernel-per-stage path and the probe kernels are
+    in libugsm_dev.so; the library a maintainer links carries only kernels a configuration of include/ugsm.h can launch."""
+    def kernels(path):   # the kernels' mangled names: _ZN4ugsm<len>k_name...
+        blob = open(path, "rb").read()
+        return set(name[:int(n)].decode() for n, name in re.findall(rb"_ZN4ugsm(\d+)(k_[a-z_0-9]+)", blob))
+    prod, dev = kernels(lib.LIB_PATH), kernels(lib.DEV_LIB_PATH)
+    banned = {"k_smooth_march", "k_iter_small", "k_poly_probe", "k_div3_probe", "k_div_probe", "k_cost_ref", "k_warp", "k_smooth_pass", "k_box",
+              "k_sqblur_clamp", "k_rgb_planes", "k_blur_decimate"}
+    assert not (prod & banned), sorted(prod & banned)
+    assert banned <= dev, sorted(banned - dev)
+    for k in ("k_cost_march", "k_cost_march4", "k_cost_small", "k_smooth_small", "k_smooth_fused", "k_pyr_base", "k_blur_decimate_tiled", "k_sqblur_tiled",
+              "k_seed", "k_copy_view", "k_lr_check"):
+        assert k in prod, k
+    # ... and the product refuses the configuration that would need them
+    cfg = lib.Config()
+    lib.load().ugsm_default_config(C.byref(cfg))
+    cfg.kernel_path = 1
+    hnd = C.c_void_p()
+    assert lib.load().ugsm_create(C.byref(cfg), C.byref(hnd)) == lib.UGSM_ERR_BAD_ARG
 
 
 def test_status_strings(lib):

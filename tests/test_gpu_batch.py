@@ -1,0 +1,260 @@
+"""B pairs per call (round 4): ugsm_submit_full_batch / ugsm_submit_foveated_batch.
+
+The pairs of a batch march through the levels in lockstep; every level of at most ~2 Mpx is one launch for all of them (a pair index in
+every kernel's grid).  Same arithmetic, so EVERY pair of EVERY batch must equal the CPU oracle's answer for that pair bit for bit --
+B = 1, 2, 4, 8; full and foveated mode; different images and different fovea offsets inside one batch; every K-cost / K-smooth form
+forced onto the batched levels in turn; contexts whose options make a batch run pair by pair.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from ug_stereomatcher_amd import _lib
+    return _lib
+
+
+def _pairs(W, H, n, seed0):
+    from ug_stereomatcher_amd import synth
+    out = []
+    for j in range(n):
+        L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + seed0 + 7 * j)
+        if j % 3 == 1:           # a zero patch in some pairs of the batch: 0/0 -> NaN correlations on their levels only
+            L = L.copy()
+            L[H // 5:H // 5 + 24, W // 4:W // 4 + 40] = 0
+        out.append((L, R))
+    return out
+
+
+def _full_batch(c, pairs, W, H, slot=0):
+    n = len(pairs)
+    dL = [c.to_device(L) for L, _ in pairs]
+    dR = [c.to_device(R) for _, R in pairs]
+    dO = [c.alloc(3 * W * H * 4) for _ in range(n)]
+    try:
+        c.submit_full_batch(slot, dL, dR, W, H, 3 * W, dO)
+        c.check(c.lib.ugsm_wait(c.handle, slot))
+        return [c.to_host(p, (3, H, W)) for p in dO]
+    finally:
+        for p in dL + dR + dO:
+            c.free(p)
+
+
+def _fovea_batch(c, lib, pairs, W, H, levels, F, offsets, want_pyr=False, slot=0):
+    n = len(pairs)
+    fw, fh = lib.fovea_dims(W, H, levels, F)
+    dL = [c.to_device(L) for L, _ in pairs]
+    dR = [c.to_device(R) for _, R in pairs]
+    dS = [c.alloc(3 * F * fh * fw * 4) for _ in range(n)]
+    dPL = [c.alloc(3 * F * fh * fw * 4) for _ in range(n)] if want_pyr else None
+    dPR = [c.alloc(3 * F * fh * fw * 4) for _ in range(n)] if want_pyr else None
+    try:
+        c.submit_foveated_batch(slot, dL, dR, W, H, 3 * W, offsets, dS, dPL, dPR)
+        c.check(c.lib.ugsm_wait(c.handle, slot))
+        st = [c.to_host(p, (3, F, fh, fw)) for p in dS]
+        pl = [c.to_host(p, (F, 3, fh, fw)) for p in dPL] if want_pyr else None
+        pr = [c.to_host(p, (F, 3, fh, fw)) for p in dPR] if want_pyr else None
+        return st, pl, pr
+    finally:
+        for p in dL + dR + dS + (dPL or []) + (dPR or []):
+            c.free(p)
+
+
+@pytest.mark.parametrize("B", [1, 2, 4, 8])
+def test_full_batch_vs_oracle(lib, orc, B):
+    """Every pair of a batch against the oracle: a size whose levels are all batched, an odd one whose coarse levels are smaller than a
+    tile, on a one-slot and on a several-slot context (the latency and the several-slot kernel choices)."""
+    for (W, H, lv, slots) in [(640, 480, 12, 1), (333, 251, 10, 2)]:
+        pairs = _pairs(W, H, B, 500 + W)
+        exp = [orc.match_full(L, R, lv) for L, R in pairs]
+        with lib.Context(levels=lv, slots=slots, batch=B) as c:
+            got = _full_batch(c, pairs, W, H, slot=slots - 1)
+            for b in range(B):
+                assert_bit_equal(got[b], exp[b], f"{W}x{H}, batch of {B}, slots={slots}, pair {b}")
+            # the slot is reused by a single call and by a smaller batch afterwards
+            out = c.alloc(3 * W * H * 4)
+            dL, dR = c.to_device(pairs[-1][0]), c.to_device(pairs[-1][1])
+            c.check(c.lib.ugsm_submit_full(c.handle, slots - 1, dL, dR, W, H, 3 * W, out))
+            c.check(c.lib.ugsm_wait(c.handle, slots - 1))
+            assert_bit_equal(c.to_host(out, (3, H, W)), exp[-1], "single call on the slot after a batch")
+            for p in (out, dL, dR):
+                c.free(p)
+
+
+def test_full_batch_with_levels_that_are_not_batched(lib, orc):
+    """2600 x 1700: level 0 (4.4 Mpx) is above the batch threshold and runs pair by pair, the levels below it as one launch for all
+    pairs; and the same batch with the threshold moved so that nothing / everything is batched."""
+    import os
+    W, H, lv = 2600, 1700, 14
+    pairs = _pairs(W, H, 3, 900)
+    exp = [orc.match_full(L, R, lv) for L, R in pairs]
+    for thr in (None, "-1", "100000", "100000000"):
+        if thr is not None:
+            os.environ["UGSM_BATCH_MAX_PIXELS"] = thr
+        try:
+            with lib.Context(levels=lv, slots=2, batch=3) as c:
+                got = _full_batch(c, pairs, W, H)
+        finally:
+            os.environ.pop("UGSM_BATCH_MAX_PIXELS", None)
+        for b in range(3):
+            assert_bit_equal(got[b], exp[b], f"2600x1700 batch of 3, UGSM_BATCH_MAX_PIXELS={thr}, pair {b}")
+
+
+@pytest.mark.parametrize("force", ["march", "march4", "throughput", "tiled", "no_fused_seed"])
+def test_full_batch_every_kernel_form_on_the_batched_levels(lib, orc, monkeypatch, force):
+    """The batched launches of every K-cost / K-smooth form: the marching kernel and the channel-parallel marching kernel on every
+    level (their seeded first launches included), the throughput choices, the LDS-tiled K-smooth / k_cost_split (which has no batch
+    index: pair by pair inside a batch), k_seed instead of the fused seeding."""
+    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "throughput": {"UGSM_POLICY": "throughput"},
+           "tiled": {"UGSM_MARCH_MIN_PIXELS": "-1", "UGSM_SMALL_MAX_PIXELS": "-1", "UGSM_MARCH4": "0,0"}, "no_fused_seed": {"UGSM_FUSE_SEED": "0"}}[force]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H, lv, B = 800, 600, 12, 3
+    pairs = _pairs(W, H, B, 1300)
+    exp = [orc.match_full(L, R, lv) for L, R in pairs]
+    with lib.Context(levels=lv, slots=2, batch=B) as c:
+        got = _full_batch(c, pairs, W, H)
+    for b in range(B):
+        assert_bit_equal(got[b], exp[b], f"800x600 batch of {B}, {force}, pair {b}")
+
+
+@pytest.mark.parametrize("B", [1, 2, 4, 8])
+def test_foveated_batch_with_different_offsets_vs_oracle(lib, orc, B):
+    """The foveated stack of every pair of a batch, every pair with its own window offset (centred, off-centre, clamped at the frame),
+    pyramid stacks included, against the oracle's answer for that pair and that offset."""
+    W, H, lv, F = 1280, 960, 12, 5
+    offs = [(0, 0), (-170, 90), (5000, -5000), (33, 17), (-64, -48), (250, 0), (0, -200), (-5000, 5000)][:B]
+    pairs = _pairs(W, H, B, 2100)
+    with lib.Context(levels=lv, fovea_levels=F, slots=2, batch=B) as c:
+        st, pl, pr = _fovea_batch(c, lib, pairs, W, H, lv, F, offs, want_pyr=True, slot=1)
+    for b in range(B):
+        est, epl, epr = orc.match_foveated(pairs[b][0], pairs[b][1], lv, F, offs[b][0], offs[b][1], want_pyr=True)
+        assert_bit_equal(st[b], est, f"foveated batch of {B}, pair {b}, offset {offs[b]}: disparity stack")
+        assert_bit_equal(pl[b], epl, f"foveated batch of {B}, pair {b}: left pyramid stack")
+        assert_bit_equal(pr[b], epr, f"foveated batch of {B}, pair {b}: right pyramid stack")
+
+
+@pytest.mark.parametrize("force", ["march", "march4", "throughput", "no_fused_seed"])
+def test_foveated_batch_every_kernel_form(lib, orc, monkeypatch, force):
+    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "throughput": {"UGSM_POLICY": "throughput"},
+           "no_fused_seed": {"UGSM_FUSE_SEED": "0"}}[force]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H, lv, F, B = 1000, 700, 11, 4, 3
+    offs = [(0, 0), (120, -80), (-300, 200)]
+    pairs = _pairs(W, H, B, 2500)
+    with lib.Context(levels=lv, fovea_levels=F, slots=1, batch=B) as c:
+        st, _, _ = _fovea_batch(c, lib, pairs, W, H, lv, F, offs)
+    for b in range(B):
+        est, _, _ = orc.match_foveated(pairs[b][0], pairs[b][1], lv, F, offs[b][0], offs[b][1])
+        assert_bit_equal(st[b], est, f"foveated batch, {force}, pair {b}, offset {offs[b]}")
+
+
+def test_batches_on_several_slots_in_flight(lib, orc):
+    """Two slots, each holding a batch of three pairs, in flight together, twice over (the slots' buffers are reused)."""
+    W, H, lv, B = 420, 300, 10, 3
+    pairs = _pairs(W, H, 2 * B, 3100)
+    exp = [orc.match_full(L, R, lv) for L, R in pairs]
+    with lib.Context(levels=lv, slots=2, batch=B) as c:
+        dL = [c.to_device(L) for L, _ in pairs]
+        dR = [c.to_device(R) for _, R in pairs]
+        dO = [c.alloc(3 * W * H * 4) for _ in range(2 * B)]
+        for rep in range(2):
+            for s in range(2):
+                sel = slice(s * B, (s + 1) * B) if rep == 0 else slice((1 - s) * B, (2 - s) * B)
+                c.submit_full_batch(s, dL[sel], dR[sel], W, H, 3 * W, dO[sel])
+            c.check(c.lib.ugsm_wait_all(c.handle))
+            for b in range(2 * B):
+                assert_bit_equal(c.to_host(dO[b], (3, H, W)), exp[b], f"two batches in flight, round {rep}, pair {b}")
+        for p in dL + dR + dO:
+            c.free(p)
+
+
+def test_batch_on_contexts_that_run_it_pair_by_pair(lib, orc):
+    """Early exit, the LR check and kernel_path 1 need a host round trip per iteration / a second match / kernels without a batch
+    index: such contexts take a batch pair by pair -- same entry point, the results of the equivalent single calls."""
+    W, H, lv, B = 320, 240, 8, 3
+    pairs = _pairs(W, H, B, 3700)
+    exp = [orc.match_full(L, R, lv) for L, R in pairs]
+    with lib.Context(levels=lv, kernel_path=1, batch=B) as c:      # (libugsm_dev.so)
+        got = _full_batch(c, pairs, W, H)
+    for b in range(B):
+        assert_bit_equal(got[b], exp[b], f"kernel_path 1, batch of {B}, pair {b}")
+    with lib.Context(levels=lv, lr_check_threshold=1.0, batch=B) as c:
+        got = _full_batch(c, pairs, W, H)
+        single = []
+        for (L, R) in pairs:
+            out = np.empty((3, H, W), np.float32)
+            c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+            single.append(out)
+    for b in range(B):
+        assert_bit_equal(got[b], single[b], f"LR check, batch of {B}, pair {b} vs the single call")
+        assert_bit_equal(got[b][:2], exp[b][:2], "the LR check leaves dx, dy alone")
+    with lib.Context(levels=lv, early_exit_threshold=0.02, batch=B) as c:
+        got = _full_batch(c, pairs, W, H)
+        out = np.empty((3, H, W), np.float32)
+        L, R = pairs[1]
+        c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, 3 * W, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+    assert_bit_equal(got[1], out, "early exit, batch vs the single call")
+
+
+def test_batch_bad_arguments(lib):
+    import ctypes as C
+    with lib.Context(levels=5, batch=2) as c:
+        p = c.alloc(64 * 48 * 3 * 4)
+        ptrs = (C.c_void_p * 9)(*([p] * 9))
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 0, ptrs, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 9, ptrs, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 2, None, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
+        holes = (C.c_void_p * 2)(p, None)
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 2, ptrs, holes, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 2, ptrs, ptrs, 64, 48, 100, ptrs) == lib.UGSM_ERR_SIZE_MISMATCH
+        assert c.lib.ugsm_submit_foveated_batch(c.handle, 0, 2, ptrs, ptrs, 64, 48, 192, None, None, None, None, None) == lib.UGSM_ERR_BAD_ARG
+        c.free(p)
+    cfg = lib.Config()
+    lib.load().ugsm_default_config(C.byref(cfg))
+    cfg.batch = 9
+    h = C.c_void_p()
+    assert lib.load().ugsm_create(C.byref(cfg), C.byref(h)) == lib.UGSM_ERR_BAD_ARG
+
+
+def test_16mp_batches_vs_single_calls(lib):
+    """BASELINE configs[2] / configs[4] at full size: a batch of two 16 MP pairs in full mode (levels 0-2 pair by pair, 3-13 as one
+    launch for both) and a batch of eight foveated 16 MP pairs with eight different windows, against the single calls on the same context
+    (which tests/test_gpu_parity.py pins to the oracle at this size)."""
+    from ug_stereomatcher_amd import synth
+    W, H, F = 4928, 3264, 7
+    fw, fh = lib.fovea_dims(W, H, 14, F)
+    imgs = [synth.make_pair(W, H, synth.BASE_SEED + 2 + 16 * j)[:2] for j in range(2)]
+    with lib.Context(levels=14, fovea_levels=F, slots=2, batch=8) as c:
+        dL = [c.to_device(L) for L, _ in imgs]
+        dR = [c.to_device(R) for _, R in imgs]
+        dO = [c.alloc(3 * W * H * 4) for _ in range(4)]
+        for j in range(2):
+            c.check(c.lib.ugsm_submit_full(c.handle, j, dL[j], dR[j], W, H, 3 * W, dO[j]))
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        c.submit_full_batch(0, dL, dR, W, H, 3 * W, dO[2:])
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        for j in range(2):
+            assert_bit_equal(c.to_host(dO[2 + j], (3, H, W)), c.to_host(dO[j], (3, H, W)), f"16 MP full, batch of 2, pair {j} vs the single call")
+        for p in dO:
+            c.free(p)
+        offs = [(0, 0), (900, -600), (-1500, 400), (5000, 5000), (-5000, -5000), (123, 456), (-700, -300), (2000, 0)]
+        sel = [j % 2 for j in range(8)]
+        dS = [c.alloc(3 * F * fh * fw * 4) for _ in range(16)]
+        for j in range(8):
+            c.check(c.lib.ugsm_submit_foveated(c.handle, 1, dL[sel[j]], dR[sel[j]], W, H, 3 * W, offs[j][0], offs[j][1], dS[j], None, None))
+            c.check(c.lib.ugsm_wait(c.handle, 1))
+        c.submit_foveated_batch(0, [dL[k] for k in sel], [dR[k] for k in sel], W, H, 3 * W, offs, dS[8:])
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        for j in range(8):
+            assert_bit_equal(c.to_host(dS[8 + j], (3, F, fh, fw)), c.to_host(dS[j], (3, F, fh, fw)), f"16 MP foveated, batch of 8, pair {j} at {offs[j]} vs the single call")
+        for p in dL + dR + dS:
+            c.free(p)

@@ -137,7 +137,7 @@ def test_division_in_range_is_ieee(lib):
     den[5 * q + 2048:5 * q + 4096] = 0.0
     with np.errstate(all="ignore"):
         exp = (num / den).astype(np.float32)
-    with lib.Context(levels=1) as c:
+    with lib.Context(levels=1, dev=True) as c:   # the probe entry points live in libugsm_dev.so (include/ugsm_dev.h)
         pn, pd = c.to_device(num), c.to_device(den)
         pq = c.alloc(4 * n)
         try:

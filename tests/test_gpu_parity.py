@@ -422,52 +422,78 @@ def test_1080p_vs_oracle_bit_exact(lib, orc):
     assert_bit_equal(out, ref, "1080p full vs oracle")
 
 
-def test_16mp_determinism_and_sanity(lib):
-    """configs[2]: 4928x3264 full pyramid: two runs identical, outputs finite, confidence in (0,1],
-    disparity near the synthetic truth (median), checksum of per-level checksums stable across slots."""
+@pytest.fixture(scope="module")
+def oracle_16mp(orc):
+    """The 16 MP synthetic pair of BASELINE configs[2] / configs[3] and the live oracle's answers for it (full pyramid: about 3 s on
+    the GPU box's 16 threads; foveated stack: under a second), shared by the tests below."""
     from ug_stereomatcher_amd import synth
     W, H = 4928, 3264
     L, R, dx, dy = synth.make_pair(W, H, synth.BASE_SEED + 2)
-    c = lib.Context(levels=14, slots=2, kernel_path=PATHS[0])
+    orc.set_num_threads(16)
+    try:
+        full = orc.match_full(L, R, 14)
+        stack, _, _ = orc.match_foveated(L, R, 14, 7)   # (3, F, fovH, fovW)
+    finally:
+        orc.set_num_threads(8)
+    return dict(W=W, H=H, L=L, R=R, dx=dx, dy=dy, full=full, stack=stack)
+
+
+def test_16mp_throughput_policy_vs_oracle_bit_exact(lib, oracle_16mp):
+    """configs[2] / configs[3] on a FOUR-SLOT context -- the configuration bench.py times: several large pairs in
+    flight select the throughput kernel choices (k_cost_march down to 50 k pixels, 112 x 36 K-smooth tiles, region height 32 on the
+    coarse levels; ugsm_plan_level), which a one-slot context never runs.  All four slots in flight at once, every slot's result
+    against the live oracle bit for bit; then the foveated stack, four in flight, on the same context."""
+    g = oracle_16mp
+    W, H, L, R = g["W"], g["H"], g["L"], g["R"]
+    plan = lib.plan_level(W, H, slots=4)
+    assert plan["latency_policy"] == 0 and plan["cost_kernel"] == 1, plan   # what the bench line's context launches at level 0
+    assert lib.plan_level(306, 202, frame=(W, H), slots=4)["cost_kernel"] == 1   # ... and at level 8 (61 812 pixels)
+    c = lib.Context(levels=14, slots=4, kernel_path=0)
     try:
         pL, pR = c.to_device(L), c.to_device(R)
-        o = [c.alloc(3 * W * H * 4) for _ in range(2)]
-        for s in range(2):
+        o = [c.alloc(3 * W * H * 4) for _ in range(4)]
+        for s in range(4):
             _submit_full(c, s, pL, pR, W, H, L.strides[0], o[s])
         c.check(c.lib.ugsm_wait_all(c.handle))
-        a = c.to_host(o[0], (3, H, W))
-        b = c.to_host(o[1], (3, H, W))
-        assert_bit_equal(a, b, "16 MP: slot 0 vs slot 1")
+        for s in range(4):
+            a = c.to_host(o[s], (3, H, W))
+            assert_bit_equal(a, g["full"], f"16 MP full pyramid, four slots in flight, slot {s} vs oracle")
         assert np.isfinite(a).all() and a[2].min() > 0 and a[2].max() <= 1
         m = 64
-        assert np.median(np.abs(a[0] - dx)[m:-m, m:-m]) < 0.5
-        assert np.median(np.abs(a[1] - dy)[m:-m, m:-m]) < 0.5
+        assert np.median(np.abs(a[0] - g["dx"])[m:-m, m:-m]) < 0.5
+        assert np.median(np.abs(a[1] - g["dy"])[m:-m, m:-m]) < 0.5
+        rmse = float(np.sqrt(np.mean((a[:2].astype(np.float64) - g["full"][:2].astype(np.float64)) ** 2)))
+        assert rmse == 0.0
+        del a
+        fw, fh = lib.fovea_dims(W, H, 14, 7)
+        for s in range(4):
+            c.check(c.lib.ugsm_submit_foveated(c.handle, s, pL, pR, W, H, L.strides[0], 0, 0, o[s], None, None))
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        for s in range(4):
+            assert_bit_equal(c.to_host(o[s], (3, 7, fh, fw)), g["stack"], f"16 MP foveated stack, four slots in flight, slot {s} vs oracle")
         for p in [pL, pR] + o:
             c.free(p)
     finally:
         c.close()
 
 
-def test_16mp_full_and_foveated_vs_oracle_bit_exact(lib, orc):
-    """BASELINE configs[2] and configs[3] at their full size against the live oracle (about 3 s of CPU on the GPU
-    box's 16 threads for the full pyramid): every one of the 3 x 16.1 M output floats identical, RMSE 0."""
-    from ug_stereomatcher_amd import MatchGPULib, synth
-    W, H = 4928, 3264
-    L, R, *_ = synth.make_pair(W, H, synth.BASE_SEED + 2)
-    orc.set_num_threads(16)
+def test_16mp_full_and_foveated_vs_oracle_bit_exact(lib, oracle_16mp):
+    """BASELINE configs[2] and configs[3] at their full size against the live oracle through the reference's class surface (a one-slot
+    context: the latency kernel choices): every one of the 3 x 16.1 M output floats identical, RMSE 0."""
+    from ug_stereomatcher_amd import MatchGPULib
+    g = oracle_16mp
+    L, R = g["L"], g["R"]
     m = MatchGPULib()
     try:
         got = m.match(L, R, 0)
-        exp = orc.match_full(L, R, 14)
+        exp = g["full"]
         assert_bit_equal(got, exp, "16 MP full pyramid vs oracle")
         rmse = float(np.sqrt(np.mean((got[:2].astype(np.float64) - exp[:2].astype(np.float64)) ** 2)))
         assert rmse == 0.0     # north_star's tolerance is RMSE < 1e-3 px; the float contract makes it exactly 0
         stk = m.matchStack(L, R)
-        est, _, _ = orc.match_foveated(L, R, 14, 7)
-        assert_bit_equal(np.transpose(stk, (1, 0, 2, 3)), est, "16 MP foveated stack vs oracle")
+        assert_bit_equal(np.transpose(stk, (1, 0, 2, 3)), g["stack"], "16 MP foveated stack vs oracle")
     finally:
         m.close()
-        orc.set_num_threads(8)
 
 
 def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
@@ -529,7 +555,7 @@ def test_exact_shortcuts_of_the_fused_kernels(lib, orc):
         ref_k = np.where(neg, kk, np.float32(0.4)).astype(np.float32)
     assert_bit_equal(ref_d[:4096], exp_d[:4096], "numpy restatement vs oracle (delta)")
     assert_bit_equal(ref_k[:4096], exp_k[:4096], "numpy restatement vs oracle (corr)")
-    ctx = lib.Context(levels=3)
+    ctx = lib.Context(levels=3, dev=True)   # the probe entry points live in libugsm_dev.so (include/ugsm_dev.h)
     try:
         ptrs = [ctx.to_device(a) for a in (c, l, r, thr)]
         outs = [ctx.alloc(4 * n) for _ in range(3)]
@@ -587,7 +613,7 @@ def test_smooth_division_shared_reciprocal_is_ieee(lib):
     a[2][3 * q:3 * q + 3 * k] = np.nan
     with np.errstate(all="ignore"):
         exp = [(x / s).astype(np.float32) for x in a]
-    ctx = lib.Context(levels=3)
+    ctx = lib.Context(levels=3, dev=True)   # the probe entry points live in libugsm_dev.so (include/ugsm_dev.h)
     try:
         ptrs = [ctx.to_device(x) for x in (*a, s)]
         outs = [ctx.alloc(4 * n) for _ in range(3)]

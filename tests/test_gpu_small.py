@@ -207,7 +207,7 @@ def test_iter_small_whole_matcher(lib, orc, monkeypatch, slots):
         L = L.copy()
         L[40:70, 60:100] = 0  # 0/0 -> NaN correlation on the coarse levels too
         exp = orc.match_full(L, R, lv)
-        with lib.Context(levels=lv, fovea_levels=5, slots=slots) as c:
+        with lib.Context(levels=lv, fovea_levels=5, slots=slots, dev=True) as c:   # k_iter_small lives in libugsm_dev.so
             out = np.empty((3, H, W), np.float32)
             c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], out[0].ctypes.data, out[1].ctypes.data,
                                           out[2].ctypes.data))

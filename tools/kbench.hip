@@ -3,6 +3,7 @@
 //   ./kbench [W H reps]
 // Times k_cost_fused and k_smooth_fused on one level-sized random problem with HIP events.
 #define UGSM_DEV_KERNELS 1  // the development forms of the marching kernels (two pixels per lane, FMA contract): not in libugsm.so
+#define UGSM_DEV_LIB 1      // ... and what libugsm_dev.so has over libugsm.so: kernel_path 1, k_smooth_march, k_iter_small, the probes
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_ref.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_fused.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march.hip"
@@ -291,7 +292,7 @@ int main(int argc, char **argv)
         float *l1 = R, *l2 = A;
         for (int round = 0; round < 3; round++) {
             timeit("k_pyr_base", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb); });
-#define PYRV(ABL) timeit("k_pyr_base<" #ABL ">", [&]() { hipLaunchKernelGGL(k_pyr_base<ABL>, dim3(((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY)), dim3(256), 0, st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb, (W + BTX - 1) / BTX, ((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY)); })
+#define PYRV(ABL) timeit("k_pyr_base<" #ABL ">", [&]() { hipLaunchKernelGGL(k_pyr_base<ABL>, dim3(((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY)), dim3(256), 0, st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb, (W + BTX - 1) / BTX, ((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY), Batch{1}); })
             PYRV(1); PYRV(2); PYRV(6); PYRV(8); PYRV(9); PYRV(14); PYRV(15);
             timeit("k_pyr_base level 0 only", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, 0, 0, l2, 0, 0, rb); });
             timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f, nullptr); });
@@ -497,7 +498,7 @@ int main(int argc, char **argv)
             const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 16 + UGSM_SMOOTH_PAD(stx)) * sizeof(float);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             const int stxn = (W + stx - 1) / stx, stn = stxn * ((H + sty - 1) / sty);
-            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn, sty); });
+            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn, sty, Batch{1}); });
         };
         for (int round = 0; round < 2; round++) {
             run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5+box");

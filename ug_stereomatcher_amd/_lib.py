@@ -2,6 +2,10 @@
 
 There is no CPU fallback: if the HIP library is missing or no device is present every
 compute call raises (UgsmError).  The pure-host geometry calls work without a GPU.
+
+libugsm_dev.so (include/ugsm_dev.h) is the same sources built with the development kernels: kernel_path 1 (one kernel per reference
+stage), march_smooth, the UGSM_ITER_SMALL switch and the probe entry points.  Tests and tools reach it through load(dev=True) /
+Context(dev=True); a Context that asks for kernel_path 1 or march_smooth gets it by itself.
 """
 from __future__ import annotations
 
@@ -12,6 +16,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libugsm.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libugsm_dev.so")
+UGSM_MAX_BATCH = 8
 
 UGSM_OK = 0
 UGSM_ERR_BAD_ARG = 1
@@ -25,15 +31,18 @@ UGSM_MAX_LEVELS = 32
 
 # every symbol include/ugsm.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "ugsm_default_config", "ugsm_abi_version", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
+    "ugsm_default_config", "ugsm_abi_version", "ugsm_is_dev_library", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
     "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full", "ugsm_submit_full_host", "ugsm_submit_foveated_host",
-    "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_wait", "ugsm_wait_all",
+    "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_submit_full_batch", "ugsm_submit_foveated_batch",
+    "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
-    "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
+    "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
     "ugsm_stage_lr_check", "ugsm_last_lr_marked", "ugsm_slot_stream",
     "ugsm_reset_kernel_stats", "ugsm_set_profile_events", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
 ]
+# ... and what include/ugsm_dev.h adds (libugsm_dev.so only)
+DEV_EXPORTS = ["ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe"]
 
 
 class UgsmError(RuntimeError):
@@ -46,7 +55,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("levels", C.c_int), ("fovea_levels", C.c_int), ("slots", C.c_int),
                 ("kernel_path", C.c_int), ("profile_events", C.c_int), ("march_min_pixels", C.c_int), ("march_np", C.c_int),
                 ("march_rows", C.c_int), ("march_smooth", C.c_int), ("early_exit_threshold", C.c_float), ("small_max_pixels", C.c_int),
-                ("lr_check_threshold", C.c_float), ("streams", C.c_int)]
+                ("lr_check_threshold", C.c_float), ("streams", C.c_int), ("batch", C.c_int), ("stream_priority", C.c_int)]
 
 
 class LevelPlan(C.Structure):
@@ -59,22 +68,23 @@ class KernelStat(C.Structure):
                 ("total_ms", C.c_double), ("pixel_launches", C.c_double)]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Loads libugsm.so; raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise UgsmError(UGSM_ERR_NO_DEVICE, f"{LIB_PATH} not built: run `make -C ug_stereomatcher_amd/csrc`")
-    lib = C.CDLL(LIB_PATH)
+def load(dev: bool = False):
+    """Loads libugsm.so (dev: libugsm_dev.so); raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    if dev in _libs:
+        return _libs[dev]
+    path = DEV_LIB_PATH if dev else LIB_PATH
+    if not os.path.exists(path):
+        raise UgsmError(UGSM_ERR_NO_DEVICE, f"{path} not built: run `make -C ug_stereomatcher_amd/csrc`")
+    lib = C.CDLL(path)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     i = C.c_int
     lib.ugsm_default_config.argtypes = [C.POINTER(Config)]
     lib.ugsm_default_config.restype = None
     lib.ugsm_abi_version.restype = i
+    lib.ugsm_is_dev_library.restype = i
     lib.ugsm_status_string.argtypes = [i]
     lib.ugsm_status_string.restype = C.c_char_p
     lib.ugsm_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
@@ -98,6 +108,9 @@ def load():
     lib.ugsm_match_foveated_full.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp]
     lib.ugsm_submit_full.argtypes = [vp, i, vp, vp, i, i, i, vp]
     lib.ugsm_submit_foveated.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, vp, vp]
+    pp = C.POINTER(vp)
+    lib.ugsm_submit_full_batch.argtypes = [vp, i, i, pp, pp, i, i, i, pp]
+    lib.ugsm_submit_foveated_batch.argtypes = [vp, i, i, pp, pp, i, i, i, ip, ip, pp, pp, pp]
     lib.ugsm_wait.argtypes = [vp, i]
     lib.ugsm_wait_all.argtypes = [vp]
     lib.ugsm_submit_pyramids.argtypes = [vp, i, vp, vp, i, i, i]
@@ -111,9 +124,10 @@ def load():
     lib.ugsm_stage_iterate.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     lib.ugsm_stage_seed.argtypes = [vp, vp, i, i, vp, i, i, i, i, i, i]
     lib.ugsm_stage_smooth.argtypes = [vp, vp, i, i, i, i]
-    lib.ugsm_stage_poly_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
-    lib.ugsm_stage_div3_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
-    lib.ugsm_stage_div_probe.argtypes = [vp, vp, vp, vp, i]
+    if dev:
+        lib.ugsm_stage_poly_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
+        lib.ugsm_stage_div3_probe.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i]
+        lib.ugsm_stage_div_probe.argtypes = [vp, vp, vp, vp, i]
     lib.ugsm_stage_weighted_difference.argtypes = [vp, vp, vp, i, i, C.POINTER(C.c_float)]
     lib.ugsm_last_iterations.argtypes = [vp, i, C.POINTER(i)]
     lib.ugsm_stage_lr_check.argtypes = [vp, vp, vp, i, i, C.c_float, C.POINTER(C.c_longlong)]
@@ -129,7 +143,9 @@ def load():
     lib.ugsm_host_free.argtypes = [vp, vp]
     lib.ugsm_copy_to_device.argtypes = [vp, vp, vp, C.c_longlong]
     lib.ugsm_copy_to_host.argtypes = [vp, vp, vp, C.c_longlong]
-    _lib = lib
+    if bool(lib.ugsm_is_dev_library()) != bool(dev):
+        raise UgsmError(UGSM_ERR_STATE, f"{path} is not the {'development' if dev else 'product'} build")
+    _libs[dev] = lib
     return lib
 
 
@@ -184,8 +200,10 @@ class Context:
     def __init__(self, device: int = 0, levels: int = 14, fovea_levels: int = 7, slots: int = 1,
                  kernel_path: int = 0, profile_events: int = 0, march_min_pixels: int = 0, march_np: int = 0,
                  march_rows: int = 0, march_smooth: int = 0, early_exit_threshold: float = 0.0, small_max_pixels: int = 0,
-                 lr_check_threshold: float = 0.0, streams: int = 0):
-        lib = load()
+                 lr_check_threshold: float = 0.0, streams: int = 0, batch: int = 0, stream_priority: int = 0, dev: bool | None = None):
+        # libugsm_dev.so when asked for, or when the configuration needs a kernel only it has
+        self.dev = bool(dev) if dev is not None else (kernel_path == 1 or march_smooth == 1)
+        lib = load(self.dev)
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))
         # full-mode users never name fovea_levels; keep the default legal for short pyramids
@@ -197,6 +215,7 @@ class Context:
         cfg.small_max_pixels = int(small_max_pixels)
         cfg.lr_check_threshold = float(lr_check_threshold)
         cfg.streams = int(streams)
+        cfg.batch, cfg.stream_priority = int(batch), int(stream_priority)
         self.cfg = cfg
         self._pinned = []
         self._h = C.c_void_p()
@@ -287,6 +306,23 @@ class Context:
         self.check(self.lib.ugsm_reconstruct_full(self._h, slot, d_stackH, d_stackV, d_stackC, W, H, off_x, off_y, d_out3))
         self.check(self.lib.ugsm_wait(self._h, slot))
 
+    # ---- B pairs per call (ugsm_submit_*_batch): lists of device pointers ---------------------------------------------
+    @staticmethod
+    def _ptrs(ps):
+        return (C.c_void_p * len(ps))(*[int(p) if p is not None else None for p in ps])
+
+    def submit_full_batch(self, slot: int, d_rgbL, d_rgbR, W: int, H: int, stride: int, d_out):
+        n = len(d_rgbL)
+        self.check(self.lib.ugsm_submit_full_batch(self._h, slot, n, self._ptrs(d_rgbL), self._ptrs(d_rgbR), W, H, stride, self._ptrs(d_out)))
+
+    def submit_foveated_batch(self, slot: int, d_rgbL, d_rgbR, W: int, H: int, stride: int, offsets, d_stack, d_pyrL=None, d_pyrR=None):
+        n = len(d_rgbL)
+        ox = (C.c_int * n)(*[int(o[0]) for o in offsets]) if offsets is not None else None
+        oy = (C.c_int * n)(*[int(o[1]) for o in offsets]) if offsets is not None else None
+        self.check(self.lib.ugsm_submit_foveated_batch(self._h, slot, n, self._ptrs(d_rgbL), self._ptrs(d_rgbR), W, H, stride, ox, oy, self._ptrs(d_stack),
+                                                       self._ptrs(d_pyrL) if d_pyrL is not None else None,
+                                                       self._ptrs(d_pyrR) if d_pyrR is not None else None))
+
     def kernel_stats(self):
         """One dict per (kernel, pyramid level) with harvested launches; level -1 = not tied to a level."""
         cap = 512
@@ -305,7 +341,7 @@ class Context:
 def plan_level(W: int, H: int, frame=None, **cfg_fields):
     """Which kernels a W x H level runs (host only): dict of ugsm_level_plan; cfg_fields override the default ugsm_config.
     frame = (w, h) of what the call matches at its finest level (default: the level itself)."""
-    lib = load()
+    lib = load(bool(cfg_fields.get("kernel_path") == 1 or cfg_fields.get("march_smooth") == 1 or cfg_fields.pop("dev", False)))
     cfg = Config()
     lib.ugsm_default_config(C.byref(cfg))
     for k, v in cfg_fields.items():

@@ -23,6 +23,13 @@ namespace ugsm {
 // MatchLib_common.h:15
 #define UGSM_SCALE 1.41421356
 
+// Batched launches (Batch, ugsm_launch.hpp): a pointer of the launch (pair 0's) moved to this workgroup's pair
+template <class T>
+__device__ __forceinline__ T *shifted(T *p, long long bytes)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<unsigned long long>(p) + (unsigned long long)bytes);
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // Default-configured texture reference (MatchLib.cu:56-60): point filter, clamp,

@@ -698,8 +698,12 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 // same kernel with the height in a register (208 against 212.5 us); the launcher picks it whenever the height is STY.
 template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false>
 __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
-                                                  int tiles_x, int n_tiles, int sty_arg)
+                                                  int tiles_x, int n_tiles, int sty_arg, Batch bt)
 {
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        s3 = shifted(s3, bt.in[blockIdx.y]);
+        o3 = shifted(o3, bt.out[blockIdx.y]);
+    }
     const int sty = FIXH ? STY : sty_arg;
     constexpr int HX = 8, HY = 7;
     constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
@@ -1172,6 +1176,7 @@ void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, floa
                        org_x, org_y);
 }
 
+#ifdef UGSM_DEV_LIB  // the probe kernels: in libugsm_dev.so only
 // test hook (tests only): poly_fast on arbitrary operands, so that its rarely taken f64 fallback and the
 // special values are exercised against the oracle's literal PolyDisparity
 __global__ void k_poly_probe(const float *__restrict__ c, const float *__restrict__ l, const float *__restrict__ r, const float *__restrict__ thr,
@@ -1211,6 +1216,7 @@ void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const f
 {
     hipLaunchKernelGGL(k_div3_probe, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, a2, s, q0, q1, q2, n);
 }
+#endif  // UGSM_DEV_LIB
 
 // ---- launchers ------------------------------------------------------------------------------
 
@@ -1229,8 +1235,12 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 #define UGSM_SMOOTH_SMALL_NT 512
 #endif
 template <int STX, int STY, int NT>
-static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int sty = 0)
+static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int sty, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    const int pairs = B.n > 1 ? B.n : 1;
     constexpr int LW = STX + 16 + UGSM_SMOOTH_PAD(STX), LH = STY + 14;
     constexpr size_t max_bytes = 3 * (size_t)LH * LW * sizeof(float);
     // the attribute is per device: a process may hold contexts on several devices (the launch is made with the context's
@@ -1247,8 +1257,8 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     if (sty < 1 || sty > STY) sty = STY;
     const size_t bytes = 3 * (size_t)(sty + 14) * LW * sizeof(float);
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + sty - 1) / sty);
-    if (sty == STY) hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, true>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty);
-    else hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, false>), dim3(n_tiles), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty);
+    if (sty == STY) hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, true>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
+    else hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, false>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
 }
 
 // Tile height of the 112-column K-smooth tile for a W x H level.  The kernel's tile may be any height up to kSmoothTileRowsMax (36); two
@@ -1260,10 +1270,10 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
 //    tiles of 37 rows = one round, 42 us -- but that kernel's unrolled loops cost every 36-row launch 7.7 % more instructions:
 //    212 against 208 us at level 0, so the tallest tile stays 36).  The height that minimises rounds x region rows; among equals the
 //    fewest tiles.  Worth 0.3 % of a 16 MP pair alone on the chip (tools/ab.py).
-int smooth_tile_rows(int W, int H, int latency)
+int smooth_tile_rows(int W, int H, int latency, int pairs)
 {
     constexpr int STX = 112, HMAX = kSmoothTileRowsMax, HDEF = 36, HMIN = 16, SLOTS = 2 * 256;
-    const int tiles_x = (W + STX - 1) / STX;
+    const int tiles_x = ((W + STX - 1) / STX) * (pairs > 1 ? pairs : 1);  // (a batched launch: the tiles of all its pairs share the chip)
     const int rows_min = (H + HMAX - 1) / HMAX;
     if (!latency || (long long)tiles_x * ((H + HDEF - 1) / HDEF) > 3 * SLOTS) return HDEF;
     int best = 0;
@@ -1287,7 +1297,7 @@ int smooth_tile_rows(int W, int H, int latency)
 // foveated stack with four slots +1.5 % (tools/ab.py; 2^19: -0.2 %, 2^16: -0.4 %)
 int smooth_mid_min_pixels = 1 << 18;
 
-void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows)
+void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows, const Batch *bt, int tile_class)
 {
     // big levels: 112 x (up to 36) tiles, 512 threads, <= 77 KB LDS -> two workgroups per CU (meant to let one's load/store phase overlap
     // the other's passes; measured, the two phases still nearly add up: DESIGN.md section 4).  The region is 128 columns = 32 quads = two whole rows per wave: no idle lanes, and the halo
@@ -1295,9 +1305,9 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
     // 64x58, 323 us for the first 64x64 version; 128x64x1024 with one workgroup per CU 406 us);
     // mid levels (from smooth_mid_min_pixels): 64x32; small levels: 32x16 so that the launch is short and the chip still fills
     const size_t px = (size_t)W * H;
-    if (tile_rows > 0 || px >= ((size_t)1 << 19)) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36);
-    else if (px >= (size_t)smooth_mid_min_pixels) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box);
-    else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box);
+    if (tile_rows > 0 || (tile_class == 0 && px >= ((size_t)1 << 19))) launch_smooth_t<112, kSmoothTileRowsMax, 512>(st, s3, o3, W, H, passes, do_box, tile_rows > 0 ? tile_rows : 36, bt);
+    else if (tile_class == 2 || (tile_class == 0 && px >= (size_t)smooth_mid_min_pixels)) launch_smooth_t<64, 32, UGSM_SMOOTH_MID_NT>(st, s3, o3, W, H, passes, do_box, 0, bt);
+    else launch_smooth_t<32, 16, UGSM_SMOOTH_SMALL_NT>(st, s3, o3, W, H, passes, do_box, 0, bt);
 }
 
 // =========================================================================================
@@ -1310,10 +1320,15 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
 constexpr int PTX = 64, PTY = 16, PRW = 2 * PTX + 8, PRH = 2 * PTY + 6;
 
 __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3,
-                                                             int W2, int H2, float sf, unsigned *__restrict__ range_bad, int tiles_x, int n_tiles)
+                                                             int W2, int H2, float sf, unsigned *__restrict__ range_bad, int tiles_x, int n_tiles, Batch bt)
 {
     __shared__ float sS[PRH * PRW];
     __shared__ float sT[PRH * PTX];
+    if (bt.n > 1) {  // this workgroup's image of the batch (blockIdx.y)
+        src3 = shifted(src3, bt.in[blockIdx.y]);
+        dst3 = shifted(dst3, bt.out[blockIdx.y]);
+        if (range_bad) range_bad += bt.cx[blockIdx.y];  // (the pair the image belongs to: the left and the right image of a pair share its range word)
+    }
     const int tid = threadIdx.x;
     int tile_x, tile_y;
     xcd_tile(n_tiles, tiles_x, tile_x, tile_y);  // (grid: n_tiles x 1 x 3 planes; the plane only rotates the XCD labels)
@@ -1373,8 +1388,12 @@ __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__rest
 
 // A = colconv_clamp(rowconv_clamp(L^2)) (Square + convolutionRows/ColumnsKernelT, MatchLib.cu:556-578,
 // 1461-1565), once per level: it does not depend on the iteration.  64x16 tile, region +2 clamped.
-__global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3, int tiles_x, int n_tiles)
+__global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3, int tiles_x, int n_tiles, Batch bt)
 {
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        src.p = shifted(src.p, bt.img[blockIdx.y]);
+        dst3 = shifted(dst3, bt.out[blockIdx.y]);
+    }
     // One workgroup = the 64x16 tile of all three planes: a workgroup of this kernel lives about as long as its global loads
     // take to arrive, so the three planes' loads are in flight together (a third of the workgroups, each with three times the
     // loads outstanding).  Both passes work on quads (4 consecutive x) through 16-byte LDS accesses.  Squares are >= +0 (or NaN):
@@ -1463,8 +1482,16 @@ constexpr int BTX = 64, BTY = 16, BRW = BTX + 8, BRH = BTY + 4, BC1 = 52, BR1 = 
 template <int ABL = 0>
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
                                                   float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
-                                                  unsigned *__restrict__ range_bad, int tiles_x, int n_tiles)
+                                                  unsigned *__restrict__ range_bad, int tiles_x, int n_tiles, Batch bt)
 {
+    if (bt.n > 1) {  // this workgroup's image of the batch (blockIdx.y): its rgb8 input, its three levels (one offset: they lie in one pyramid)
+        const int b = (int)blockIdx.y;
+        rgb = shifted(rgb, bt.img[b]);
+        lvl0 = shifted(lvl0, bt.out[b]);
+        lvl1 = shifted(lvl1, bt.out[b]);
+        lvl2 = shifted(lvl2, bt.out[b]);
+        if (range_bad) range_bad += bt.cx[b];  // (the pair the image belongs to)
+    }
     __shared__ __attribute__((aligned(16))) float sS[3][BRH * BRW];  // tile + halo 2: region column c at [c], rows 16-byte aligned
     __shared__ __attribute__((aligned(16))) float sT[3][BRH * BTX];  // row pass of every tile column, every region row
     __shared__ int sRowSite[BR1 + BR2];  // region row of the sampling site of candidate row ly (level 1, then level 2), -1 = not in this tile
@@ -1587,27 +1614,44 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 }
 
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
-                     int H2, unsigned *range_bad)
+                     int H2, unsigned *range_bad, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
     const int tiles_x = (W + BTX - 1) / BTX, n_tiles = tiles_x * ((H + BTY - 1) / BTY);
-    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles);
+    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B);
 }
 
-void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad)
+// bt (optional): bt->n IMAGES in one launch -- image j reads src3 + in[j], writes dst3 + out[j] and reports into range_bad[cx[j]]
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    const int images = B.n > 1 ? B.n : 1;
+#ifdef UGSM_DEV_LIB  // (the product's pyramid only ever asks for sqrt 2 and 2; the one-kernel-per-stage fallback lives in libugsm_dev.so)
     if (sf > 2.0f || sf < 1.0f) {  // region bound assumes 1 <= sf <= 2 (the reference uses sqrt2 and 2)
-        launch_blur_decimate_ref(st, src3, W, H, dst3, W2, H2, sf);
-        if (range_bad) launch_range_scan(st, dst3, 3 * (size_t)W2 * H2, range_bad);
+        for (int j = 0; j < images; j++) {
+            const float *src = images > 1 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(src3) + B.in[j]) : src3;
+            float *dst = images > 1 ? reinterpret_cast<float *>(reinterpret_cast<char *>(dst3) + B.out[j]) : dst3;
+            launch_blur_decimate_ref(st, src, W, H, dst, W2, H2, sf);
+            if (range_bad) launch_range_scan(st, dst, 3 * (size_t)W2 * H2, range_bad + (images > 1 ? B.cx[j] : 0));
+        }
         return;
     }
+#endif
     const int tiles_x = (W2 + PTX - 1) / PTX, n_tiles = tiles_x * ((H2 + PTY - 1) / PTY);
-    hipLaunchKernelGGL(k_blur_decimate_tiled, dim3(n_tiles, 1, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles);
+    hipLaunchKernelGGL(k_blur_decimate_tiled, dim3(n_tiles, images, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles, B);
 }
 
-void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3)
+void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
     const int tiles_x = (W + PTX - 1) / PTX, n_tiles = tiles_x * ((H + PTY - 1) / PTY);
-    hipLaunchKernelGGL(k_sqblur_tiled, dim3(n_tiles), dim3(256), 0, st, src, W, H, dst3, tiles_x, n_tiles);
+    hipLaunchKernelGGL(k_sqblur_tiled, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, src, W, H, dst3, tiles_x, n_tiles, B);
 }
 
 }  // namespace ugsm

@@ -464,8 +464,20 @@ __device__ long long *g_march_stamps = nullptr;  // per wave: delta s_memtime, d
 template <int NP, bool FMAD>
 __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
-                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm, StripClasses sc)
+                                                                      int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm, StripClasses sc,
+                                                                      Batch bt)
 {
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        const int b = (int)blockIdx.y;
+        L.p = shifted(L.p, bt.img[b]);
+        R.p = shifted(R.p, bt.img[b]);
+        A3 = shifted(A3, bt.in[b]);
+        d3 = shifted(d3, bt.in[b]);
+        nd3 = shifted(nd3, bt.out[b]);
+        if (range_bad) range_bad += b;
+        sm.cx = bt.cx[b];
+        sm.cy = bt.cy[b];
+    }
 #ifdef UGSM_MARCH_STAMP  // diagnostic build only (tools/kbench_stamp): in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
     const long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -524,13 +536,13 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 // matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
 // `throughput` (several pairs in flight: other pairs' kernels share the SIMDs whatever this launch does): the tallest strips that
 // are still all resident -- the fewest halo rows.
-int march_strip_rows(int W, int H, int np, int throughput)
+int march_strip_rows(int W, int H, int np, int throughput, int pairs)
 {
 #ifndef UGSM_DEV_KERNELS
     np = 1;
 #endif
     const int vx = np == 2 ? March<2>::VX : March<1>::VX, org = np == 2 ? March<2>::ORG : March<1>::ORG;
-    const int strips_x = (W - org + vx - 1) / vx;
+    const int strips_x = ((W - org + vx - 1) / vx) * (pairs > 1 ? pairs : 1);  // (a batched launch: the strips of all its pairs share the chip)
     static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
     const int max_w = np == 2 ? MARCH_WAVES(2) : MARCH_WAVES(1);
     float best = 0.0f;
@@ -558,14 +570,18 @@ int march_strip_rows(int W, int H, int np, int throughput)
 int march_age_permille[2] = {470, 340};
 template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
-                                int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0})
+                                int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0}, const Batch *bt = nullptr)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    const int pairs = B.n > 1 ? B.n : 1;
     const int VX = March<NP>::VX;
     const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
     // rows: > 0 a fixed strip height; 0 the latency heights and strips by age class; -1 the latency heights, no age classes; -2 the
     // throughput heights, no age classes; -3 the throughput heights and age classes
-    const bool age = rows == 0 || rows == -3, tput = rows == -2 || rows == -3;
-    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP, tput);
+    const bool age = (rows == 0 || rows == -3) && pairs == 1, tput = rows == -2 || rows == -3;  // (age classes count on blockIdx.x being the dispatch order)
+    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP, tput, pairs);
     int strips_y = (H + Hs - 1) / Hs;
     int n_strips = strips_x * strips_y;
     int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
@@ -588,36 +604,37 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     }
 #ifdef UGSM_DEV_KERNELS
     if (fmad) {
-        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc);
+        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
         return;
     }
 #endif
     (void)fmad;
-    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc);
+    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
 }
 
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
-                              int blend, int rows, const unsigned *range_bad)
+                              int blend, int rows, const unsigned *range_bad, const Batch *bt)
 {
-    launch_cost_march_t<1>(st, L, R, A3, coarse3, nd3, W, H, thr, blend, 0, rows, range_bad, sm);
+    launch_cost_march_t<1>(st, L, R, A3, coarse3, nd3, W, H, thr, blend, 0, rows, range_bad, sm, bt);
 }
 
 void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
-                       int np, int rows, const unsigned *range_bad)
+                       int np, int rows, const unsigned *range_bad, const Batch *bt)
 {
     // The product library holds the one-pixel-per-lane, literal-contract kernel only.  The two development forms -- two pixels per
     // lane (spills at any occupancy that pays) and FMA-contracted convolutions (no parity claim; slower) -- are instantiated by
     // tools/kbench.hip, which defines UGSM_DEV_KERNELS; here `np` and `fmad` are ignored.
 #ifdef UGSM_DEV_KERNELS
     if (np == 2) {
-        launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+        launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad, SeedMap{0, 0, 0, 0}, bt);
         return;
     }
 #endif
     (void)np;
-    launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad);
+    launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad, SeedMap{0, 0, 0, 0}, bt);
 }
 
+#ifdef UGSM_DEV_LIB  // k_smooth_march: built, bit-exact, measured slower than the LDS-tiled K-smooth -- in libugsm_dev.so only
 // =========================================================================================
 // K-smooth for the large levels, marching form: PASSES confidence-weighted Jacobi passes (smoothKernel,
 // MatchLib.cu:1092-1145; MatchGPULib.cpp:2262-2292) and the 3x3 box (convolutionRows/ColumnsKernelTa, MatchLib.cu:1593-1697;
@@ -941,6 +958,8 @@ void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int 
     }
 }
 
+#endif  // UGSM_DEV_LIB
+
 // range_bad[0] = 1 if any of the `count` floats at p is outside range_ok (ugsm_exact.hpp); the caller zeroes the word first.
 // The pyramid kernels make this check as they write a level; this pass serves the stage-level test entry points, which
 // receive their planes ready-made.
@@ -1014,6 +1033,7 @@ void launch_weighted_difference(hipStream_t st, const float *newd3, const float 
     hipLaunchKernelGGL(k_wdiff_total, dim3(1), dim3(64), 0, st, rowsum, H, out3);
 }
 
+#ifdef UGSM_DEV_LIB
 // test hook: the range-guarded division on arbitrary operands
 __global__ void k_div_probe(const float *__restrict__ n, const float *__restrict__ d, float *__restrict__ q, int count)
 {
@@ -1024,5 +1044,6 @@ void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, 
 {
     hipLaunchKernelGGL(k_div_probe, dim3((count + 255) / 256), dim3(256), 0, st, n, d, q, count);
 }
+#endif  // UGSM_DEV_LIB
 
 }  // namespace ugsm

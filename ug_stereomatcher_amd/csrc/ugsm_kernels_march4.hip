@@ -279,9 +279,20 @@ __device__ __forceinline__ void epilogue_wave(const float *__restrict__ d3, floa
 // grid: one workgroup of four waves per strip of m4::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
 __global__ __launch_bounds__(256, 4) void k_cost_march4(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3, float *__restrict__ nd3,
                                                        int W, int H, float thr, int blend, int strips_x, int n_strips, int Hs,
-                                                       const unsigned *__restrict__ range_bad, SeedMap sm)
+                                                       const unsigned *__restrict__ range_bad, SeedMap sm, Batch bt)
 {
     __shared__ float q_lds[m4::Q_FLOATS];
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        const int b = (int)blockIdx.y;
+        L.p = shifted(L.p, bt.img[b]);
+        R.p = shifted(R.p, bt.img[b]);
+        A3 = shifted(A3, bt.in[b]);
+        d3 = shifted(d3, bt.in[b]);
+        nd3 = shifted(nd3, bt.out[b]);
+        if (range_bad) range_bad += b;
+        sm.cx = bt.cx[b];
+        sm.cy = bt.cy[b];
+    }
     int sx, sy;
     xcd_tile(n_strips, strips_x, sx, sy);
     const int xs = sx * m4::VX, ys = sy * Hs;
@@ -311,22 +322,26 @@ __global__ __launch_bounds__(256, 4) void k_cost_march4(Img3 L, Img3 R, const fl
 
 // Strip height: every strip resident at once (four workgroups of four waves per CU: one wave of every workgroup per SIMD), the
 // shortest strips that still fit -- a launch lasts (rows + halo + prologue) row steps.
-int march4_strip_rows(int W, int H)
+int march4_strip_rows(int W, int H, int pairs)
 {
-    const int strips_x = (W + m4::VX - 1) / m4::VX;
+    const int strips_x = ((W + m4::VX - 1) / m4::VX) * (pairs > 1 ? pairs : 1);  // (a batched launch: the strips of all its pairs share the chip)
     const int per_col = (4 * 256) / strips_x > 0 ? (4 * 256) / strips_x : 1;
     int h = (H + per_col - 1) / per_col;
     return h < 6 ? 6 : h;
 }
 
 void launch_cost_march4(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int rows,
-                        const unsigned *range_bad, SeedMap sm)
+                        const unsigned *range_bad, SeedMap sm, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    const int pairs = B.n > 1 ? B.n : 1;
     const int strips_x = (W + m4::VX - 1) / m4::VX;
-    const int Hs = rows > 0 ? rows : march4_strip_rows(W, H);
+    const int Hs = rows > 0 ? rows : march4_strip_rows(W, H, pairs);
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    hipLaunchKernelGGL(k_cost_march4, dim3(n_strips), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm);
+    hipLaunchKernelGGL(k_cost_march4, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
 }
 
 }  // namespace ugsm

@@ -333,9 +333,18 @@ __device__ __forceinline__ void cost_small_body(const Img3 &L, const Img3 &R, co
 
 template <int TXS, int TYS>
 __global__ __launch_bounds__((CostSmall<TXS, TYS>::NT), 4) void k_cost_small(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
-                                                                        float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles)
+                                                                        float *__restrict__ nd3, int W, int H, float thr, int blend, int tiles_x, int n_tiles,
+                                                                        Batch bt)
 {
     extern __shared__ __attribute__((aligned(16))) float smem_cs[];
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        const int b = (int)blockIdx.y;
+        L.p = shifted(L.p, bt.img[b]);
+        R.p = shifted(R.p, bt.img[b]);
+        A3 = shifted(A3, bt.in[b]);
+        d3 = shifted(d3, bt.in[b]);
+        nd3 = shifted(nd3, bt.out[b]);
+    }
     int tile_x, tile_y;
     xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
     const int x0 = tile_x * TXS, y0 = tile_y * TYS;
@@ -345,20 +354,24 @@ __global__ __launch_bounds__((CostSmall<TXS, TYS>::NT), 4) void k_cost_small(Img
 }
 
 template <int TXS, int TYS>
-static void launch_cost_small_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend)
+static void launch_cost_small_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, const Batch *bt)
 {
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
     using G = CostSmall<TXS, TYS>;
     const int tiles_x = (W + TXS - 1) / TXS, n_tiles = tiles_x * ((H + TYS - 1) / TYS);
     constexpr size_t bytes = 3 * (size_t)G::CH_FLOATS * sizeof(float);
     static_assert(bytes <= 64 * 1024, "stays under the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_cost_small<TXS, TYS>), dim3(n_tiles), dim3(G::NT), bytes, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles);
+    hipLaunchKernelGGL((k_cost_small<TXS, TYS>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(G::NT), bytes, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles, B);
 }
 
-void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend)
+void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, const Batch *bt)
 {
-    launch_cost_small_t<16, 12>(st, L, R, A3, d3, nd3, W, H, thr, blend);
+    launch_cost_small_t<16, 12>(st, L, R, A3, d3, nd3, W, H, thr, blend, bt);
 }
 
+#ifdef UGSM_DEV_LIB  // k_iter_small: built, bit-exact, measured equal per launch and slower in the pipeline -- in libugsm_dev.so only
 // =========================================================================================
 // k_iter_small: the smoothing of iteration m AND the cost step of iteration m+1 in one launch (coarse levels, a call that has the chip to
 // itself).  An iteration of a coarse level is two dependent launches that each last as long as one short tile chain + the launch itself
@@ -546,6 +559,8 @@ void launch_iter_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
     hipLaunchKernelGGL((k_iter_small<TXS, TYS>), dim3(n_tiles), dim3(I::NT), bytes, st, L, R, A3, c3, nd3, W, H, thr, blend, passes, tiles_x, n_tiles);
 }
 
+#endif  // UGSM_DEV_LIB
+
 // =========================================================================================
 // k_smooth_small: P (<= 5) Jacobi passes of smoothKernel (MatchLib.cu:1092-1145) + the 3x3 box (convolutionRows/ColumnsKernelTa,
 // :1593-1697), same arithmetic as k_smooth_fused (ugsm_kernels_fused.hip), one THREAD PER PIXEL of the tile + halo 7 region.
@@ -556,10 +571,14 @@ void launch_iter_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
 // at the last column / row); the box reads its taps at clamped coordinates.
 template <int RH>
 __global__ __launch_bounds__(32 * RH) void k_smooth_small(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
-                                                          int tiles_x, int n_tiles)
+                                                          int tiles_x, int n_tiles, Batch bt)
 {
     constexpr int RW = 32, HALO = 7, STX = RW - 2 * HALO, STY = RH - 2 * HALO, NT = RW * RH;
     __shared__ float buf[2][3][NT];
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        s3 = shifted(s3, bt.in[blockIdx.y]);
+        o3 = shifted(o3, bt.out[blockIdx.y]);
+    }
     const int tid = threadIdx.x;
     const int c = tid & (RW - 1), r = tid >> 5;
     int tile_x, tile_y;
@@ -674,22 +693,25 @@ __global__ __launch_bounds__(32 * RH) void k_smooth_small(const float *__restric
 }
 
 template <int RH>
-static void launch_smooth_small_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box)
+static void launch_smooth_small_t(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, const Batch *bt)
 {
     constexpr int STX = 18, STY = RH - 14;
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + STY - 1) / STY);
-    hipLaunchKernelGGL((k_smooth_small<RH>), dim3(n_tiles), dim3(32 * RH), 0, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles);
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    hipLaunchKernelGGL((k_smooth_small<RH>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(32 * RH), 0, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, B);
 }
 
-void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh)
+void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh, const Batch *bt)
 {
     if (passes < 0 || passes > 5) {  // the halo of 7 covers five passes + the box (callers split longer runs, enqueue_smooth)
-        launch_smooth_fused(st, s3, o3, W, H, passes, do_box);
+        launch_smooth_fused(st, s3, o3, W, H, passes, do_box, 0, bt);
         return;
     }
-    if (rh == 18) launch_smooth_small_t<18>(st, s3, o3, W, H, passes, do_box);
-    else if (rh == 24) launch_smooth_small_t<24>(st, s3, o3, W, H, passes, do_box);
-    else launch_smooth_small_t<32>(st, s3, o3, W, H, passes, do_box);
+    if (rh == 18) launch_smooth_small_t<18>(st, s3, o3, W, H, passes, do_box, bt);
+    else if (rh == 24) launch_smooth_small_t<24>(st, s3, o3, W, H, passes, do_box, bt);
+    else launch_smooth_small_t<32>(st, s3, o3, W, H, passes, do_box, bt);
 }
 
 }  // namespace ugsm

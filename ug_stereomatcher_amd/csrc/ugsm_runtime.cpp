@@ -57,6 +57,10 @@ struct Slot {
     size_t off[UGSM_MAX_LEVELS];  // float offset of level i inside pyrL/pyrR
     float *pyrL = nullptr, *pyrR = nullptr;
     size_t pyr_cap = 0;  // floats
+    // Batch (round 4): the call in flight matches `nb` pairs of one size in lockstep.  Every per-pair buffer of the slot holds nb copies:
+    // pair b's pyramids at pyrL / pyrR + b * pyr_stride, its level buffers (A, d0, d1) at + b * lvl_stride, its range word at range_bad + b.
+    int nb = 1;
+    size_t pyr_stride = 0, lvl_stride = 0;  // floats
     float *A = nullptr, *Rw = nullptr, *B = nullptr, *d0 = nullptr, *d1 = nullptr;
     // Side stream of the slot (round 3): the right image's upload and pyramid, and then A = G_clamp * L^2 of every full-frame level
     // (MatchGPULib.cpp:1866-1875, once per level), run there beside the left pyramid and the coarse levels' iterations -- launches
@@ -191,6 +195,7 @@ struct ugsm_ctx {
     int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
     int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
+    long long batch_max_px = 0;  // development override of kBatchMaxPixels (batch_level): levels up to this size go through a batched call as one launch; < 0 = none
 };
 
 namespace {
@@ -328,11 +333,12 @@ int ensure_level_bufs(ugsm_ctx *ctx, Slot &s, size_t lvl)
     return UGSM_OK;
 }
 
-int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H)
+int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
 {
     const int levels = ctx->cfg.levels;
     int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
     UCHK(level_dims(W, H, levels, w, h));
+    if (nb < 1 || nb > kMaxBatch) return UGSM_ERR_BAD_ARG;
     size_t tot = 0;
     for (int i = 0; i < levels; i++) {
         s.w[i] = w[i];
@@ -343,17 +349,22 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H)
     s.W = W;
     s.H = H;
     s.levels = levels;
+    s.nb = nb;
     for (int i = 0; i < UGSM_MAX_LEVELS; i++) s.iters_run[i] = -1;
     s.have_pyr = false;
     s.have_coarse = false;
     s.a_from = -1;
-    if (tot > s.pyr_cap) {
-        size_t cap = s.pyr_cap;
-        UCHK(grow(ctx, s.pyrL, cap, tot));
-        UCHK(grow(ctx, s.pyrR, s.pyr_cap, tot));
-    }
     const size_t lvl = 3 * (size_t)W * H;
-    UCHK(ensure_level_bufs(ctx, s, lvl));
+    // (pairs of a batch start on 256-byte boundaries: the kernels' 16-byte accesses stay aligned whatever the level sizes add up to)
+    s.pyr_stride = (tot + 63) & ~(size_t)63;
+    s.lvl_stride = (lvl + 63) & ~(size_t)63;
+    const size_t pyr_need = nb > 1 ? s.pyr_stride * nb : tot;
+    if (pyr_need > s.pyr_cap) {
+        size_t cap = s.pyr_cap;
+        UCHK(grow(ctx, s.pyrL, cap, pyr_need));
+        UCHK(grow(ctx, s.pyrR, s.pyr_cap, pyr_need));
+    }
+    UCHK(ensure_level_bufs(ctx, s, nb > 1 ? s.lvl_stride * nb : lvl));
     return UGSM_OK;
 }
 
@@ -368,7 +379,8 @@ struct Timer {
     {
         // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
         // has ~750 launches; bracketing all of them costs slot 0 about 20 %); 2: every kernel class
-        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && (kclass == KC_COST || kclass == KC_COST_MARCH || kclass == KC_COST_SMALL)));
+        const bool cost_class = kclass == KC_COST || kclass == KC_COST_MARCH || kclass == KC_COST_SMALL || kclass == KC_COST_MARCH4 || kclass == KC_ITER_SMALL;
+        on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && cost_class));
         if (!on) return;
         rec.kclass = kclass;
         rec.level = sl->cur_level;
@@ -416,13 +428,13 @@ struct DevKnobs {
     int fuse_seed = 1;       // UGSM_FUSE_SEED=0: seed every level with its own launch
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
-    int graph = -1;          // UGSM_COARSE_GRAPH: 0 / 1 overrides ugsm_config.coarse_graph
     int iter_small = -1;     // UGSM_ITER_SMALL=0 / 1: k_iter_small on the coarse levels (default: off -- measured equal)
     int force_mode = -1;     // UGSM_POLICY=latency|throughput: the kernel choices of every call, whatever the slots and the frame size
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
     char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
     char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
-    int march_mode = 1;      // UGSM_MARCH_MODE=0,-1,-2,-3: launch_cost_march's strip-height / age-class mode (default: by the slots)
+    int march_mode = 0;      // UGSM_MARCH_MODE=0,-1,-2,-3: launch_cost_march's strip-height / age-class mode (default 0: latency heights, strips by age class)
+    long long batch_max_px = 0;  // UGSM_BATCH_MAX_PIXELS: levels up to this many pixels are ONE launch for all pairs of a batched call (default kBatchMaxPixels; < 0: none)
     int smooth_big_min = 0;  // UGSM_SMOOTH_BIG_MIN: pixel count from which K-smooth uses the 112-column tile (default 2^19)
     int smooth_rows = 0;     // UGSM_SMOOTH_ROWS: tile height of the large levels' K-smooth (1..39), -1 / -2 = the latency / throughput rule whatever the slots
     int march4_lo = -1, march4_hi = -1;  // UGSM_MARCH4=lo,hi: pixel range of k_cost_march4 (0,0 = never; default: march4_default_range)
@@ -432,7 +444,9 @@ bool dev_env_on()
     const char *e = getenv("UGSM_DEV");
     return e && e[0] == '1';
 }
-void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
+// set_globals: also apply the two process-wide tuning variables (UGSM_SMOOTH_MID_MIN, UGSM_MARCH_AGE).  ugsm_create does; the host-only
+// ugsm_plan_level does not, so that asking for a plan never changes the kernels of live contexts.
+void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
 {
     if (!dev_env_on()) return;
     auto geti = [](const char *name, int &dst) {
@@ -445,7 +459,6 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     geti("UGSM_SMALL_MAX_PIXELS", cfg.small_max_pixels);
     geti("UGSM_SMALL_MASK", k.small_mask);
     geti("UGSM_FUSE_SEED", k.fuse_seed);
-    geti("UGSM_COARSE_GRAPH", k.graph);
     geti("UGSM_TWO_STREAMS", k.two_streams);
     geti("UGSM_SMOOTH_ROWS", k.smooth_rows);
     geti("UGSM_MARCH_MODE", k.march_mode);
@@ -454,8 +467,9 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
     if (const char *e = getenv("UGSM_POLICY")) k.force_mode = e[0] == 'l' ? 1 : (e[0] == 't' ? 0 : -1);
     geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
     geti("UGSM_ITER_SMALL", k.iter_small);
-    geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);  // (a process-wide tuning variable, like UGSM_MARCH_AGE)
-    if (const char *e = getenv("UGSM_MARCH_AGE")) {
+    if (const char *e = getenv("UGSM_BATCH_MAX_PIXELS")) k.batch_max_px = atoll(e);
+    if (set_globals) geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);  // (a process-wide tuning variable, like UGSM_MARCH_AGE)
+    if (const char *e = set_globals ? getenv("UGSM_MARCH_AGE") : nullptr) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
             march_age_permille[0] = a;
@@ -476,37 +490,79 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k)
 
 // ---- stages ----------------------------------------------------------------------------
 
-int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int stride, float *pyr, hipStream_t stream = nullptr)
+// The pairs of one launch: b0 .. b0 + n - 1 of the batch in the slot (n = 1: an ordinary launch of pair b0).
+struct Grp {
+    int b0, n;
+};
+// f(Grp) for the whole batch in one launch (`batched`) or pair by pair
+template <class F>
+void for_groups(int nb, bool batched, F &&f)
+{
+    if (batched && nb > 1) {
+        f(Grp{0, nb});
+        return;
+    }
+    for (int b = 0; b < nb; b++) f(Grp{b, 1});
+}
+inline long long byte_diff(const void *a, const void *b) { return (long long)(reinterpret_cast<intptr_t>(a) - reinterpret_cast<intptr_t>(b)); }
+// The Batch argument of a group's launch.  Inputs and outputs are the slot's level buffers (pair b at + b * lvl_stride) unless
+// `outs` names per-pair destinations (the callers' buffers); `views`: the L / R views of the pairs (fovea windows sit at different
+// places); `seeds`: their seed-crop origins.  All arrays are indexed by the pair's number in the batch.
+Batch make_batch(const Slot &s, Grp g, const Img3 *views = nullptr, const SeedMap *seeds = nullptr, float *const *outs = nullptr)
+{
+    Batch b{};
+    b.n = g.n;
+    for (int j = 0; j < g.n; j++) {
+        b.in[j] = (long long)(j * s.lvl_stride * sizeof(float));
+        b.out[j] = outs ? byte_diff(outs[g.b0 + j], outs[g.b0]) : b.in[j];
+        b.img[j] = views ? byte_diff(views[g.b0 + j].p, views[g.b0].p) : 0;
+        b.cx[j] = seeds ? seeds[g.b0 + j].cx : 0;
+        b.cy[j] = seeds ? seeds[g.b0 + j].cy : 0;
+    }
+    return b;
+}
+
+// CreatePyramidFromImage (MatchGPULib.cpp:1033-1125) for the left OR the right image of every pair of the call: rgb[b] -> pyr + b * pyr_stride.
+// The images of a batch go through every pyramid kernel together (one launch per level for all of them).
+int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, int stride, float *pyr, hipStream_t stream = nullptr)
 {
     const hipStream_t pst = stream ? stream : s.st;  // (launches on the side stream are not bracketed by events: Timer records on s.st)
-    const int levels = s.levels;
+    const int levels = s.levels, nb = s.nb;
     const bool ref = ctx->cfg.kernel_path == 1;
     // levels 0, 1, 2 in one pass over the rgb8 input (k_pyr_base); the one-stage-per-kernel path keeps the three launches
     const bool base = !ref && levels >= 3;
+    Batch bt{};  // image j of the launch = pair j: its rgb8 input, its pyramid, its range word
+    bt.n = nb;
+    for (int j = 0; j < nb; j++) {
+        bt.img[j] = byte_diff(rgb[j], rgb[0]);
+        bt.in[j] = bt.out[j] = (long long)(j * s.pyr_stride * sizeof(float));
+        bt.cx[j] = j;
+    }
+    const Batch *const pb = nb > 1 ? &bt : nullptr;
     s.cur_level = 0;
     if (base) {
-        Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H);
-        launch_pyr_base(pst, d_rgb, stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad);
+        Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H * nb);
+        launch_pyr_base(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad, pb);
     } else {
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
-        launch_rgb_planes(pst, d_rgb, stride, s.W, s.H, pyr + s.off[0]);
+        launch_rgb_planes(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0]);  // (kernel_path 1: never batched)
     }
     // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
     for (int i = 0; i < levels; i++) {
         if (i == 0 && levels > 1 && !base) {
             s.cur_level = 1;
-            Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1]);
+            Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1] * nb);
             float sf = (float)kScale;
             if (ref) launch_blur_decimate_ref(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
-            else launch_blur_decimate(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad);
+            else launch_blur_decimate(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad, pb);
         }
         if (i + 2 < levels && !(base && i == 0)) {
             s.cur_level = i + 2;
-            Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2]);
+            Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2] * nb);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
             if (ref) launch_blur_decimate_ref(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
-            else launch_blur_decimate(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad);
+            else launch_blur_decimate(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad, pb);
         }
     }
     s.cur_level = kNoLevel;
@@ -522,6 +578,8 @@ int build_pyramid_one(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgb, int 
 // the frames are large enough that a pair spends most of its time in levels that fill the chip by themselves.  Four slots: 16 MP and
 // 8 MP frames are 3.8 % / 1.8 % faster under the throughput choices, 4 MP frames 3.9 % SLOWER, the foveated stack (0.25 Mpx windows)
 // 16 % slower.  The frame is what the call matches at its finest level: W x H in full mode, the fovea window in foveated mode.
+// Batched calls (round 4): what counts wherever "does this launch fill the chip" is asked is what the LAUNCH holds -- `pairs` x the level
+// (pairs = the batch where the level is batched, else 1); the thresholds below are therefore compared with pairs x W x H.
 constexpr long long kBusyFramePixels = 6000000;
 bool latency_mode(const ugsm_ctx *ctx, long long frame_px)
 {
@@ -529,18 +587,29 @@ bool latency_mode(const ugsm_ctx *ctx, long long frame_px)
     return ctx->cfg.slots == 1 || frame_px < kBusyFramePixels;
 }
 
+// Levels of at most this many pixels go through a batched call as ONE launch for all its pairs; larger levels fill the chip pair by
+// pair and are launched so (one launch per pair, one after the other on the slot's stream).
+constexpr long long kBatchMaxPixels = 2200000;
+bool batch_level(const ugsm_ctx *ctx, int W, int H)
+{
+    const long long thr = ctx->batch_max_px > 0 ? ctx->batch_max_px : (ctx->batch_max_px < 0 ? 0 : kBatchMaxPixels);
+    return (long long)W * H <= thr;
+}
+// pairs a launch of a W x H level of the call in `s` holds
+int launch_pairs(const ugsm_ctx *ctx, const Slot &s, int W, int H) { return (s.nb > 1 && batch_level(ctx, W, H)) ? s.nb : 1; }
+
 // K-cost as the marching kernel (ugsm_kernels_march.hip): a strip is one wave working down >= 6 rows.  Throughput: it does the least
 // work per pixel (6 halo rows per strip against the tiles' halos) down to the 63 k-pixel level -- four slots at 16 MP: 163.2 pairs/s at
 // a threshold of 50 000, 162.7 at 100 000, 160.4 at 200 000 (round 2's value), 159.1 at 400 000; below 50 000 the coarse-level latency
 // kernels win again (161.4 with everything marching).  Latency: from 0.4 Mpx -- but the levels of 0.15 - 3 Mpx go to k_cost_march4
 // first (use_march4), so in effect from 3 Mpx.
 constexpr int kMarchMinPixelsThroughput = 50000, kMarchMinPixelsLatency = 400000;
-bool use_march(const ugsm_ctx *ctx, int W, int H, bool lat)
+bool use_march(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.march_min_pixels < 0) return false;
     const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (lat ? kMarchMinPixelsLatency : kMarchMinPixelsThroughput);
-    return (long long)W * H >= thr;
+    return (long long)W * H * pairs >= thr && H >= 6;
 }
 
 int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
@@ -560,11 +629,11 @@ int small_max_px(const ugsm_config &cfg)
     if (cfg.small_max_pixels < 0) return 0;
     return cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.slots == 1 ? kSmallMaxPixelsAlone : kSmallMaxPixelsShared);
 }
-bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat)
+bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
-    const long long px = (long long)W * H;
-    if (cfg.kernel_path == 1) return false;
+    const long long px = (long long)W * H * pairs;
+    if (cfg.kernel_path == 1 || H < 6) return false;
     if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
     return lat && px > small_max_px(cfg) && px <= kMarch4MaxPixels;
 }
@@ -583,19 +652,20 @@ void set_policy(ugsm_ctx *c, const DevKnobs &k)
     c->march4_lo = k.march4_lo;
     c->march4_hi = k.march4_hi;
     c->force_mode = k.force_mode;
-    c->iter_small = k.iter_small > 0 ? 1 : 0;
+    c->iter_small = (kDevLib && k.iter_small > 0) ? 1 : 0;
+    c->batch_max_px = k.batch_max_px;
 }
 
 // K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
 // has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
 // (tools/kbench mode 7).  Returns the K-smooth region height to use (0 = not a small level).
-int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat)
+int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
     const long long thr = small_max_px(cfg);
-    const long long px = (long long)W * H;
-    if (px > thr || use_march(ctx, W, H, lat)) return 0;
+    const long long px = (long long)W * H * pairs;
+    if (px > thr || use_march(ctx, W, H, lat, pairs)) return 0;
     if (ctx->small_rh_force) return ctx->small_rh_force;
     // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other slots' pairs share the chip -- the 18 x 4 / 18 x 10 tiles
     // redo 8 x / 4.6 x the work, free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight (tools/ab.py).
@@ -607,32 +677,39 @@ int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat)
 // Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is a marching
 // kernel: the seeded field is then never written (launch_cost_march_seeded, launch_cost_march4).  Not with the early
 // exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
-bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool lat)
+bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, lat) || use_march4(ctx, W, H, lat));
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, lat, pairs) || use_march4(ctx, W, H, lat, pairs));
 }
 
 // k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.26 Mpx, else 32 x 16), > 0 = the
 // 112-column tile at this height (smooth_tile_rows, ugsm_kernels_fused.hip).  Throughput: the 112 x 36 tile (1.39 x the tile in halo
 // work, against 1.8 x for 64 x 32) from 0.1 Mpx on, +1.7 % with four 16 MP pairs in flight.  Latency: from 0.5 Mpx, and a one-slot
 // context picks the height that fills whole rounds of workgroups.
-int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool lat)
+int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const int big_min = ctx->smooth_big_min > 0 ? ctx->smooth_big_min : (lat ? (1 << 19) : 100000);
-    if ((long long)W * H < big_min) return 0;
+    if ((long long)W * H * pairs < big_min) return 0;
+    if (pairs > 1 && W < 100) return 0;  // (a level narrower than the 112-column tile: the smaller tile classes waste fewer lanes)
     if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
     const int rounds_rule = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
-    return smooth_tile_rows(W, H, rounds_rule);
+    return smooth_tile_rows(W, H, rounds_rule, pairs);
+}
+// ... and the tile class of the smaller levels (launch_smooth_fused's tile_class): by what the launch holds
+int smooth_class_for(int W, int H, int pairs)
+{
+    if (pairs <= 1) return 0;
+    return ((long long)W * H * pairs >= smooth_mid_min_pixels && W >= 48 && H >= 24) ? 2 : 1;
 }
 
-// S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412).  On return `a` holds the
-// result and `b` is scratch.
-// final_out (optional, fused path): the last launch writes there instead of into `b`; `a` then points at final_out.
-int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, int H, int S, bool do_box, float *final_out = nullptr)
+// S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412) for every pair of the call.  On return `a` holds the
+// result and `b` is scratch (base pointers: pair k's buffers lie at + k * lvl_stride).
+// final_out (optional, fused path): per-pair destinations; the last launch writes there instead of into `b`, and `a` is then not meaningful.
+int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, int H, int S, bool do_box, float *const *final_out = nullptr)
 {
     const double px = (double)W * H;
-    if (ctx->cfg.kernel_path == 1) {
+    if (ctx->cfg.kernel_path == 1) {  // (never batched)
         for (int j = 0; j < S; j++) {
             Timer t(ctx, &s, si, KC_SMOOTH, px);
             launch_smooth_pass_ref(s.st, a, b, W, H);
@@ -644,22 +721,28 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             std::swap(a, b);
         }
     } else {
+        const int pairs = launch_pairs(ctx, s, W, H);
         int left = S;
         do {
             int p = std::min(left, 5);
             left -= p;
             if (p == 0 && !do_box) break;
-            const bool march = p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx, W, H, s.lat);
-            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H, s.lat) : 0;
-            Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : (rh ? KC_SMOOTH_SMALL : KC_SMOOTH), px);
+            const bool march = kDevLib && s.nb == 1 && p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx, W, H, s.lat);
+            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H, s.lat, pairs) : 0;
             const bool box_now = do_box && left == 0;
-            float *dst = (left == 0 && final_out) ? final_out : b;
-            // five passes at a time on a large level may run as the marching kernel; anything else: the LDS-tiled one
-            if (march) launch_smooth_march(s.st, a, dst, W, H, box_now, 1, ctx->cfg.march_rows);
-            else if (rh) launch_smooth_small(s.st, a, dst, W, H, p, box_now, rh);
-            else launch_smooth_fused(s.st, a, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H, s.lat));
-            if (dst == final_out) a = final_out;
-            else std::swap(a, b);
+            const bool to_final = left == 0 && final_out;
+            for_groups(s.nb, pairs > 1, [&](Grp g) {
+                Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : (rh ? KC_SMOOTH_SMALL : KC_SMOOTH), px * g.n);
+                const float *src = a + g.b0 * s.lvl_stride;
+                float *dst = to_final ? final_out[g.b0] : b + g.b0 * s.lvl_stride;
+                const Batch bt = make_batch(s, g, nullptr, nullptr, to_final ? final_out : nullptr);
+                const Batch *pb = g.n > 1 ? &bt : nullptr;
+                // five passes at a time on a large level may run as the marching kernel (libugsm_dev.so); anything else: the LDS-tiled ones
+                if (march) launch_smooth_march(s.st, src, dst, W, H, box_now, 1, ctx->cfg.march_rows);
+                else if (rh) launch_smooth_small(s.st, src, dst, W, H, p, box_now, rh, pb);
+                else launch_smooth_fused(s.st, src, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H, s.lat, g.n), pb, smooth_class_for(W, H, g.n));
+            });
+            if (!to_final) std::swap(a, b);
         } while (left > 0);
     }
     return UGSM_OK;
@@ -686,16 +769,17 @@ int weighted_difference(ugsm_ctx *ctx, Slot &s, const float *newd3, const float 
     return UGSM_OK;
 }
 
-// matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to.  cur holds (dx,dy,conf)
-// on entry and on exit; other is scratch of the same size.
-// final_out (optional, fused path only): where the last iteration leaves its result instead of the ping-pong buffer
+// matchlevel (MatchGPULib.cpp:1662-2489), iterations m_from..m_to, for every pair of the call (s.nb; in lockstep).  Lv / Rv: the pairs'
+// views of the level (s.nb entries).  cur holds (dx,dy,conf) on entry and on exit; other is scratch of the same size (base pointers:
+// pair k's fields lie at + k * lvl_stride).
+// final_out (optional, fused path only): per-pair destinations where the last iteration leaves its result instead of the ping-pong buffer
 // (saves the device-to-device copy of the finished level); cur/other are then not meaningful afterwards.
-// seed (optional, see fuse_seed): `cur` holds the COARSER level's field (seed->Ws x seed->Hs) and iteration m_from reads its starting
-// field through the seeding map instead of from a materialised seeded field.
-// A_pre (optional): A = G_clamp * L^2 of this level, already computed (on the slot's side stream; the caller has made the main
-// stream wait for it); otherwise it is computed here, into s.A.
-int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int mi, int S, bool is_top, int m_from,
-              int m_to, float *&cur, float *&other, float *dbg8, float *final_out = nullptr, const SeedMap *seed = nullptr,
+// seed (optional, see fuse_seed; s.nb entries): `cur` holds the COARSER level's field (seed->Ws x seed->Hs) and iteration m_from reads its
+// starting field through the seeding map instead of from a materialised seeded field.
+// A_pre (optional, single pairs only): A = G_clamp * L^2 of this level, already computed (on the slot's side stream; the caller has made
+// the main stream wait for it); otherwise it is computed here, into s.A.
+int run_level(ugsm_ctx *ctx, Slot &s, int si, const Img3 *Lv, const Img3 *Rv, int W, int H, int mi, int S, bool is_top, int m_from,
+              int m_to, float *&cur, float *&other, float *dbg8, float *const *final_out = nullptr, const SeedMap *seed = nullptr,
               const float *A_pre = nullptr)
 {
     const bool ref = ctx->cfg.kernel_path == 1;
@@ -706,6 +790,7 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
     // previous iteration's field has to survive the smoothing ping-pong, hence a third buffer.
     const float eps = ctx->cfg.early_exit_threshold;
     const bool early = eps > 0.0f;
+    if ((early || ref) && s.nb != 1) return UGSM_ERR_STATE;  // (the batch entry points run such contexts pair by pair)
     float *third = nullptr;
     if (early) {
         const size_t lvl = 3 * (size_t)W * H;
@@ -715,16 +800,29 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
         final_out = nullptr;
     }
     int ran = 0;
-    const float *const A3 = A_pre ? A_pre : s.A;
+    const int pairs = launch_pairs(ctx, s, W, H);
+    const bool batched = pairs > 1;
+    const float *const A3 = A_pre ? A_pre : s.A;  // (pair k's A at + k * lvl_stride)
     if (!A_pre) {   // A = G_clamp * L^2 does not depend on the iteration: once per level.
-        Timer t(ctx, &s, si, KC_SQBLUR, px);
-        if (ref) launch_sqblur_clamp_ref(s.st, L, W, H, s.A);
-        else launch_sqblur_clamp(s.st, L, W, H, s.A);
+        for_groups(s.nb, batched, [&](Grp g) {
+            Timer t(ctx, &s, si, KC_SQBLUR, px * g.n);
+            if (ref) {
+                launch_sqblur_clamp_ref(s.st, Lv[g.b0], W, H, s.A);
+            } else {
+                const Batch bt = make_batch(s, g, Lv);
+                launch_sqblur_clamp(s.st, Lv[g.b0], W, H, s.A + g.b0 * s.lvl_stride, g.n > 1 ? &bt : nullptr);
+            }
+        });
     }
-    // coarse levels, optional: the smoothing of iteration m and the cost step of iteration m + 1 in one launch (k_iter_small); the level is
+    // coarse levels, optional (libugsm_dev.so): the smoothing of iteration m and the cost step of iteration m + 1 in one launch (k_iter_small); the level is
     // then  cost, (mi - 1) x [smooth + cost], smooth.  `other` carries the cost step's output from one launch to the next.
-    const bool fuse_iter = ctx->iter_small && !ref && !early && S == 5 && (ctx->small_mask & 3) == 3 && small_rh(ctx, W, H, s.lat) != 0 &&
+    const bool fuse_iter = kDevLib && s.nb == 1 && ctx->iter_small && !ref && !early && S == 5 && (ctx->small_mask & 3) == 3 && small_rh(ctx, W, H, s.lat) != 0 &&
                            !use_march4(ctx, W, H, s.lat);
+    const bool march4 = !ref && use_march4(ctx, W, H, s.lat, pairs);
+    const bool march = !ref && use_march(ctx, W, H, s.lat, pairs);
+    const bool small = !ref && (ctx->small_mask & 1) && small_rh(ctx, W, H, s.lat, pairs) != 0;
+    // (k_cost_split, the LDS-tiled form a level falls back to when the marching kernels are switched off, has no batch index: pair by pair)
+    const bool cost_batched = batched && (march4 || march || small);
     for (int m = m_from; m <= m_to; m++) {
         const int blend = !(is_top && m == 1);  // MatchGPULib.cpp:2223
         if (fuse_iter && m > m_from) {
@@ -732,27 +830,31 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
         } else if (ref) {
             {
                 Timer t(ctx, &s, si, KC_WARP, px);
-                launch_warp_ref(s.st, R, cur, W, H, s.Rw);
+                launch_warp_ref(s.st, Rv[0], cur, W, H, s.Rw);
             }
             {
                 Timer t(ctx, &s, si, KC_SQBLUR, px);
                 launch_sqblur_clamp_ref(s.st, Img3{s.Rw, W, (size_t)W * H}, W, H, s.B);
             }
             Timer t(ctx, &s, si, KC_COST, px);
-            launch_cost_ref(s.st, L, s.Rw, A3, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
+            launch_cost_ref(s.st, Lv[0], s.Rw, A3, s.B, cur, other, W, H, thr[m - 1], blend, (m == m_to) ? dbg8 : nullptr);
         } else {
-            const bool march4 = use_march4(ctx, W, H, s.lat);
-            const bool march = use_march(ctx, W, H, s.lat);
-            const bool small = (ctx->small_mask & 1) && small_rh(ctx, W, H, s.lat) != 0;
-            Timer t(ctx, &s, si, march4 ? KC_COST_MARCH4 : (march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST)), px);
-            if (march4)
-                launch_cost_march4(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, s.range_known ? s.range_bad : nullptr,
-                                   (seed && m == m_from) ? *seed : SeedMap{0, 0, 0, 0});
-            else if (march && seed && m == m_from)
-                launch_cost_march_seeded(s.st, L, R, A3, cur, *seed, other, W, H, thr[m - 1], blend, march_rows_arg(ctx), s.range_known ? s.range_bad : nullptr);
-            else if (march) launch_cost_march(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend, 0, 1, march_rows_arg(ctx), s.range_known ? s.range_bad : nullptr);
-            else if (small) launch_cost_small(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
-            else launch_cost_fused(s.st, L, R, A3, cur, other, W, H, thr[m - 1], blend);
+            const bool seeded = seed && m == m_from;
+            for_groups(s.nb, cost_batched, [&](Grp g) {
+                Timer t(ctx, &s, si, march4 ? KC_COST_MARCH4 : (march ? KC_COST_MARCH : (small ? KC_COST_SMALL : KC_COST)), px * g.n);
+                const size_t fo = g.b0 * s.lvl_stride;
+                const Img3 L = Lv[g.b0], R = Rv[g.b0];
+                const Batch bt = make_batch(s, g, Lv, seeded ? seed : nullptr);
+                const Batch *pb = g.n > 1 ? &bt : nullptr;
+                const unsigned *rb = s.range_known ? s.range_bad + g.b0 : nullptr;
+                if (march4)
+                    launch_cost_march4(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, 0, rb, seeded ? seed[g.b0] : SeedMap{0, 0, 0, 0}, pb);
+                else if (march && seeded)
+                    launch_cost_march_seeded(s.st, L, R, A3 + fo, cur + fo, seed[g.b0], other + fo, W, H, thr[m - 1], blend, march_rows_arg(ctx), rb, pb);
+                else if (march) launch_cost_march(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, 0, 1, march_rows_arg(ctx), rb, pb);
+                else if (small) launch_cost_small(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, pb);
+                else launch_cost_fused(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend);
+            });
         }
         ran = m;
         if (early) {
@@ -769,7 +871,7 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, Img3 L, Img3 R, int W, int H, int 
         }
         if (fuse_iter && m < m_to) {
             Timer t(ctx, &s, si, KC_ITER_SMALL, px);
-            launch_iter_small(s.st, L, R, A3, other, cur, W, H, thr[m], 1, S);  // iteration m + 1 >= 2 always blends (MatchGPULib.cpp:2223)
+            launch_iter_small(s.st, Lv[0], Rv[0], A3, other, cur, W, H, thr[m], 1, S);  // iteration m + 1 >= 2 always blends (MatchGPULib.cpp:2223)
             std::swap(cur, other);
             continue;
         }
@@ -788,49 +890,73 @@ Img3 level_view(const Slot &s, const float *pyr, int lev, int ox, int oy)
 {
     return Img3{pyr + s.off[lev] + (size_t)oy * s.w[lev] + ox, s.w[lev], (size_t)s.w[lev] * s.h[lev]};
 }
+// the full-frame views of level `lev` for every pair of the call
+void full_views(const Slot &s, const float *pyr, int lev, Img3 *out)
+{
+    for (int b = 0; b < s.nb; b++) out[b] = level_view(s, pyr + b * s.pyr_stride, lev, 0, 0);
+}
 
+// Whether this call may use the slot's side stream: single pairs on a context that has one, the fused path, no event brackets (the
+// statistics belong to one stream).
+bool side_stream_ok(const ugsm_ctx *ctx, const Slot &s)
+{
+    return s.nb == 1 && s.st2 != nullptr && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams;
+}
+// A = G_clamp * L^2 of the full-frame levels a_from .. top on the side stream, beside whatever the main stream does next (the right
+// pyramid's join, the coarse levels' iterations); run_level takes them through level_A, which makes the main stream wait for each.
+int enqueue_side_A(ugsm_ctx *ctx, Slot &s, int a_from)
+{
+    if (a_from < 0 || ctx->cfg.early_exit_threshold > 0.0f) return UGSM_OK;
+    size_t tot = s.off[s.levels - 1] + 3 * (size_t)s.w[s.levels - 1] * s.h[s.levels - 1];
+    UCHK(grow(ctx, s.Apyr, s.apyr_cap, tot));
+    HIPCHK(ctx, hipEventRecord(s.ev_L, s.st));  // (the left pyramid is complete on the main stream)
+    HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_L, 0));
+    for (int i = s.levels - 1; i >= a_from; i--) {  // coarsest first: that is the order the levels need them in
+        launch_sqblur_clamp(s.st2, level_view(s, s.pyrL, i, 0, 0), s.w[i], s.h[i], s.Apyr + s.off[i]);
+        HIPCHK(ctx, hipEventRecord(s.ev_A[i], s.st2));
+    }
+    s.a_from = a_from;
+    return UGSM_OK;
+}
+
+// The pyramids of every pair of the call (s.nb = nb pairs; rgbL / rgbR: nb device pointers).
 // a_from: the levels a_from .. top get their A = G_clamp * L^2 precomputed on the side stream (full mode: 0; foveated: F-1, the
 // fine levels work on crops whose A is clamped at the crop's own border and is computed in line); < 0: none.
-// side_in: the right image's upload is already in flight on the side stream (stage_in), so the fork event is not needed for it.
-int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int a_from = -1)
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR, int nb, int W, int H, int stride, int a_from = -1)
 {
-    if (!d_rgbL || !d_rgbR) return UGSM_ERR_BAD_ARG;
+    if (!d_rgbL || !d_rgbR || nb < 1 || nb > kMaxBatch) return UGSM_ERR_BAD_ARG;
+    for (int b = 0; b < nb; b++)
+        if (!d_rgbL[b] || !d_rgbR[b]) return UGSM_ERR_BAD_ARG;
     if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
-    UCHK(prepare_slot(ctx, s, W, H));
+    UCHK(prepare_slot(ctx, s, W, H, nb));
     // the pyramid kernels of the fused path check every value they write (level 0 holds the integers 0..255)
     s.range_known = ctx->cfg.kernel_path != 1 && s.range_bad != nullptr;
-    if (s.range_known) HIPCHK(ctx, hipMemsetAsync(s.range_bad, 0, sizeof(unsigned), s.st));
-    // One stream, as in rounds 1 and 2: the one-stage-per-kernel path, and whenever launches are bracketed by events (the
+    if (s.range_known) HIPCHK(ctx, hipMemsetAsync(s.range_bad, 0, sizeof(unsigned) * nb, s.st));
+    // One stream, as in rounds 1 and 2: the one-stage-per-kernel path, a batch, and whenever launches are bracketed by events (the
     // statistics belong to one stream).  Otherwise fork: R's pyramid and the A planes on the side stream.
-    const bool fork = s.st2 != nullptr && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams;
+    const bool fork = side_stream_ok(ctx, s);
     s.a_from = -1;
     if (!fork) {
-        UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
-        UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR));
-        s.have_pyr = true;
+        UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL));
+        UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR));
+        s.have_pyr = nb == 1;  // (the fovea-shard entry points work on single pairs)
         return UGSM_OK;
     }
     // the side stream starts after everything enqueued on this slot so far (the previous pair still reads pyrR and Apyr)
     HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
     HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
-    UCHK(build_pyramid_one(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2));
+    UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2));
     HIPCHK(ctx, hipEventRecord(s.ev_R, s.st2));
-    UCHK(build_pyramid_one(ctx, s, si, d_rgbL, stride, s.pyrL));
-    if (a_from >= 0 && !(ctx->cfg.early_exit_threshold > 0.0f)) {
-        size_t tot = s.off[s.levels - 1] + 3 * (size_t)s.w[s.levels - 1] * s.h[s.levels - 1];
-        UCHK(grow(ctx, s.Apyr, s.apyr_cap, tot));
-        HIPCHK(ctx, hipEventRecord(s.ev_L, s.st));
-        HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_L, 0));
-        for (int i = s.levels - 1; i >= a_from; i--) {  // coarsest first: that is the order the levels need them in
-            launch_sqblur_clamp(s.st2, level_view(s, s.pyrL, i, 0, 0), s.w[i], s.h[i], s.Apyr + s.off[i]);
-            HIPCHK(ctx, hipEventRecord(s.ev_A[i], s.st2));
-        }
-        s.a_from = a_from;
-    }
+    UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL));
+    if (a_from >= 0) UCHK(enqueue_side_A(ctx, s, a_from));
     HIPCHK(ctx, hipStreamWaitEvent(s.st, s.ev_R, 0));
     HIPCHK(ctx, hipGetLastError());
     s.have_pyr = true;
     return UGSM_OK;
+}
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int a_from = -1)
+{
+    return enqueue_pyramids(ctx, s, si, &d_rgbL, &d_rgbR, 1, W, H, stride, a_from);
 }
 
 // A of full-frame level i if it was precomputed on the side stream (the main stream is made to wait for it here), else null
@@ -842,46 +968,58 @@ const float *level_A(ugsm_ctx *ctx, Slot &s, int i)
     return s.Apyr + s.off[i];
 }
 
-// matching() with foveatedmatching==0, MatchGPULib.cpp:1196-1318
+// the kernel choices of a call whose finest level is frame_px pixels per pair: what is in flight is the batch
+void set_call_mode(ugsm_ctx *ctx, Slot &s, long long frame_px) { s.lat = latency_mode(ctx, frame_px * s.nb); }
+
+// matching() with foveatedmatching==0, MatchGPULib.cpp:1196-1318, for the s.nb pairs of the call; d_out: their result buffers.
 // swap: the images exchanged (the right-to-left match of the LR check): the right pyramid is the "left" image; A is then computed
 // in line (the side stream's A planes belong to the left image).
-int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out, bool swap = false)
+int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *const *d_out, bool swap = false)
 {
-    const int levels = s.levels;
-    s.lat = latency_mode(ctx, (long long)s.W * s.H);
+    const int levels = s.levels, nb = s.nb;
+    set_call_mode(ctx, s, (long long)s.W * s.H);
     const float *const pL = swap ? s.pyrR : s.pyrL, *const pR = swap ? s.pyrL : s.pyrR;
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
-    HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));  // U1: zero seed
-    SeedMap sm{0, 0, 0, 0};
+    for (int b = 0; b < nb; b++)  // U1: zero seed
+        HIPCHK(ctx, hipMemsetAsync(cur + b * s.lvl_stride, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
+    SeedMap sm[kMaxBatch];
+    Img3 Lv[kMaxBatch], Rv[kMaxBatch];
     bool seeded = false;
     for (int i = top; i >= 0; i--) {
         s.cur_level = i;
         const int mi = level_iterations(i);
         // the finest level's last smoothing launch writes the caller's buffer directly (no 193 MB device copy at 16 MP)
         const bool direct = i == 0 && ctx->cfg.kernel_path != 1 && level_smooth(0) > 0 && !(ctx->cfg.early_exit_threshold > 0.0f);
-        UCHK(run_level(ctx, s, si, level_view(s, pL, i, 0, 0), level_view(s, pR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr, seeded ? &sm : nullptr,
-                       swap ? nullptr : level_A(ctx, s, i)));
+        full_views(s, pL, i, Lv);
+        full_views(s, pR, i, Rv);
+        UCHK(run_level(ctx, s, si, Lv, Rv, s.w[i], s.h[i], mi, level_smooth(i), i == top, 1, mi, cur, other, nullptr, direct ? d_out : nullptr,
+                       seeded ? sm : nullptr, (swap || nb > 1) ? nullptr : level_A(ctx, s, i)));
         if (direct) return UGSM_OK;
         seeded = false;
         if (i > 0) {
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat)) {  // the next level's first K-cost launch reads `cur` through the seeding map
-                sm = SeedMap{s.w[i], s.h[i], 0, 0};
+            const int np = launch_pairs(ctx, s, s.w[i - 1], s.h[i - 1]);
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat, np)) {  // the next level's first K-cost launch reads `cur` through the seeding map
+                for (int b = 0; b < nb; b++) sm[b] = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
-                Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
-                launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+                for_groups(nb, np > 1, [&](Grp g) {
+                    Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1] * g.n);
+                    const Batch bt = make_batch(s, g);
+                    launch_seed(s.st, cur + g.b0 * s.lvl_stride, s.w[i], s.h[i], other + g.b0 * s.lvl_stride, s.w[i - 1], s.h[i - 1], 0, 0, g.n > 1 ? &bt : nullptr);
+                });
                 std::swap(cur, other);
             }
         }
     }
-    HIPCHK(ctx, hipMemcpyAsync(d_out, cur, sizeof(float) * 3 * (size_t)s.W * s.H, hipMemcpyDeviceToDevice, s.st));
+    for (int b = 0; b < nb; b++)
+        HIPCHK(ctx, hipMemcpyAsync(d_out[b], cur + b * s.lvl_stride, sizeof(float) * 3 * (size_t)s.W * s.H, hipMemcpyDeviceToDevice, s.st));
     return UGSM_OK;
 }
+int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *d_out, bool swap = false) { return enqueue_full(ctx, s, si, &d_out, swap); }
 
 // Full mode with the optional LR-consistency check (ugsm_config.lr_check_threshold; no reference counterpart): the match, the match
-// with the images exchanged into the slot's own buffer, then one kernel that zeroes the inconsistent confidences of d_out.
+// with the images exchanged into the slot's own buffer, then one kernel that zeroes the inconsistent confidences of d_out.  (Single pairs.)
 int enqueue_full_lr(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
 {
     s.lr_ran = false;
@@ -904,75 +1042,146 @@ int enqueue_full_lr(ugsm_ctx *ctx, Slot &s, int si, float *d_out)
     return UGSM_OK;
 }
 
-// matching() with foveatedmatching==1 (MatchGPULib.cpp:1230-1294), split at level F-1.
-int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state)
+// a batched plane copy: pair j of group g from src0 + j * lvl_stride (a level buffer) or from its view, to its own destination
+Batch copy_batch(const Slot &s, Grp g, const Img3 *views, float *const *dsts, size_t dst_off)
 {
-    const int levels = s.levels, F = ctx->cfg.fovea_levels;
+    Batch b{};
+    b.n = g.n;
+    for (int j = 0; j < g.n; j++) {
+        b.img[j] = views ? byte_diff(views[g.b0 + j].p, views[g.b0].p) : (long long)(j * s.lvl_stride * sizeof(float));
+        b.out[j] = byte_diff(dsts[g.b0 + j] + dst_off, dsts[g.b0] + dst_off);
+    }
+    return b;
+}
+
+// matching() with foveatedmatching==1 (MatchGPULib.cpp:1230-1294), split at level F-1; d_state: one buffer per pair of the call.
+int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *const *d_state)
+{
+    const int levels = s.levels, F = ctx->cfg.fovea_levels, nb = s.nb;
     if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
-    s.lat = latency_mode(ctx, (long long)s.w[F - 1] * s.h[F - 1]);  // (the fovea window is as large as level F-1)
+    set_call_mode(ctx, s, (long long)s.w[F - 1] * s.h[F - 1]);  // (the fovea window is as large as level F-1)
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
-    HIPCHK(ctx, hipMemsetAsync(cur, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
-    SeedMap sm{0, 0, 0, 0};
+    for (int b = 0; b < nb; b++)
+        HIPCHK(ctx, hipMemsetAsync(cur + b * s.lvl_stride, 0, sizeof(float) * 3 * (size_t)s.w[top] * s.h[top], s.st));
+    SeedMap sm[kMaxBatch];
+    Img3 Lv[kMaxBatch], Rv[kMaxBatch];
     bool seeded = false;
     for (int i = top; i >= F - 1; i--) {
         s.cur_level = i;
         const int mi = level_iterations(i);
-        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, 0, 0), level_view(s, s.pyrR, i, 0, 0), s.w[i], s.h[i], mi,
-                       level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr, level_A(ctx, s, i)));
+        full_views(s, s.pyrL, i, Lv);
+        full_views(s, s.pyrR, i, Rv);
+        UCHK(run_level(ctx, s, si, Lv, Rv, s.w[i], s.h[i], mi, level_smooth(i), i == top, 1, mi, cur, other, nullptr, nullptr, seeded ? sm : nullptr,
+                       nb > 1 ? nullptr : level_A(ctx, s, i)));
         seeded = false;
         if (i > F - 1) {
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat)) {
-                sm = SeedMap{s.w[i], s.h[i], 0, 0};
+            const int np = launch_pairs(ctx, s, s.w[i - 1], s.h[i - 1]);
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat, np)) {
+                for (int b = 0; b < nb; b++) sm[b] = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
-                Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1]);
-                launch_seed(s.st, cur, s.w[i], s.h[i], other, s.w[i - 1], s.h[i - 1], 0, 0);
+                for_groups(nb, np > 1, [&](Grp g) {
+                    Timer t(ctx, &s, si, KC_SEED, (double)s.w[i - 1] * s.h[i - 1] * g.n);
+                    const Batch bt = make_batch(s, g);
+                    launch_seed(s.st, cur + g.b0 * s.lvl_stride, s.w[i], s.h[i], other + g.b0 * s.lvl_stride, s.w[i - 1], s.h[i - 1], 0, 0, g.n > 1 ? &bt : nullptr);
+                });
                 std::swap(cur, other);
             }
         }
     }
-    HIPCHK(ctx, hipMemcpyAsync(d_state, cur, sizeof(float) * 3 * (size_t)s.w[F - 1] * s.h[F - 1], hipMemcpyDeviceToDevice, s.st));
-    s.have_coarse = true;
+    const size_t fn = (size_t)s.w[F - 1] * s.h[F - 1];
+    if (nb == 1) {
+        HIPCHK(ctx, hipMemcpyAsync(d_state[0], cur, sizeof(float) * 3 * fn, hipMemcpyDeviceToDevice, s.st));
+    } else {
+        const Grp g{0, nb};
+        const Batch bt = copy_batch(s, g, nullptr, d_state, 0);
+        launch_copy_view(s.st, Img3{cur, s.w[F - 1], fn}, s.w[F - 1], s.h[F - 1], d_state[0], fn, s.w[F - 1], &bt);
+    }
+    s.have_coarse = nb == 1;
     return UGSM_OK;
 }
+int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *d_state) { return enqueue_fovea_coarse(ctx, s, si, &d_state); }
 
-int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int off_x, int off_y, float *d_stack,
-                       float *d_pyrL, float *d_pyrR)
+// The fine phase for the s.nb pairs of the call: per-pair states, window offsets and destinations (d_pyrL / d_pyrR may be null, and so may
+// their entries).
+int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *const *d_state, const int *off_x, const int *off_y, float *const *d_stack,
+                       float *const *d_pyrL, float *const *d_pyrR)
 {
-    const int levels = s.levels, F = ctx->cfg.fovea_levels;
+    const int levels = s.levels, F = ctx->cfg.fovea_levels, nb = s.nb;
     if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
-    FoveaGeom g;
-    fovea_geometry(s.w, s.h, F, off_x, off_y, g);
-    s.lat = latency_mode(ctx, (long long)g.fw * g.fh);
-    const size_t fn = (size_t)g.fw * g.fh;
+    FoveaGeom g[kMaxBatch];
+    for (int b = 0; b < nb; b++) fovea_geometry(s.w, s.h, F, off_x[b], off_y[b], g[b]);
+    const int fw = g[0].fw, fh = g[0].fh;
+    set_call_mode(ctx, s, (long long)fw * fh);
+    const size_t fn = (size_t)fw * fh;
+    const int np = launch_pairs(ctx, s, fw, fh);  // (every level of the fine phase is a window of this size)
     float *cur = s.d0, *other = s.d1;
-    HIPCHK(ctx, hipMemcpyAsync(cur, d_state, sizeof(float) * 3 * fn, hipMemcpyDeviceToDevice, s.st));
+    for (int b = 0; b < nb; b++)
+        HIPCHK(ctx, hipMemcpyAsync(cur + b * s.lvl_stride, d_state[b], sizeof(float) * 3 * fn, hipMemcpyDeviceToDevice, s.st));
+    // a stack row block / a pyramid-stack block for every pair: one launch for the batch
+    auto copy_out = [&](const Img3 *views, const float *field, float *const *dsts, size_t dst_off, size_t dst_plane) {
+        for_groups(nb, np > 1, [&](Grp gr) {
+            const Batch bt = copy_batch(s, gr, views, dsts, dst_off);
+            const Img3 src = views ? views[gr.b0] : Img3{field + gr.b0 * s.lvl_stride, fw, fn};
+            launch_copy_view(s.st, src, fw, fh, dsts[gr.b0] + dst_off, dst_plane, fw, gr.n > 1 ? &bt : nullptr);
+        });
+    };
     // stack row block F-1 = the whole level F-1 (UG_GPU_matcher.cpp:293-303)
-    launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)(F - 1) * fn, (size_t)F * fn, g.fw);
+    copy_out(nullptr, cur, d_stack, (size_t)(F - 1) * fn, (size_t)F * fn);
+    SeedMap sm[kMaxBatch];
+    Img3 Lv[kMaxBatch], Rv[kMaxBatch];
     for (int i = F - 2; i >= 0; i--) {
         s.cur_level = i;
         // foveatedsubsampleDisp, MatchGPULib.cpp:1595-1655
-        const SeedMap sm{g.fw, g.fh, g.cx[i], g.cy[i]};
-        const bool seeded = fuse_seed(ctx, g.fw, g.fh, s.lat);
+        for (int b = 0; b < nb; b++) {
+            sm[b] = SeedMap{fw, fh, g[b].cx[i], g[b].cy[i]};
+            Lv[b] = level_view(s, s.pyrL + b * s.pyr_stride, i, g[b].ox[i], g[b].oy[i]);
+            Rv[b] = level_view(s, s.pyrR + b * s.pyr_stride, i, g[b].ox[i], g[b].oy[i]);
+        }
+        const bool seeded = fuse_seed(ctx, fw, fh, s.lat, np);
         if (!seeded) {
-            Timer t(ctx, &s, si, KC_SEED, (double)fn);
-            launch_seed(s.st, cur, g.fw, g.fh, other, g.fw, g.fh, g.cx[i], g.cy[i]);
+            for_groups(nb, np > 1, [&](Grp gr) {
+                Timer t(ctx, &s, si, KC_SEED, (double)fn * gr.n);
+                const Batch bt = make_batch(s, gr, nullptr, sm);
+                launch_seed(s.st, cur + gr.b0 * s.lvl_stride, fw, fh, other + gr.b0 * s.lvl_stride, fw, fh, sm[gr.b0].cx, sm[gr.b0].cy, gr.n > 1 ? &bt : nullptr);
+            });
             std::swap(cur, other);
         }
         const int mi = level_iterations(i);
-        UCHK(run_level(ctx, s, si, level_view(s, s.pyrL, i, g.ox[i], g.oy[i]), level_view(s, s.pyrR, i, g.ox[i], g.oy[i]),
-                       g.fw, g.fh, mi, level_smooth(i), false, 1, mi, cur, other, nullptr, nullptr, seeded ? &sm : nullptr));
-        launch_copy_view(s.st, Img3{cur, g.fw, fn}, g.fw, g.fh, d_stack + (size_t)i * fn, (size_t)F * fn, g.fw);
+        UCHK(run_level(ctx, s, si, Lv, Rv, fw, fh, mi, level_smooth(i), false, 1, mi, cur, other, nullptr, nullptr, seeded ? sm : nullptr));
+        copy_out(nullptr, cur, d_stack, (size_t)i * fn, (size_t)F * fn);
     }
     // pyramid stacks as the node publishes them (UG_GPU_matcher.cpp:203-213): [level][channel][row]
-    for (int k = 0; k < F; k++) {
-        int ox = (k < F - 1) ? g.ox[k] : 0, oy = (k < F - 1) ? g.oy[k] : 0;
-        if (d_pyrL) launch_copy_view(s.st, level_view(s, s.pyrL, k, ox, oy), g.fw, g.fh, d_pyrL + (size_t)k * 3 * fn, fn, g.fw);
-        if (d_pyrR) launch_copy_view(s.st, level_view(s, s.pyrR, k, ox, oy), g.fw, g.fh, d_pyrR + (size_t)k * 3 * fn, fn, g.fw);
+    for (int side = 0; side < 2; side++) {
+        float *const *dsts = side == 0 ? d_pyrL : d_pyrR;
+        if (!dsts) continue;
+        bool all = true, any = false;
+        for (int b = 0; b < nb; b++) {
+            all = all && dsts[b] != nullptr;
+            any = any || dsts[b] != nullptr;
+        }
+        if (!any) continue;
+        const float *pyr = side == 0 ? s.pyrL : s.pyrR;
+        for (int k = 0; k < F; k++) {
+            for (int b = 0; b < nb; b++) {
+                const int ox = (k < F - 1) ? g[b].ox[k] : 0, oy = (k < F - 1) ? g[b].oy[k] : 0;
+                Lv[b] = level_view(s, pyr + b * s.pyr_stride, k, ox, oy);
+            }
+            if (all) {
+                copy_out(Lv, nullptr, dsts, (size_t)k * 3 * fn, fn);
+            } else {
+                for (int b = 0; b < nb; b++)
+                    if (dsts[b]) launch_copy_view(s.st, Lv[b], fw, fh, dsts[b] + (size_t)k * 3 * fn, fn, fw);
+            }
+        }
     }
     HIPCHK(ctx, hipGetLastError());
     return UGSM_OK;
+}
+int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int off_x, int off_y, float *d_stack, float *d_pyrL, float *d_pyrR)
+{
+    return enqueue_fovea_fine(ctx, s, si, &d_state, &off_x, &off_y, &d_stack, d_pyrL ? &d_pyrL : nullptr, d_pyrR ? &d_pyrR : nullptr);
 }
 
 int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
@@ -1148,6 +1357,7 @@ void ugsm_default_config(ugsm_config *cfg)
 }
 
 int ugsm_abi_version(void) { return UGSM_ABI_VERSION; }
+int ugsm_is_dev_library(void) { return kDevLib ? 1 : 0; }
 
 const char *ugsm_status_string(int st)
 {
@@ -1172,7 +1382,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (cfg_in) cfg = *cfg_in;
     else ugsm_default_config(&cfg);
     DevKnobs knobs;
-    apply_dev_env(cfg, knobs);  // (nothing unless UGSM_DEV=1)
+    apply_dev_env(cfg, knobs, true);  // (nothing unless UGSM_DEV=1)
     {   // the kernels carry the Gaussian taps as literals (ugsm_device.hpp); they must be the numbers the reference computes at
         // start-up: five float literals divided by their float sum (MatchGPULib.cpp:761-774)
         const float lit[5] = {0.0816475f, 0.218507f, 0.303281f, 0.218507f, 0.0816475f};
@@ -1182,8 +1392,12 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         if (memcmp(g, k, sizeof g) != 0) return UGSM_ERR_STATE;
     }
     if (cfg.levels < 1 || cfg.levels > UGSM_MAX_LEVELS || cfg.slots < 1 || cfg.slots > 64 || cfg.kernel_path < 0 ||
-        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f) || cfg.streams < 0)
+        cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f) || cfg.streams < 0 ||
+        cfg.batch < 0 || cfg.batch > UGSM_MAX_BATCH || cfg.stream_priority < 0 || cfg.stream_priority > 3)
         return UGSM_ERR_BAD_ARG;
+    if (cfg.kernel_path == 1 && !kDevLib) return UGSM_ERR_BAD_ARG;  // the one-kernel-per-stage path lives in libugsm_dev.so
+    if (!kDevLib) cfg.march_smooth = 0;                              // ... and so does the marching K-smooth
+    static_assert(UGSM_MAX_BATCH == kMaxBatch, "include/ugsm.h and ugsm_launch.hpp disagree on the batch size");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return UGSM_ERR_NO_DEVICE;
     if (cfg.device < 0 || cfg.device >= ndev) return UGSM_ERR_BAD_ARG;
@@ -1215,7 +1429,9 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         // at 16 MP (tools/ab.py; round 2 measured 161 only because its idle side streams happened to push the slots apart).  So:
         // slots 0-3 at the greatest priority (a pool the application is unlikely to use), slots 4-7 at the least, the rest at the
         // default.  Equal priority among the first four; the side stream of a one-slot context rides in the same pool.
-        const char pc = knobs.stream_prio[0] ? (si < (int)strlen(knobs.stream_prio) ? knobs.stream_prio[si] : 'n') : (si < 4 ? 'h' : (si < 8 ? 'l' : 'n'));
+        // ugsm_config.stream_priority: 1 = everything at the process default (opt out), 2 / 3 = everything at the greatest / least
+        const char by_cfg = cfg.stream_priority == 1 ? 'n' : (cfg.stream_priority == 2 ? 'h' : (cfg.stream_priority == 3 ? 'l' : (si < 4 ? 'h' : (si < 8 ? 'l' : 'n'))));
+        const char pc = knobs.stream_prio[0] ? (si < (int)strlen(knobs.stream_prio) ? knobs.stream_prio[si] : 'n') : by_cfg;
         const int prio = pc == 'h' ? prio_greatest : (pc == 'l' ? prio_least : 0);
         bool ok = (!s.owns_st || hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess) &&
                   hipMalloc((void **)&s.range_bad, 64) == hipSuccess && hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
@@ -1281,7 +1497,7 @@ int ugsm_plan_level_in_frame(const ugsm_config *cfg_in, int frame_w, int frame_h
     else ugsm_default_config(&probe.cfg);
     {   // ... under the same development overrides ugsm_create would apply in this process (none unless UGSM_DEV=1)
         DevKnobs knobs;
-        apply_dev_env(probe.cfg, knobs);
+        apply_dev_env(probe.cfg, knobs, false);
         set_policy(&probe, knobs);
     }
     memset(out, 0, sizeof *out);
@@ -1334,7 +1550,9 @@ int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     Slot *s;
     UCHK(get_slot(ctx, slot, &s));
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, ctx->cfg.fovea_levels >= 2 ? ctx->cfg.fovea_levels - 1 : -1));
+    // (no A planes here: the ranks of a fovea shard that only run the fine phase never use them; a coarse phase that follows computes
+    // them on the side stream itself -- ADVICE r03)
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, -1));
     return mark_done(ctx, *s);
 }
 
@@ -1356,6 +1574,7 @@ int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state)
     if (!d_state) return UGSM_ERR_BAD_ARG;
     if (!s->have_pyr) return UGSM_ERR_STATE;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (s->a_from < 0 && side_stream_ok(ctx, *s) && ctx->cfg.fovea_levels >= 2) UCHK(enqueue_side_A(ctx, *s, ctx->cfg.fovea_levels - 1));
     UCHK(enqueue_fovea_coarse(ctx, *s, slot, d_state));
     return mark_done(ctx, *s);
 }
@@ -1387,6 +1606,68 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     UCHK(grow(ctx, s->hout, s->hout_cap, std::max(fn3, s->hout_cap)));
     UCHK(enqueue_fovea_coarse(ctx, *s, slot, s->hout));
     UCHK(enqueue_fovea_fine(ctx, *s, slot, s->hout, off_x, off_y, d_stack, d_pyrL, d_pyrR));
+    return mark_done(ctx, *s);
+}
+
+// ---- B pairs per call ---------------------------------------------------------------------------------------------------------
+// Contexts whose options need a host round trip per iteration, a second match, or the one-kernel-per-stage path: pair by pair.
+static bool batch_runs_pair_by_pair(const ugsm_ctx *ctx)
+{
+    return ctx->cfg.kernel_path == 1 || ctx->cfg.early_exit_threshold > 0.0f || ctx->cfg.lr_check_threshold > 0.0f;
+}
+
+int ugsm_submit_full_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR, int W, int H, int stride,
+                           float *const *d_out)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (n < 1 || n > UGSM_MAX_BATCH || !d_rgbL || !d_rgbR || !d_out) return UGSM_ERR_BAD_ARG;
+    for (int b = 0; b < n; b++)
+        if (!d_rgbL[b] || !d_rgbR[b] || !d_out[b]) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (n == 1 || batch_runs_pair_by_pair(ctx)) {
+        for (int b = 0; b < n; b++) {
+            UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL[b], d_rgbR[b], W, H, stride, 0));
+            UCHK(enqueue_full_lr(ctx, *s, slot, d_out[b]));
+        }
+        return mark_done(ctx, *s);
+    }
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, n, W, H, stride));
+    s->lr_ran = false;
+    UCHK(enqueue_full(ctx, *s, slot, d_out));
+    return mark_done(ctx, *s);
+}
+
+int ugsm_submit_foveated_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR, int W, int H, int stride,
+                               const int *off_x, const int *off_y, float *const *d_stack, float *const *d_pyrL, float *const *d_pyrR)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (n < 1 || n > UGSM_MAX_BATCH || !d_rgbL || !d_rgbR || !d_stack) return UGSM_ERR_BAD_ARG;
+    for (int b = 0; b < n; b++)
+        if (!d_rgbL[b] || !d_rgbR[b] || !d_stack[b]) return UGSM_ERR_BAD_ARG;
+    const int F = ctx->cfg.fovea_levels;
+    if (F < 2) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    int zeros[UGSM_MAX_BATCH] = {0};
+    const int *ox = off_x ? off_x : zeros, *oy = off_y ? off_y : zeros;
+    int fw, fh;
+    UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
+    const size_t fn3 = (3 * (size_t)fw * fh + 63) & ~(size_t)63;  // level F-1's state of every pair, staged in the slot's hout
+    UCHK(grow(ctx, s->hout, s->hout_cap, std::max(fn3 * n, s->hout_cap)));
+    if (n == 1 || batch_runs_pair_by_pair(ctx)) {
+        for (int b = 0; b < n; b++) {
+            UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL[b], d_rgbR[b], W, H, stride, F - 1));
+            UCHK(enqueue_fovea_coarse(ctx, *s, slot, s->hout));
+            UCHK(enqueue_fovea_fine(ctx, *s, slot, s->hout, ox[b], oy[b], d_stack[b], d_pyrL ? d_pyrL[b] : nullptr, d_pyrR ? d_pyrR[b] : nullptr));
+        }
+        return mark_done(ctx, *s);
+    }
+    float *state[UGSM_MAX_BATCH];
+    for (int b = 0; b < n; b++) state[b] = s->hout + b * fn3;
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, n, W, H, stride));
+    UCHK(enqueue_fovea_coarse(ctx, *s, slot, state));
+    UCHK(enqueue_fovea_fine(ctx, *s, slot, state, ox, oy, d_stack, d_pyrL, d_pyrR));
     return mark_done(ctx, *s);
 }
 
@@ -1530,7 +1811,7 @@ int ugsm_stage_pyramid(ugsm_ctx *ctx, const uint8_t *d_rgb, int W, int H, int st
     if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     UCHK(prepare_slot(ctx, *s, W, H));
-    UCHK(build_pyramid_one(ctx, *s, 0, d_rgb, stride, s->pyrL));
+    UCHK(build_pyramids(ctx, *s, 0, &d_rgb, stride, s->pyrL));
     HIPCHK(ctx, hipMemcpyAsync(d_out3, s->pyrL + s->off[level], sizeof(float) * 3 * (size_t)s->w[level] * s->h[level],
                                hipMemcpyDeviceToDevice, s->st));
     return ugsm_wait(ctx, 0);
@@ -1562,7 +1843,9 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
         launch_range_scan(s->st, d_R3, 3 * n, s->range_bad);
     }
     s->lat = latency_mode(ctx, (long long)W * H);
-    UCHK(run_level(ctx, *s, 0, Img3{d_L3, W, n}, Img3{d_R3, W, n}, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
+    s->nb = 1;
+    const Img3 Lv{d_L3, W, n}, Rv{d_R3, W, n};
+    UCHK(run_level(ctx, *s, 0, &Lv, &Rv, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
     HIPCHK(ctx, hipMemcpyAsync(d_d3, cur, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     return ugsm_wait(ctx, 0);
 }
@@ -1591,6 +1874,7 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
     UCHK(ensure_level_bufs(ctx, *s, lvl));
     float *a = s->d0, *b = s->d1;
     HIPCHK(ctx, hipMemcpyAsync(a, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
+    s->nb = 1;
     s->lat = latency_mode(ctx, (long long)W * H);
     UCHK(enqueue_smooth(ctx, *s, 0, a, b, W, H, passes, do_box != 0));
     HIPCHK(ctx, hipGetLastError());
@@ -1689,6 +1973,7 @@ int ugsm_reconstruct_full(ugsm_ctx *ctx, int slot, const float *d_stackH, const 
     return UGSM_OK;
 }
 
+#ifdef UGSM_DEV_LIB
 int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, const float *d_r, const float *d_thr, float *d_delta,
                           float *d_corr, float *d_third, int n)
 {
@@ -1700,6 +1985,7 @@ int ugsm_stage_poly_probe(ugsm_ctx *ctx, const float *d_c, const float *d_l, con
     HIPCHK(ctx, hipGetLastError());
     return ugsm_wait(ctx, 0);
 }
+#endif
 
 int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const float *d_old3, int W, int H, float *out2)
 {
@@ -1754,6 +2040,7 @@ int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level)
     return UGSM_OK;
 }
 
+#ifdef UGSM_DEV_LIB
 int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n)
 {
     Slot *s;
@@ -1764,7 +2051,9 @@ int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, floa
     HIPCHK(ctx, hipGetLastError());
     return ugsm_wait(ctx, 0);
 }
+#endif
 
+#ifdef UGSM_DEV_LIB
 int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, const float *d_a2, const float *d_s, float *d_q0, float *d_q1,
                           float *d_q2, int n)
 {
@@ -1776,6 +2065,7 @@ int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, c
     HIPCHK(ctx, hipGetLastError());
     return ugsm_wait(ctx, 0);
 }
+#endif
 
 // ---- instrumentation / memory helpers ---------------------------------------------------
 
