@@ -52,11 +52,11 @@ def test_product_library_holds_no_development_kernel(lib):
         return set(name[:int(n)].decode() for n, name in re.findall(rb"_ZN4ugsm(\d+)(k_[a-z_0-9]+)", blob))
     prod, dev = kernels(lib.LIB_PATH), kernels(lib.DEV_LIB_PATH)
     banned = {"k_smooth_march", "k_iter_small", "k_poly_probe", "k_div3_probe", "k_div_probe", "k_cost_ref", "k_warp", "k_smooth_pass", "k_box",
-              "k_sqblur_clamp", "k_rgb_planes", "k_blur_decimate"}
+              "k_sqblur_clamp", "k_blur_decimate"}
     assert not (prod & banned), sorted(prod & banned)
     assert banned <= dev, sorted(banned - dev)
     for k in ("k_cost_march", "k_cost_march4", "k_cost_small", "k_smooth_small", "k_smooth_fused", "k_pyr_base", "k_blur_decimate_tiled", "k_sqblur_tiled",
-              "k_seed", "k_copy_view", "k_lr_check"):
+              "k_seed", "k_copy_view", "k_lr_check", "k_rgb_planes"):
         assert k in prod, k
     # ... and the product refuses the configuration that would need them
     cfg = lib.Config()

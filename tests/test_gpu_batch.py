@@ -71,7 +71,7 @@ def _fovea_batch(c, lib, pairs, W, H, levels, F, offsets, want_pyr=False, slot=0
 def test_full_batch_vs_oracle(lib, orc, B):
     """Every pair of a batch against the oracle: a size whose levels are all batched, an odd one whose coarse levels are smaller than a
     tile, on a one-slot and on a several-slot context (the latency and the several-slot kernel choices)."""
-    for (W, H, lv, slots) in [(640, 480, 12, 1), (333, 251, 10, 2)]:
+    for (W, H, lv, slots) in [(640, 480, 12, 1), (333, 251, 10, 2), (584, 190, 2, 2)]:   # (two levels: no k_pyr_base)
         pairs = _pairs(W, H, B, 500 + W)
         exp = [orc.match_full(L, R, lv) for L, R in pairs]
         with lib.Context(levels=lv, slots=slots, batch=B) as c:

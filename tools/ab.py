@@ -17,6 +17,7 @@ ap.add_argument("--levels", type=int, default=14)
 ap.add_argument("--size", type=int, nargs=2, default=(4928, 3264))
 ap.add_argument("--streams", type=int, default=0, help="ugsm_config.streams (0 = one per slot)")
 ap.add_argument("--fovea", type=int, default=0, help="foveated mode with this many fovea levels (0 = full mode)")
+ap.add_argument("--batch", type=int, default=1, help="pairs per ugsm_submit_*_batch call (1 = the single-pair calls); a configuration may override it with BATCH=n and the slots with SLOTS=n")
 ap.add_argument("--child", action="store_true", help="(internal) measure under the current environment, print the rate")
 ap.add_argument("configs", nargs="*")
 args = ap.parse_args()
@@ -28,30 +29,41 @@ if args.child:
     import torch
     from ug_stereomatcher_amd import _lib, synth
     dev = torch.device("cuda:0")
+    B = int(os.environ.get("BATCH", args.batch))
+    args.slots = int(os.environ.get("SLOTS", args.slots))
+    args.streams = int(os.environ.get("STREAMS", args.streams))
     pairs = []
     for j in range(max(args.slots, 2)):
         L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + j)
         pairs.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
     F = args.fovea
     fw, fh = _lib.fovea_dims(W, H, args.levels, F) if F else (W, H)
-    outs = [torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(args.slots)]
+    outs = [[torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(args.slots)]
     torch.cuda.synchronize()
-    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams) as c:
+    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams, batch=B) as c:
         lib, h = c.lib, c.handle
 
         def run(n):
-            for i in range(n):
+            for i in range((n + B - 1) // B):          # n pairs, B per call
                 s = i % args.slots
                 if i >= args.slots:
                     c.check(lib.ugsm_wait(h, s))
+                if B > 1:
+                    sel = [pairs[(i * B + b) % len(pairs)] for b in range(B)]
+                    dLs, dRs, dOs = [p[0].data_ptr() for p in sel], [p[1].data_ptr() for p in sel], [o.data_ptr() for o in outs[s]]
+                    if F:
+                        c.submit_foveated_batch(s, dLs, dRs, W, H, W * 3, None, dOs)
+                    else:
+                        c.submit_full_batch(s, dLs, dRs, W, H, W * 3, dOs)
+                    continue
                 dL, dR = pairs[i % len(pairs)]
                 if F:
-                    c.check(lib.ugsm_submit_foveated(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, 0, 0, outs[s].data_ptr(), None, None))
+                    c.check(lib.ugsm_submit_foveated(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, 0, 0, outs[s][0].data_ptr(), None, None))
                 else:
-                    c.check(lib.ugsm_submit_full(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, outs[s].data_ptr()))
+                    c.check(lib.ugsm_submit_full(h, s, dL.data_ptr(), dR.data_ptr(), W, H, W * 3, outs[s][0].data_ptr()))
             c.check(lib.ugsm_wait_all(h))
 
-        run(3 * args.slots)
+        run(3 * args.slots * B)
         best = []
         for _ in range(3):
             t0 = time.perf_counter()
@@ -70,7 +82,7 @@ for r in range(args.rounds):
     for i in order:
         env = dict(os.environ, UGSM_DEV="1", **cfgs[i][1])
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--slots", str(args.slots), "--pairs", str(args.pairs), "--levels",
-                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea), "--streams", str(args.streams)], env=env, capture_output=True, text=True, timeout=300)
+                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea), "--streams", str(args.streams), "--batch", str(args.batch)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RATE")]
         if not line:
             print(out.stdout[-2000:], out.stderr[-2000:])

@@ -1,7 +1,7 @@
 // ugsm_kernels_ref.hip -- the plain per-pixel kernels.
 //
 // In the product (libugsm.so): k_seed (a level's starting field where the next level's K-cost does not seed itself), k_copy_view
-// (the fovea / pyramid stacks) and k_lr_check.
+// (the fovea / pyramid stacks), k_lr_check and k_rgb_planes (level 0 of a pyramid of fewer than three levels: BASELINE configs[0]).
 // In libugsm_dev.so only (UGSM_DEV_LIB; round 4): kernel_path 1, one stage per kernel, global memory only -- the
 // plainest possible gfx950 statement of each stage (one thread per output pixel, every neighbourhood re-read through L1/L2).  They
 // exist to (a) get a first correct HIP path, (b) expose per-stage intermediates to the parity tests and (c) A/B the fused kernels of
@@ -103,8 +103,6 @@ void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, i
     hipLaunchKernelGGL(k_lr_check, grid2(W, H), dim3(256), 0, st, left3, right3, W, H, tau, marked);
 }
 
-#ifdef UGSM_DEV_LIB  // kernel_path 1, one kernel per reference stage: the A/B reference of the fused kernels -- in libugsm_dev.so only
-
 // --------------------------------------------------------------------------------------
 // MatchGPULib.cpp:332-338 : rgb8 interleaved -> 3 planar f32
 __global__ void k_rgb_planes(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ planes)
@@ -118,6 +116,13 @@ __global__ void k_rgb_planes(const uint8_t *__restrict__ rgb, int stride, int W,
     planes[n + at] = (float)p[1];
     planes[2 * n + at] = (float)p[2];
 }
+
+void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes)
+{
+    hipLaunchKernelGGL(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
+}
+
+#ifdef UGSM_DEV_LIB  // kernel_path 1, one kernel per reference stage: the A/B reference of the fused kernels -- in libugsm_dev.so only
 
 // --------------------------------------------------------------------------------------
 // MatchGPULib.cpp:1071-1096 + MatchLib.cu:71-156,195-278,311-339.
@@ -314,10 +319,6 @@ __global__ void k_box(const float *__restrict__ s3, float *__restrict__ o3, int 
 
 // ---- launchers -------------------------------------------------------------------------
 
-void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes)
-{
-    hipLaunchKernelGGL(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
-}
 void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
 {
     hipLaunchKernelGGL(k_blur_decimate, grid2(W2, H2, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);

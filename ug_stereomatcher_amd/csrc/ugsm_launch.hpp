@@ -39,6 +39,8 @@ struct Batch {
 // ---- plain per-pixel kernels of the product (ugsm_kernels_ref.hip) ----------------------
 void launch_seed(hipStream_t st, const float *src3, int Ws, int Hs, float *dst3, int Wd, int Hd, int cx, int cy, const Batch *bt = nullptr);
 void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch, const Batch *bt = nullptr);
+// rgb8 -> planar float level 0 (MatchGPULib.cpp:332-338) where k_pyr_base does not apply: pyramids of fewer than three levels, kernel_path 1
+void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes);
 // LR-consistency check (north_star; no reference counterpart): zeroes the confidence of left3 where right3 does not point back within tau
 void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, int H, float tau, unsigned long long *marked);
 
@@ -47,7 +49,6 @@ void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, i
 // that would reach them (kernel_path 1, march_smooth) and the probe entry points are not compiled in.
 #ifdef UGSM_DEV_LIB
 constexpr bool kDevLib = true;
-void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes);
 void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf);
 void launch_sqblur_clamp_ref(hipStream_t st, Img3 src, int W, int H, float *dst3);
 void launch_warp_ref(hipStream_t st, Img3 R, const float *d3, int W, int H, float *Rw3);
@@ -65,7 +66,6 @@ void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const f
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n);
 #else
 constexpr bool kDevLib = false;
-inline void launch_rgb_planes(hipStream_t, const uint8_t *, int, int, int, float *) {}
 inline void launch_blur_decimate_ref(hipStream_t, const float *, int, int, float *, int, int, float) {}
 inline void launch_sqblur_clamp_ref(hipStream_t, Img3, int, int, float *) {}
 inline void launch_warp_ref(hipStream_t, Img3, const float *, int, int, float *) {}

@@ -544,8 +544,9 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
         Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H * nb);
         launch_pyr_base(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad, pb);
     } else {
-        Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
-        launch_rgb_planes(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0]);  // (kernel_path 1: never batched)
+        // (pyramids of fewer than three levels, and kernel_path 1: image by image)
+        Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H * nb);
+        for (int b = 0; b < nb; b++) launch_rgb_planes(pst, rgb[b], stride, s.W, s.H, pyr + b * s.pyr_stride + s.off[0]);
     }
     // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
@@ -609,7 +610,7 @@ bool use_march(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.march_min_pixels < 0) return false;
     const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (lat ? kMarchMinPixelsLatency : kMarchMinPixelsThroughput);
-    return (long long)W * H * pairs >= thr && H >= 6;
+    return (long long)W * H * pairs >= thr;
 }
 
 int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
@@ -633,7 +634,7 @@ bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
     const long long px = (long long)W * H * pairs;
-    if (cfg.kernel_path == 1 || H < 6) return false;
+    if (cfg.kernel_path == 1) return false;
     if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
     return lat && px > small_max_px(cfg) && px <= kMarch4MaxPixels;
 }
