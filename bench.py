@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--workload", default="full16mp", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams the slots are dealt onto (ugsm_config.streams; 0 = one per slot)")
+    ap.add_argument("--batch", type=int, default=4, help="pairs per call at most (ugsm_submit_*_batch: the pairs of a call march through the levels in lockstep, "
+                    "one launch per level of <= 9 Mpx for all of them); 1 = the single-pair calls of rounds 1-3")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-pairs", type=int, default=3, help="pairs of the single-pair event pass after the timed region (0 = skip)")
@@ -225,7 +227,8 @@ def main():
     W, H, mode = wl["W"], wl["H"], wl["mode"]
     slots = max(1, args.slots)
     F = 7
-    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0, streams=args.streams)
+    ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0, streams=args.streams,
+                       batch=max(1, min(args.batch, _lib.UGSM_MAX_BATCH)))
     fw, fh = _lib.fovea_dims(W, H, 14, F)
 
     # synthetic inputs: two distinct pairs per rank, resident in HBM before the timed region
@@ -239,10 +242,11 @@ def main():
     stride = 3 * W
     if rank == 0:
         log(f"synthetic inputs ready in {time.perf_counter() - t0:.1f} s; workload: {wl['desc']}; slots={slots}")
+    nbuf = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1   # result buffers per slot: one per pair of a call
     if mode == "full":
-        outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(slots)]
+        outs = [[torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)] for _ in range(slots)]
     else:
-        outs = [torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev) for _ in range(slots)]
+        outs = [[torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev) for _ in range(nbuf)] for _ in range(slots)]
     # fovea-shard: one coarse-state buffer and one "fine phase has read it" event PER SLOT, so that the broadcast of a later
     # step never overwrites a state an earlier step's fine phase has not copied yet, and the slots overlap
     states = [torch.empty((3, fh, fw), dtype=torch.float32, device=dev) for _ in range(slots)]
@@ -252,37 +256,66 @@ def main():
     torch.cuda.synchronize()
 
     done_t = []   # host clock when a pair's completion was noticed (ugsm_wait on its slot returned), in submission order
+    in_slot = [0] * slots   # pairs of the call each slot holds
+    call_sizes = []         # pairs per call of the region being timed, in submission order
+    B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
+    TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "1"))   # a call takes at most remaining / (TAPER x slots) pairs
 
-    def submit(k, slot=None, stamp=False):
-        s = k % slots if slot is None else slot
+    def wait_slot(s, stamp):
         ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?  (also: the slot's fine phase has consumed states[s])
-        if stamp and k >= slots:
-            done_t.append(time.perf_counter())       # pair k - slots is complete
+        if stamp and in_slot[s]:
+            done_t.extend([time.perf_counter()] * in_slot[s])   # the pairs of the slot's previous call are complete
+        in_slot[s] = 0
+
+    def submit(k, slot=None, stamp=False, n=1):
+        """Pairs k .. k+n-1 as ONE call on a slot (n > 1: ugsm_submit_*_batch)."""
+        s = k % slots if slot is None else slot
+        wait_slot(s, stamp)
+        in_slot[s] = n
+        if n > 1:
+            sel = [pairs[(k + b) % 2] for b in range(n)]
+            dL, dR, dO = [p[0].data_ptr() for p in sel], [p[1].data_ptr() for p in sel], [o.data_ptr() for o in outs[s][:n]]
+            if mode == "full":
+                ctx.submit_full_batch(s, dL, dR, W, H, stride, dO)
+            else:
+                ctx.submit_foveated_batch(s, dL, dR, W, H, stride, None, dO)
+            return
         Lt, Rt = pairs[k % 2]
         if mode == "full":
-            ctx.check(ctx.lib.ugsm_submit_full(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, outs[s].data_ptr()))
+            ctx.check(ctx.lib.ugsm_submit_full(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, outs[s][0].data_ptr()))
         elif mode == "fovea":
             ctx.check(ctx.lib.ugsm_submit_foveated(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, 0, 0,
-                                                   outs[s].data_ptr(), None, None))
+                                                   outs[s][0].data_ptr(), None, None))
         else:
-            ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s], rank)
+            ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s][0], rank)
 
     def run(n, stamp=False):
-        for k in range(n):
-            submit(k, stamp=stamp)
-        for k in range(max(0, n - slots), n):        # the last pairs, in the order they were submitted
-            ctx.check(ctx.lib.ugsm_wait(ctx.handle, k % slots))
-            if stamp:
-                done_t.append(time.perf_counter())
+        """n pairs through the slots.  With --batch B a call takes up to B pairs, as many as the work still queued allows without
+        starving the other slots: min(B, remaining / (2 x slots)), at least 1 -- a host that batches what has piled up, and goes back to
+        single pairs when little is left, so that the region does not end with one slot grinding through a whole batch alone."""
+        del call_sizes[:]
+        k = call = 0
+        while k < n:
+            nb = max(1, min(B, int((n - k) / (TAPER * slots))))
+            submit(k, slot=call % slots, stamp=stamp, n=nb)
+            call_sizes.append(nb)
+            k += nb
+            call += 1
+        for c in range(max(0, call - slots), call):   # the last calls, in the order they were submitted
+            wait_slot(c % slots, stamp)
         ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
 
     def steady_state(n):
-        """Pairs/s between the completion of pair `slots + 1` and of pair `n - slots` of the region just timed (SURVEY 8d defines the
-        metric as steady state with the slots full): the region starts from a drained pipe with all slots submitted in phase and ends
-        by draining them, which costs about one pair's in-flight time whatever the length of the region -- 4 % of 96 steps, more of
-        20 -- and hides changes of a few per cent (VERDICT r03 weak #5).  None when the region is too short to have a middle."""
-        lo, hi = slots, n - slots - 1               # indices into done_t: completion of pair slots + 1 and of pair n - slots
-        if len(done_t) != n or hi - lo < 2:
+        """Pairs/s between the completion of the first call after the slots have been filled once and the completion of the last call
+        before they drain, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
+        from a drained pipe with all slots submitted in phase and ends by draining them, which costs about one pair's in-flight time
+        whatever the length of the region -- 4 % of 96 steps, more of 20 -- and hides changes of a few per cent.
+        None when the region is too short to have a middle."""
+        if len(done_t) != n or len(call_sizes) < 2 * slots + 2:
+            return None
+        lo = sum(call_sizes[:slots + 1]) - 1                 # index of the last pair of call `slots` (0-based): the pipe is full
+        hi = n - sum(call_sizes[-slots:]) - 1                # index of the last pair before the final `slots` calls
+        if hi - lo < 2 or done_t[hi] <= done_t[lo]:
             return None
         return (hi - lo) / (done_t[hi] - done_t[lo])
 
@@ -297,6 +330,12 @@ def main():
         return ud.max_over_ranks(time.perf_counter() - t0, dev)
 
     run(args.warmup)
+    if B > 1:   # ... and one full-size call per slot, untimed: whatever a first batched call sets up is not the workload
+        for s_ in range(slots):
+            submit(0, slot=s_, n=B)
+        ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
+        for s_ in range(slots):
+            in_slot[s_] = 0
     dt = timed(args.steps)
     work = n_gpus if mode != "fovea-shard" else 1
     value = work * args.steps / dt
@@ -320,13 +359,14 @@ def main():
         "vs_baseline": (value / REFERENCE_PAIRS_PER_S[args.workload]) if args.workload in REFERENCE_PAIRS_PER_S else None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl["desc"], "pairs_in_flight_per_gpu": slots, "streams_per_gpu": args.streams or slots, "kernel_path": args.kernel_path,
+        "config": {"workload": wl["desc"], "slots_per_gpu": slots, "pairs_per_call_max": B, "pairs_in_flight_per_gpu": slots * B,
+                   "streams_per_gpu": args.streams or slots, "kernel_path": args.kernel_path,
                    "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}"},
         "value_repeats": repeats,
         # this rank's pairs/s between the completions of pair slots + 1 and pair steps - slots, inside the same timed regions as `value`
         # and `value_repeats` (first entry: the region `value` comes from); x n_gpus for independent replicas
         "steady_state": {"value": (work * steady[0]) if steady[0] else None, "repeats": [(work * v) if v else None for v in steady[1:]],
-                         "unit": "pairs/s", "pairs_counted": max(0, args.steps - 2 * slots - 1),
+                         "unit": "pairs/s", "calls": len(call_sizes), "call_sizes_head_tail": [call_sizes[:6], call_sizes[-6:]],
                          "note": "host clock at the return of ugsm_wait(slot) for every pair, in submission order; the rate between the "
                                  "completion of pair slots+1 and of pair steps-slots: no fill, no drain"},
         "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),
@@ -417,7 +457,7 @@ def main():
     # ---- one pair at a time, un-instrumented, on a ONE-SLOT context: the reference's call pattern (UG_GPU_matcher.cpp:497-694) ------
     if rank == 0 and n_gpus == 1 and mode != "fovea-shard" and args.single_pairs > 0:
         ctx1 = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=1, kernel_path=args.kernel_path, profile_events=0)
-        out1 = outs[0]
+        out1 = outs[0][0]
 
         def one(k):
             Lt, Rt = pairs[k % 2]

@@ -292,7 +292,7 @@ int main(int argc, char **argv)
         float *l1 = R, *l2 = A;
         for (int round = 0; round < 3; round++) {
             timeit("k_pyr_base", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb); });
-#define PYRV(ABL) timeit("k_pyr_base<" #ABL ">", [&]() { hipLaunchKernelGGL(k_pyr_base<ABL>, dim3(((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY)), dim3(256), 0, st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb, (W + BTX - 1) / BTX, ((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY), Batch{1}); })
+#define PYRV(ABL) timeit("k_pyr_base<" #ABL ">", [&]() { hipLaunchKernelGGL(k_pyr_base<ABL>, dim3(((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY)), dim3(256), 0, st, rgb, 3 * W, W, H, L, l1, W1, H1, l2, W2, H2, rb, (W + BTX - 1) / BTX, ((W + BTX - 1) / BTX) * ((H + BTY - 1) / BTY), Batch{1}, PyrWindow{0, 0, 0, 0}); })
             PYRV(1); PYRV(2); PYRV(6); PYRV(8); PYRV(9); PYRV(14); PYRV(15);
             timeit("k_pyr_base level 0 only", [&]() { launch_pyr_base(st, rgb, 3 * W, W, H, L, l1, 0, 0, l2, 0, 0, rb); });
             timeit("blur_decimate sqrt2", [&]() { launch_blur_decimate(st, L, W, H, o, W1, H1, 1.41421356f, nullptr); });

@@ -1386,6 +1386,69 @@ __global__ __launch_bounds__(256) void k_blur_decimate_tiled(const float *__rest
     if (bad && range_bad) *range_bad = 1u;
 }
 
+// K-pyr for the factor-2 levels (level i+2 from level i, MatchGPULib.cpp:1088-1096: sf = 2.0f, sampling site 2i + 1), streaming form
+// (round 4).  The tiled kernel above stages a 133 x 37 parent region per 64 x 16 outputs in LDS with scalar loads and runs at 2-3 TB/s on
+// the levels that matter (16 MP: 43 / 26 / 16 us for levels 3 / 4 / 5, a third of a foveated pair's GPU time once the matching is
+// batched).  Here ONE WAVE owns a strip of 30 output columns x HS output rows of one plane: lane l holds parent column X0 + l, so a
+// parent row is one unit-stride load per lane; ALL 2 HS + 3 parent rows of the strip are requested before the first is used (one memory
+// round trip per wave); the row pass is the systolic DPP chain of the marching K-cost (taps added in the reference's order j = -2..2,
+// the window centred on column c complete in lane c + 2), evaluated densely and used at the odd columns; the column pass slides a window
+// of five row-pass values down the parent rows and emits an output row every second one.  No LDS, no barrier.  Same arithmetic as the
+// tiled kernel: zero padding outside the parent (U2/U3), row pass rounded to binary32 before the column pass; level values are >= 0, so
+// tap5's leading "0 +" is exact (tap5p).
+template <int HS>
+__global__ __launch_bounds__(256) void k_blur_decimate2(const float *__restrict__ src3, int W, int H, float *__restrict__ dst3, int W2, int H2,
+                                                        unsigned *__restrict__ range_bad, int strips_x, int n_strips, Batch bt)
+{
+    if (bt.n > 1) {  // this workgroup's image of the batch (blockIdx.y)
+        src3 = shifted(src3, bt.in[blockIdx.y]);
+        dst3 = shifted(dst3, bt.out[blockIdx.y]);
+        if (range_bad) range_bad += bt.cx[blockIdx.y];  // (the pair the image belongs to)
+    }
+    constexpr int VXO = 30, NR = 2 * HS + 3;  // output columns per strip; parent rows 2 rs - 1 .. 2 (rs + HS - 1) + 3
+    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // strip x plane
+    if (wv >= 3 * n_strips) return;
+    const int plane = wv / n_strips, strip = wv - plane * n_strips;
+    const int sy = strip / strips_x, sx = strip - sy * strips_x;
+    const int lane = threadIdx.x & 63;
+    const int pc = 2 * VXO * sx - 1 + lane;  // parent column of this lane
+    const int rs = sy * HS;
+    const bool cin = pc >= 0 && pc < W;
+    gchar_c *const Sb = uniform_base(src3 + (size_t)plane * W * H);
+    const unsigned coff = (unsigned)clampi(pc, 0, W - 1) * 4u, pitch = (unsigned)W * 4u;
+    float v[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int y = 2 * rs - 1 + j;
+        const float t = ld_at(Sb, (unsigned)clampi(y, 0, H - 1) * pitch + coff);
+        v[j] = (cin && y >= 0 && y < H) ? t : 0.0f;  // zero padding
+    }
+    // the window centred on parent column c is complete in lane (c - X0) + 2; output ix samples column 2 ix + 1
+    const int ix = VXO * sx + ((lane - 4) >> 1);
+    const bool out_lane = lane >= 4 && (lane & 1) == 0 && ix < W2;
+    float *const dst = dst3 + (size_t)plane * W2 * H2;
+    float h[5];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        // row pass (convolutionRowsKernel, MatchLib.cu:127-134): the partial sum travels one lane to the right per tap
+        const float a0 = v[j] * UGSM_G0, a1 = v[j] * UGSM_G1, a2 = v[j] * UGSM_G2;
+        const float p2 = lane_below(a0) + a1;
+        const float p3 = lane_below(p2) + a2;
+        const float p4 = lane_below(p3) + a1;
+        h[j % 5] = lane_below(p4) + a0;
+        if (j >= 4 && (j & 1) == 0) {  // parent row 2 iy + 3 has arrived: output row iy = rs + (j - 4) / 2
+            const int iy = rs + (j - 4) / 2;
+            const float o = tap5p(h[(j + 1) % 5], h[(j + 2) % 5], h[(j + 3) % 5], h[(j + 4) % 5], h[j % 5]);
+            if (out_lane && iy < H2) {
+                dst[(size_t)iy * W2 + ix] = o;
+                bad |= !range_ok(o);
+            }
+        }
+    }
+    if (bad && range_bad) *range_bad = 1u;
+}
+
 // A = colconv_clamp(rowconv_clamp(L^2)) (Square + convolutionRows/ColumnsKernelT, MatchLib.cu:556-578,
 // 1461-1565), once per level: it does not depend on the iteration.  64x16 tile, region +2 clamped.
 __global__ __launch_bounds__(256) void k_sqblur_tiled(Img3 src, int W, int H, float *__restrict__ dst3, int tiles_x, int n_tiles, Batch bt)
@@ -1482,7 +1545,7 @@ constexpr int BTX = 64, BTY = 16, BRW = BTX + 8, BRH = BTY + 4, BC1 = 52, BR1 = 
 template <int ABL = 0>
 __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
                                                   float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
-                                                  unsigned *__restrict__ range_bad, int tiles_x, int n_tiles, Batch bt)
+                                                  unsigned *__restrict__ range_bad, int tiles_x, int n_tiles, Batch bt, PyrWindow win)
 {
     if (bt.n > 1) {  // this workgroup's image of the batch (blockIdx.y): its rgb8 input, its three levels (one offset: they lie in one pyramid)
         const int b = (int)blockIdx.y;
@@ -1491,6 +1554,8 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
         lvl1 = shifted(lvl1, bt.out[b]);
         lvl2 = shifted(lvl2, bt.out[b]);
         if (range_bad) range_bad += bt.cx[b];  // (the pair the image belongs to)
+        win.x0 = (int)(bt.in[b] & 0xffffffffll);  // (its fovea window's origin rides in the otherwise unused input-field offset)
+        win.y0 = (int)(bt.in[b] >> 32);
     }
     __shared__ __attribute__((aligned(16))) float sS[3][BRH * BRW];  // tile + halo 2: region column c at [c], rows 16-byte aligned
     __shared__ __attribute__((aligned(16))) float sT[3][BRH * BTX];  // row pass of every tile column, every region row
@@ -1543,7 +1608,12 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
         sRowSite[tid] = site;
     }
     __syncthreads();
-    if constexpr (!(ABL & 8)) {  // level 0: the tile itself; a thread owns 4 consecutive pixels of one row
+    // Foveated calls (win.w > 0) read level 0 only inside the fovea window (CreateFoveatedPyramid crops after a full build,
+    // MatchGPULib.cpp:1128-1190; here the crop is a view, and what no view covers need not exist): the tiles that do not touch the
+    // window skip their level-0 store -- 193 MB of the 338 MB this kernel writes per 16 MP image.  Levels 1 and 2 are written whole:
+    // levels 3 and 4 are made from them.
+    const bool store0 = win.w <= 0 || (x0 < win.x0 + win.w && x0 + BTX > win.x0 && y0 < win.y0 + win.h && y0 + BTY > win.y0);
+    if (!(ABL & 8) && store0) {  // level 0: the tile itself; a thread owns 4 consecutive pixels of one row
         const size_t n = (size_t)W * H;
         const int r = tid >> 4, c = (tid & 15) * 4;
         const int gx = x0 + c, gy = y0 + r;
@@ -1614,15 +1684,16 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
 }
 
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
-                     int H2, unsigned *range_bad, const Batch *bt)
+                     int H2, unsigned *range_bad, const Batch *bt, PyrWindow win)
 {
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
     const int tiles_x = (W + BTX - 1) / BTX, n_tiles = tiles_x * ((H + BTY - 1) / BTY);
-    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B);
+    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B, win);
 }
 
+int blur_decimate_streaming = 1;  // (development: UGSM_PYR_STREAM=0 -> the tiled kernel for the factor-2 levels too)
 // bt (optional): bt->n IMAGES in one launch -- image j reads src3 + in[j], writes dst3 + out[j] and reports into range_bad[cx[j]]
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt)
 {
@@ -1641,6 +1712,16 @@ void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float
         return;
     }
 #endif
+    if (sf == 2.0f && blur_decimate_streaming) {  // every level from the third on: the streaming form
+        const long long out_px = (long long)W2 * H2 * images;
+        const int hs = out_px >= 400000 ? 16 : (out_px >= 40000 ? 8 : 4);  // short strips where there are few: a launch lasts as long as one wave
+        const int strips_x = (W2 + 29) / 30, n_strips = strips_x * ((H2 + hs - 1) / hs);
+        const dim3 grid((3 * n_strips + 3) / 4, images);
+        if (hs == 16) hipLaunchKernelGGL(k_blur_decimate2<16>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        else if (hs == 8) hipLaunchKernelGGL(k_blur_decimate2<8>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        else hipLaunchKernelGGL(k_blur_decimate2<4>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        return;
+    }
     const int tiles_x = (W2 + PTX - 1) / PTX, n_tiles = tiles_x * ((H2 + PTY - 1) / PTY);
     hipLaunchKernelGGL(k_blur_decimate_tiled, dim3(n_tiles, images, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles, B);
 }

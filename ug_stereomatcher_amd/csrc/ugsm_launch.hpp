@@ -114,11 +114,17 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
                          int tile_class = 0);
 int smooth_tile_rows(int W, int H, int latency, int pairs = 1);
 extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
+extern int blur_decimate_streaming;  // (development: UGSM_PYR_STREAM)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt = nullptr);
+// The part of level 0 a foveated call reads: the fovea window (w x h at (x0, y0), level-0 pixels); w <= 0: everything (full mode).  In a
+// batched launch the origin of image b's window is bt->in[b] = (y0 << 32) | x0.
+struct PyrWindow {
+    int x0, y0, w, h;
+};
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
-                     int H2, unsigned *range_bad, const Batch *bt = nullptr);
+                     int H2, unsigned *range_bad, const Batch *bt = nullptr, PyrWindow win = PyrWindow{0, 0, 0, 0});
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3, const Batch *bt = nullptr);
 // X, Y, Z planes from the full-resolution (dx, dy) and the two 3x4 projection matrices
 void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, int W, int H, const double *P1, const double *P2, float *xyz);

@@ -358,13 +358,17 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
     // (pairs of a batch start on 256-byte boundaries: the kernels' 16-byte accesses stay aligned whatever the level sizes add up to)
     s.pyr_stride = (tot + 63) & ~(size_t)63;
     s.lvl_stride = (lvl + 63) & ~(size_t)63;
-    const size_t pyr_need = nb > 1 ? s.pyr_stride * nb : tot;
+    // sized for the batch the context was created for (ugsm_config.batch) even when this call brings fewer pairs: a host that batches
+    // what has piled up alternates between call sizes, and a reallocation (hipFree + hipMalloc of gigabytes: a device-wide
+    // synchronisation) must not land in the middle of its stream of calls
+    const int cap_pairs = std::max(nb, std::min(std::max(ctx->cfg.batch, 1), kMaxBatch));
+    const size_t pyr_need = cap_pairs > 1 ? s.pyr_stride * cap_pairs : tot;
     if (pyr_need > s.pyr_cap) {
         size_t cap = s.pyr_cap;
         UCHK(grow(ctx, s.pyrL, cap, pyr_need));
         UCHK(grow(ctx, s.pyrR, s.pyr_cap, pyr_need));
     }
-    UCHK(ensure_level_bufs(ctx, s, nb > 1 ? s.lvl_stride * nb : lvl));
+    UCHK(ensure_level_bufs(ctx, s, cap_pairs > 1 ? s.lvl_stride * cap_pairs : lvl));
     return UGSM_OK;
 }
 
@@ -469,6 +473,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     geti("UGSM_ITER_SMALL", k.iter_small);
     if (const char *e = getenv("UGSM_BATCH_MAX_PIXELS")) k.batch_max_px = atoll(e);
     if (set_globals) geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);  // (a process-wide tuning variable, like UGSM_MARCH_AGE)
+    if (set_globals) geti("UGSM_PYR_STREAM", blur_decimate_streaming);
     if (const char *e = set_globals ? getenv("UGSM_MARCH_AGE") : nullptr) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
@@ -524,7 +529,13 @@ Batch make_batch(const Slot &s, Grp g, const Img3 *views = nullptr, const SeedMa
 
 // CreatePyramidFromImage (MatchGPULib.cpp:1033-1125) for the left OR the right image of every pair of the call: rgb[b] -> pyr + b * pyr_stride.
 // The images of a batch go through every pyramid kernel together (one launch per level for all of them).
-int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, int stride, float *pyr, hipStream_t stream = nullptr)
+// What a foveated call reads of level 0: every pair's fovea window (the level-0 crop of fovea_geometry); k_pyr_base then stores level 0
+// only where a window lies.  Full-mode calls and ugsm_submit_pyramids (window not known yet) pass none.
+struct FoveaWin {
+    int w = 0, h = 0;
+    int x0[kMaxBatch], y0[kMaxBatch];
+};
+int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, int stride, float *pyr, hipStream_t stream = nullptr, const FoveaWin *win = nullptr)
 {
     const hipStream_t pst = stream ? stream : s.st;  // (launches on the side stream are not bracketed by events: Timer records on s.st)
     const int levels = s.levels, nb = s.nb;
@@ -538,11 +549,16 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
         bt.in[j] = bt.out[j] = (long long)(j * s.pyr_stride * sizeof(float));
         bt.cx[j] = j;
     }
+    Batch bt0 = bt;  // k_pyr_base: the input-field offsets carry the pairs' window origins instead
+    if (win)
+        for (int j = 0; j < nb; j++) bt0.in[j] = ((long long)win->y0[j] << 32) | (unsigned)win->x0[j];
+    const PyrWindow pw = win ? PyrWindow{win->x0[0], win->y0[0], win->w, win->h} : PyrWindow{0, 0, 0, 0};
     const Batch *const pb = nb > 1 ? &bt : nullptr;
     s.cur_level = 0;
     if (base) {
         Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H * nb);
-        launch_pyr_base(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad, pb);
+        launch_pyr_base(pst, rgb[0], stride, s.W, s.H, pyr + s.off[0], pyr + s.off[1], s.w[1], s.h[1], pyr + s.off[2], s.w[2], s.h[2], s.range_bad,
+                        nb > 1 ? &bt0 : nullptr, pw);
     } else {
         // (pyramids of fewer than three levels, and kernel_path 1: image by image)
         Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H * nb);
@@ -588,9 +604,11 @@ bool latency_mode(const ugsm_ctx *ctx, long long frame_px)
     return ctx->cfg.slots == 1 || frame_px < kBusyFramePixels;
 }
 
-// Levels of at most this many pixels go through a batched call as ONE launch for all its pairs; larger levels fill the chip pair by
-// pair and are launched so (one launch per pair, one after the other on the slot's stream).
-constexpr long long kBatchMaxPixels = 2200000;
+// Levels of at most this many pixels go through a batched call as ONE launch for all its pairs; larger levels are launched pair by
+// pair (one after the other on the slot's stream).  Four slots x four 16 MP pairs, tools/ab.py, same box: 9 Mpx (levels 1-13 batched)
+// +1.9 % against 2.2 Mpx (levels 3-13), 4.5 Mpx +1.2 %, everything +1.5 %; 0.6 Mpx -1 %, 0.15 Mpx -2.8 %.  Level 0 stays per pair: its
+// marching K-cost keeps the strips by age class, which count on one pair's strips filling the chip exactly.
+constexpr long long kBatchMaxPixels = 9000000;
 bool batch_level(const ugsm_ctx *ctx, int W, int H)
 {
     const long long thr = ctx->batch_max_px > 0 ? ctx->batch_max_px : (ctx->batch_max_px < 0 ? 0 : kBatchMaxPixels);
@@ -923,7 +941,8 @@ int enqueue_side_A(ugsm_ctx *ctx, Slot &s, int a_from)
 // The pyramids of every pair of the call (s.nb = nb pairs; rgbL / rgbR: nb device pointers).
 // a_from: the levels a_from .. top get their A = G_clamp * L^2 precomputed on the side stream (full mode: 0; foveated: F-1, the
 // fine levels work on crops whose A is clamped at the crop's own border and is computed in line); < 0: none.
-int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR, int nb, int W, int H, int stride, int a_from = -1)
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR, int nb, int W, int H, int stride, int a_from = -1,
+                     const FoveaWin *win = nullptr)
 {
     if (!d_rgbL || !d_rgbR || nb < 1 || nb > kMaxBatch) return UGSM_ERR_BAD_ARG;
     for (int b = 0; b < nb; b++)
@@ -938,26 +957,45 @@ int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *d_rgb
     const bool fork = side_stream_ok(ctx, s);
     s.a_from = -1;
     if (!fork) {
-        UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL));
-        UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR));
-        s.have_pyr = nb == 1;  // (the fovea-shard entry points work on single pairs)
+        UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL, nullptr, win));
+        UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR, nullptr, win));
+        s.have_pyr = nb == 1 && !win;  // (the fovea-shard entry points work on single pairs, and on whole pyramids)
         return UGSM_OK;
     }
     // the side stream starts after everything enqueued on this slot so far (the previous pair still reads pyrR and Apyr)
     HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
     HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
-    UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2));
+    UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2, win));
     HIPCHK(ctx, hipEventRecord(s.ev_R, s.st2));
-    UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL));
+    UCHK(build_pyramids(ctx, s, si, d_rgbL, stride, s.pyrL, nullptr, win));
     if (a_from >= 0) UCHK(enqueue_side_A(ctx, s, a_from));
     HIPCHK(ctx, hipStreamWaitEvent(s.st, s.ev_R, 0));
     HIPCHK(ctx, hipGetLastError());
-    s.have_pyr = true;
+    s.have_pyr = !win;
     return UGSM_OK;
 }
-int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int a_from = -1)
+int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int a_from = -1,
+                     const FoveaWin *win = nullptr)
 {
-    return enqueue_pyramids(ctx, s, si, &d_rgbL, &d_rgbR, 1, W, H, stride, a_from);
+    return enqueue_pyramids(ctx, s, si, &d_rgbL, &d_rgbR, 1, W, H, stride, a_from, win);
+}
+
+// the windows of a foveated call's pairs (n offsets), for enqueue_pyramids
+int fovea_windows(const ugsm_ctx *ctx, int W, int H, int n, const int *off_x, const int *off_y, FoveaWin &win)
+{
+    const int F = ctx->cfg.fovea_levels;
+    int w[UGSM_MAX_LEVELS], h[UGSM_MAX_LEVELS];
+    UCHK(level_dims(W, H, ctx->cfg.levels, w, h));
+    if (F < 2 || F > ctx->cfg.levels || n < 1 || n > kMaxBatch) return UGSM_ERR_BAD_ARG;
+    for (int b = 0; b < n; b++) {
+        FoveaGeom g;
+        fovea_geometry(w, h, F, off_x[b], off_y[b], g);
+        win.w = g.fw;
+        win.h = g.fh;
+        win.x0[b] = g.ox[0];
+        win.y0[b] = g.oy[0];
+    }
+    return UGSM_OK;
 }
 
 // A of full-frame level i if it was precomputed on the side stream (the main stream is made to wait for it here), else null
@@ -1600,7 +1638,9 @@ int ugsm_submit_foveated(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     const int F = ctx->cfg.fovea_levels;
     if (F < 2) return UGSM_ERR_BAD_ARG;
-    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, F - 1));
+    FoveaWin win;
+    UCHK(fovea_windows(ctx, W, H, 1, &off_x, &off_y, win));
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, W, H, stride, F - 1, &win));
     // level F-1's state is parked in the (otherwise idle) A buffer's tail? No: use a dedicated spot
     // at the end of d_stack's level F-1 block is not 3-plane contiguous, so stage through hout.
     const size_t fn3 = 3 * (size_t)s->w[F - 1] * s->h[F - 1];
@@ -1656,9 +1696,13 @@ int ugsm_submit_foveated_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *co
     UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
     const size_t fn3 = (3 * (size_t)fw * fh + 63) & ~(size_t)63;  // level F-1's state of every pair, staged in the slot's hout
     UCHK(grow(ctx, s->hout, s->hout_cap, std::max(fn3 * n, s->hout_cap)));
+    FoveaWin win;
+    UCHK(fovea_windows(ctx, W, H, n, ox, oy, win));
     if (n == 1 || batch_runs_pair_by_pair(ctx)) {
         for (int b = 0; b < n; b++) {
-            UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL[b], d_rgbR[b], W, H, stride, F - 1));
+            FoveaWin w1;
+            UCHK(fovea_windows(ctx, W, H, 1, ox + b, oy + b, w1));
+            UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL[b], d_rgbR[b], W, H, stride, F - 1, &w1));
             UCHK(enqueue_fovea_coarse(ctx, *s, slot, s->hout));
             UCHK(enqueue_fovea_fine(ctx, *s, slot, s->hout, ox[b], oy[b], d_stack[b], d_pyrL ? d_pyrL[b] : nullptr, d_pyrR ? d_pyrR[b] : nullptr));
         }
@@ -1666,7 +1710,7 @@ int ugsm_submit_foveated_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *co
     }
     float *state[UGSM_MAX_BATCH];
     for (int b = 0; b < n; b++) state[b] = s->hout + b * fn3;
-    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, n, W, H, stride));
+    UCHK(enqueue_pyramids(ctx, *s, slot, d_rgbL, d_rgbR, n, W, H, stride, -1, &win));
     UCHK(enqueue_fovea_coarse(ctx, *s, slot, state));
     UCHK(enqueue_fovea_fine(ctx, *s, slot, state, ox, oy, d_stack, d_pyrL, d_pyrR));
     return mark_done(ctx, *s);
@@ -1753,7 +1797,9 @@ static int match_foveated_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, 
     float *d_state = s->hout, *d_stack = d_state + 3 * fn;
     float *d_pl = pyrL ? d_stack + 3 * stackn : nullptr;
     float *d_pr = pyrR ? d_stack + 3 * stackn + (pyrL ? 3 * stackn : 0) : nullptr;
-    UCHK(enqueue_pyramids(ctx, *s, slot, s->rgbL, s->rgbR, W, H, stride, F - 1));
+    FoveaWin win;
+    UCHK(fovea_windows(ctx, W, H, 1, &off_x, &off_y, win));
+    UCHK(enqueue_pyramids(ctx, *s, slot, s->rgbL, s->rgbR, W, H, stride, F - 1, &win));
     UCHK(enqueue_fovea_coarse(ctx, *s, slot, d_state));
     UCHK(enqueue_fovea_fine(ctx, *s, slot, d_state, off_x, off_y, d_stack, d_pl, d_pr));
     HIPCHK(ctx, hipMemcpyAsync(stackH, d_stack, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
@@ -1792,7 +1838,9 @@ int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *
     const size_t fn = (size_t)fw * fh, stackn = (size_t)F * fn, n = (size_t)W * H;
     UCHK(grow(ctx, s->hout, s->hout_cap, 3 * fn + 3 * stackn + 3 * n));  // [state][stack][full field]
     float *d_state = s->hout, *d_stack = d_state + 3 * fn, *d_full = d_stack + 3 * stackn;
-    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, F - 1));
+    FoveaWin win;
+    UCHK(fovea_windows(ctx, W, H, 1, &off_x, &off_y, win));
+    UCHK(enqueue_pyramids(ctx, *s, 0, s->rgbL, s->rgbR, W, H, stride, F - 1, &win));
     UCHK(enqueue_fovea_coarse(ctx, *s, 0, d_state));
     UCHK(enqueue_fovea_fine(ctx, *s, 0, d_state, off_x, off_y, d_stack, nullptr, nullptr));
     UCHK(ugsm_reconstruct_full(ctx, 0, d_stack, d_stack + stackn, d_stack + 2 * stackn, W, H, off_x, off_y, d_full));
