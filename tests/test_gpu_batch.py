@@ -258,3 +258,51 @@ def test_16mp_batches_vs_single_calls(lib):
             assert_bit_equal(c.to_host(dS[8 + j], (3, F, fh, fw)), c.to_host(dS[j], (3, F, fh, fw)), f"16 MP foveated, batch of 8, pair {j} at {offs[j]} vs the single call")
         for p in dL + dR + dS:
             c.free(p)
+
+
+def test_two_contexts_in_one_process_with_stream_priority_pools(lib):
+    """ugsm_config.stream_priority: HIP deals streams onto four hardware queues PER PRIORITY LEVEL, and two
+    streams on one queue run strictly one after the other -- so a second context whose slots sit in the same pool as the first one's
+    shares its queues.  A host that runs two contexts gives them different pools (default: slots 0-3 at the greatest priority; 3: all at
+    the least) and each then runs at the rate a context alone in the process reaches; results do not depend on any of it."""
+    import time
+    import torch
+    from ug_stereomatcher_amd import synth
+    W, H, lv, slots, n = 1920, 1080, 14, 4, 96
+    dev = torch.device("cuda:0")
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 77)
+    dL, dR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(2 * slots)]
+    torch.cuda.synchronize()
+
+    def rate(c, o):
+        def run(k):
+            for i in range(k):
+                s = i % slots
+                c.check(c.lib.ugsm_wait(c.handle, s))
+                c.check(c.lib.ugsm_submit_full(c.handle, s, dL.data_ptr(), dR.data_ptr(), W, H, 3 * W, o[s].data_ptr()))
+            c.check(c.lib.ugsm_wait_all(c.handle))
+        run(2 * slots)
+        best = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            run(n)
+            best = max(best, n / (time.perf_counter() - t0))
+        return best
+
+    with lib.Context(levels=lv, slots=slots) as a:
+        alone = rate(a, outs[:slots])
+        ref = outs[0].clone()
+        with lib.Context(levels=lv, slots=slots, stream_priority=3) as b:       # a pool of its own: the least priority
+            rb = rate(b, outs[slots:])
+            ra = rate(a, outs[:slots])
+            assert torch.equal(outs[slots].view(torch.int32), ref.view(torch.int32)), "results do not depend on the stream priorities"
+        with lib.Context(levels=lv, slots=slots, stream_priority=1) as d:       # the opt-out: the process default priority
+            rd = rate(d, outs[slots:])
+            assert torch.equal(outs[slots].view(torch.int32), ref.view(torch.int32))
+    print(f"pairs/s at 1080p, four slots: context alone {alone:.0f}; second context in the least-priority pool {rb:.0f}, the first again {ra:.0f}; "
+          f"a context at the process default priority (torch holds the null stream's queue) {rd:.0f}")
+    assert rb >= 0.85 * alone and ra >= 0.85 * alone, (alone, rb, ra)
+    for bad in (4, -1):
+        with pytest.raises(lib.UgsmError):
+            lib.Context(levels=lv, stream_priority=bad)

@@ -509,6 +509,40 @@ int main(int argc, char **argv)
             run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p1", 1, 0);
         }
     }
+    if (argc > 4 && atoi(argv[4]) == 17) {  // k_smooth_pipe against k_smooth_fused (112-column tile): bit-exactness and time
+        unsigned *queue; CK(hipMalloc(&queue, 64));
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        for (int wgs : {256, 512, 128}) {
+            smooth_pipe_workgroups = wgs;
+            for (int box = 0; box < 2; box++)
+                for (int P : {5, 1, 0, 3}) {
+                    if (P == 0 && !box) continue;
+                    for (int rows : {36, 29}) {
+                        launch_smooth_fused(st, d, o, W, H, P, box, rows);
+                        CK(hipMemsetAsync(queue, 0, 64, st));
+                        launch_smooth_pipe(st, d, o2, W, H, P, box, rows, queue);
+                        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                        CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+                        size_t bad = 0;
+                        for (size_t i = 0; i < 3 * n; i++) bad += memcmp(&ha[i], &hb[i], 4) != 0;
+                        printf("wgs %d P=%d box=%d rows=%d: %zu of %zu values differ%s\n", wgs, P, box, rows, bad, 3 * n, bad ? "  <-- MISMATCH" : "");
+                    }
+                }
+            for (int round = 0; round < 2; round++) {
+                char nm[64];
+                timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 1, 36); });
+                snprintf(nm, sizeof nm, "k_smooth_pipe p5+box wgs%d", wgs);
+                timeit(nm, [&]() { CK(hipMemsetAsync(queue, 0, 64, st)); launch_smooth_pipe(st, d, o2, W, H, 5, 1, 36, queue); });
+                timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0, 36); });
+                snprintf(nm, sizeof nm, "k_smooth_pipe p5 wgs%d", wgs);
+                timeit(nm, [&]() { CK(hipMemsetAsync(queue, 0, 64, st)); launch_smooth_pipe(st, d, o2, W, H, 5, 0, 36, queue); });
+                snprintf(nm, sizeof nm, "k_smooth_pipe p0 wgs%d", wgs);
+                timeit(nm, [&]() { CK(hipMemsetAsync(queue, 0, 64, st)); launch_smooth_pipe(st, d, o2, W, H, 0, 0, 36, queue); });
+            }
+        }
+        return 0;
+    }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });
     timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 1); });
     {

@@ -696,15 +696,15 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #endif
 // FIXH: the tile is STY rows high whatever `sty_arg` says -- the height folds into the loop bounds, 2 % faster at level 0 than the
 // same kernel with the height in a register (208 against 212.5 us); the launcher picks it whenever the height is STY.
-template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false>
-__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
-                                                  int tiles_x, int n_tiles, int sty_arg, Batch bt)
+// The passes, the box and the copy-out of ONE tile whose region (tile + halo, clamped onto the image) is in LDS at f0 / f1 / f2 -- shared by
+// k_smooth_fused (one tile per workgroup, loaded through registers) and k_smooth_pipe (a workgroup walks tiles; the next tile's region
+// arrives by LDS-DMA in a second buffer meanwhile).  Every thread of the workgroup calls it; it contains barriers.
+// PIPE (k_smooth_pipe): the wave's LDS-DMA loads of the NEXT tile (issued before this call) are waited for right before this tile's
+// global stores are issued -- by then they have long arrived, and the stores themselves are never waited for.
+template <int STX, int STY, int NT, int VAR, bool FIXH, bool PIPE = false>
+__device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f1, float *const f2, float *__restrict__ o3, const int W, const int H, const int P,
+                                                 const int do_box, const int tile_x, const int tile_y, const int sty)
 {
-    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
-        s3 = shifted(s3, bt.in[blockIdx.y]);
-        o3 = shifted(o3, bt.out[blockIdx.y]);
-    }
-    const int sty = FIXH ? STY : sty_arg;
     constexpr int HX = 8, HY = 7;
     constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
     constexpr int LW = RWID + UGSM_SMOOTH_PAD(STX);  // LDS row stride (rows 16-B aligned)
@@ -714,52 +714,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
                                              // that a quad's west / east neighbours sit in the neighbouring lanes
     constexpr int RG = (NT / 64) * RPW;      // row groups
     constexpr int MAXR = (LH + RG - 1) / RG; // rows per thread per pass
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // A tile is `sty` <= STY rows high (the host picks the height that fills whole rounds of workgroups: smooth_tile_rows);
-    // the region is LHr rows, the LDS planes are that long.
+    (void)LH;
     const int LHr = sty + 2 * HY;
-    float *f0 = smem, *f1 = smem + LHr * LW, *f2 = smem + 2 * LHr * LW;
-
     const int tid = threadIdx.x;
-    int tile_x, tile_y;
-    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
     const int tx0 = tile_x * STX, ty0 = tile_y * sty;
     const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
     const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
-
-    // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
-    // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
-    {
-        const int r_lo = HY - h, r_hi = LHr - (HY - h);
-        constexpr int NLD = (LH * RWID + NT - 1) / NT;
-        float v[NLD][3];
-#pragma unroll
-        for (int u = 0; u < NLD; u++) {
-            const int it = tid + u * NT;
-            const int r = it / RWID, c = it - r * RWID;
-            const bool need = r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
-            const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
-            // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
-            // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
-            const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
-            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
-            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
-            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < NLD; u++) {
-            const int it = tid + u * NT;
-            const int r = it / RWID, c = it - r * RWID;
-            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
-                f0[r * LW + c] = v[u][0];
-                f1[r * LW + c] = v[u][1];
-                f2[r * LW + c] = v[u][2];
-            }
-        }
-    }
-    __syncthreads();
-
     const int lane = tid & 63;
     const int q = lane % QW, rg = (tid >> 6) * RPW + lane / QW;
     const int c0 = q * 4, gx0 = x0 + c0;
@@ -979,6 +940,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
         if ((W & 3) == 0) {  // rows are 16-byte aligned: the quads leave as they are (a wave's lanes hold consecutive quads of a row)
+            if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < CMAXR; u++) {
                 const int r = HY + brg + u * BRG;
@@ -1002,6 +964,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
         __syncthreads();
+        if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int it = tid; it < STX * sty; it += NT) {
             const int r = it / STX, c = it - r * STX;
             const int gx = tx0 + c, gy = ty0 + r;
@@ -1014,6 +977,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
             }
         }
     } else {
+        if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int it = tid; it < STX * sty; it += NT) {
             const int r = it / STX, c = it - r * STX;
             const int gx = tx0 + c, gy = ty0 + r;
@@ -1027,6 +991,190 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused
         }
     }
 }
+
+template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false>
+__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
+                                                  int tiles_x, int n_tiles, int sty_arg, Batch bt)
+{
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        s3 = shifted(s3, bt.in[blockIdx.y]);
+        o3 = shifted(o3, bt.out[blockIdx.y]);
+    }
+    const int sty = FIXH ? STY : sty_arg;
+    constexpr int HX = 8, HY = 7;
+    constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
+    constexpr int LW = RWID + UGSM_SMOOTH_PAD(STX);  // LDS row stride (rows 16-B aligned)
+    constexpr int LH = STY + 2 * HY;         // region rows of the TALLEST tile (register arrays and unrolled loops are sized for it)
+    constexpr int QW = RWID / 4;             // quad columns
+    constexpr int RPW = 64 / QW;             // whole region rows per wave: lane -> (row lane / QW, quad lane % QW), so
+                                             // that a quad's west / east neighbours sit in the neighbouring lanes
+    constexpr int RG = (NT / 64) * RPW;      // row groups
+    constexpr int MAXR = (LH + RG - 1) / RG; // rows per thread per pass
+    (void)QW; (void)RPW; (void)RG; (void)MAXR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // A tile is `sty` <= STY rows high (the host picks the height that fills whole rounds of workgroups: smooth_tile_rows);
+    // the region is LHr rows, the LDS planes are that long.
+    const int LHr = sty + 2 * HY;
+    float *f0 = smem, *f1 = smem + LHr * LW, *f2 = smem + 2 * LHr * LW;
+
+    const int tid = threadIdx.x;
+    int tile_x, tile_y;
+    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
+    const int tx0 = tile_x * STX, ty0 = tile_y * sty;
+    const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
+    const size_t n = (size_t)W * H;
+    const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
+
+    // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
+    // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
+    {
+        const int r_lo = HY - h, r_hi = LHr - (HY - h);
+        constexpr int NLD = (LH * RWID + NT - 1) / NT;
+        float v[NLD][3];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * NT;
+            const int r = it / RWID, c = it - r * RWID;
+            const bool need = r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h);
+            const int gx = clampi(x0 + c, 0, W - 1), gy = clampi(y0 + r, 0, H - 1);
+            // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
+            // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
+            const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
+            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
+            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
+            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int it = tid + u * NT;
+            const int r = it / RWID, c = it - r * RWID;
+            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+                f0[r * LW + c] = v[u][0];
+                f1[r * LW + c] = v[u][1];
+                f2[r * LW + c] = v[u][2];
+            }
+        }
+    }
+    __syncthreads();
+
+    smooth_tile_body<STX, STY, NT, VAR, FIXH>(f0, f1, f2, o3, W, H, P, do_box, tile_x, tile_y, sty);
+}
+
+#ifdef UGSM_DEV_LIB  // k_smooth_pipe: built, bit-exact, measured 17-20 % SLOWER than k_smooth_fused (profiles/r04_kbench_smooth_pipe.txt) -- libugsm_dev.so / tools only
+// =========================================================================================
+// K-smooth, pipelined form (round 4): k_smooth_fused alternates a memory phase (tile + halo in, 77 KB; tile out) and a
+// compute phase (the passes) per workgroup, and with two workgroups per CU the phases add up instead of overlapping (a launch with zero
+// passes takes 82 us at 16 MP, five passes 185 us: DESIGN.md section 4).  Here ONE workgroup of sixteen waves per CU walks tiles it takes
+// from a queue and owns TWO tile buffers: while it computes tile k in one, the region of tile k + 1 arrives in the other by LDS-DMA
+// (global_load_lds: no registers, no instruction slots of the computing waves beyond the issue), and tile k's stores are issued and
+// never waited for.  Same passes, same box, same copy-out (smooth_tile_body): bit-identical.
+// MEASURED (tools/kbench mode 17, 16 MP, same box): with zero passes it runs at the chip's copy rate like k_smooth_fused (83 us), but five
+// passes take 224 us against 185 us, five passes + box 270 against 226: what the prefetch saves is less than what ONE sixteen-wave
+// workgroup per CU loses at its ten to twelve barriers per tile -- with two eight-wave workgroups per CU (k_smooth_fused) a workgroup
+// stalled at a barrier leaves the SIMDs to the other one's tile; here all sixteen waves stall together (14.3 us per tile and CU against
+// 11.8, for 7.9 us of VALU issue).  Two workgroups per CU with two buffers each would need 4 x 77 KB of LDS.  Not used.
+// =========================================================================================
+typedef __attribute__((address_space(1))) const void gvoid_c;
+typedef __attribute__((address_space(3))) void lvoid;
+template <int STY, bool FIXH>
+__global__ __launch_bounds__(1024) void k_smooth_pipe(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box, int tiles_x,
+                                                      int n_tiles, int sty_arg, unsigned *__restrict__ queue, Batch bt)
+{
+    constexpr int STX = 112, NT = 1024, HX = 8, HY = 7, RWID = STX + 2 * HX, LW = RWID;
+    static_assert(UGSM_SMOOTH_PAD(112) == 0 && RWID == 128, "an LDS-DMA instruction fills whole region rows: they must be contiguous");
+    if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
+        s3 = shifted(s3, bt.in[blockIdx.y]);
+        o3 = shifted(o3, bt.out[blockIdx.y]);
+        queue += blockIdx.y;
+    }
+    const int sty = FIXH ? STY : sty_arg;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_next;
+    const int LHr = sty + 2 * HY;
+    const int plane_f = LHr * LW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t n = (size_t)W * H;
+    // the region of tile t (clamped onto the image) -> buffer b, asynchronously; every wave issues its share
+    auto issue = [&](const int t, float *const b) {
+        const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
+        const int x0 = tile_x * STX - HX, y0 = tile_y * sty - HY;
+        const bool interior = x0 >= 0 && x0 + RWID <= W && y0 >= 0 && y0 + LHr <= H && (W & 3) == 0;
+        if (interior) {  // 16 bytes per lane: an instruction fills two region rows (the rows are 16-byte aligned in memory when W is a multiple of 4)
+            const int half = (LHr + 1) >> 1;
+            for (int j = wave; j < 3 * half; j += NT / 64) {
+                const int f = j / half, rp = j - f * half;
+                const int r = 2 * rp + (lane >> 5), c = (lane & 31) * 4;
+                if (r < LHr) {
+                    const float *g = s3 + f * n + (size_t)(y0 + r) * W + (x0 + c);
+                    __builtin_amdgcn_global_load_lds((gvoid_c *)g, (lvoid *)(b + f * plane_f + 2 * rp * LW), 16, 0, 0);
+                }
+            }
+        } else {  // the tiles on the frame (and levels whose rows are not 16-byte aligned): 4 bytes per lane from the clamped pixel, half a region row per instruction
+            for (int j = wave; j < 6 * LHr; j += NT / 64) {
+                const int f = j / (2 * LHr), rem = j - f * 2 * LHr;
+                const int r = rem >> 1, c = (rem & 1) * 64 + lane;
+                const float *g = s3 + f * n + (size_t)clampi(y0 + r, 0, H - 1) * W + clampi(x0 + c, 0, W - 1);
+                __builtin_amdgcn_global_load_lds((gvoid_c *)g, (lvoid *)(b + f * plane_f + r * LW + (rem & 1) * 64), 4, 0, 0);
+            }
+        }
+    };
+    // the first two tiles of this workgroup
+    if (tid == 0) s_next = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    int t = s_next;
+    __syncthreads();
+    if (t >= n_tiles) return;
+    float *const buf0 = smem, *const buf1 = smem + 3 * plane_f;
+    issue(t, buf0);
+    if (tid == 0) s_next = (int)atomicAdd(queue, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int tn = s_next, cur = 0;
+    for (;;) {
+        if (tn < n_tiles) issue(tn, cur ? buf0 : buf1);
+        int got = 0;
+        if (tid == 0) got = (int)atomicAdd(queue, 1u);  // the tile after next (its latency hides behind this tile's passes)
+        const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
+        float *const f0 = cur ? buf1 : buf0, *const f1 = f0 + plane_f, *const f2 = f1 + plane_f;
+        smooth_tile_body<STX, STY, NT, 0, FIXH, true>(f0, f1, f2, o3, W, H, P, do_box, tile_x, tile_y, sty);
+        if (tid == 0) s_next = got;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every path of the tile body has waited already; the no-store corner cases too now)
+        __syncthreads();  // the next tile's region is complete in LDS; nobody reads this tile's buffer any more
+        if (tn >= n_tiles) break;
+        t = tn;
+        tn = s_next;
+        cur ^= 1;
+    }
+}
+
+int smooth_pipe_workgroups = 256;  // persistent workgroups per pair of a launch: one per CU
+// queue: one zeroed counter per pair of the launch (the caller clears it on the stream before the launch)
+void launch_smooth_pipe(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows, unsigned *queue, const Batch *bt)
+{
+    constexpr int STY = kSmoothTileRowsMax, LWp = 128;
+    Batch one{};
+    one.n = 1;
+    const Batch &B = bt ? *bt : one;
+    const int pairs = B.n > 1 ? B.n : 1;
+    int sty = tile_rows;
+    if (sty < 1 || sty > STY) sty = STY;
+    const size_t bytes = 2 * 3 * (size_t)(sty + 14) * LWp * sizeof(float);
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_relaxed) & bit)) {
+        const int max_bytes = 2 * 3 * (STY + 14) * LWp * (int)sizeof(float);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_pipe<STY, true>), hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_pipe<STY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+        attr_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
+    const int tiles_x = (W + 111) / 112, n_tiles = tiles_x * ((H + sty - 1) / sty);
+    const int wgs = std::min(n_tiles, smooth_pipe_workgroups);
+    if (sty == STY) hipLaunchKernelGGL((k_smooth_pipe<STY, true>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
+    else hipLaunchKernelGGL((k_smooth_pipe<STY, false>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
+}
+#endif  // UGSM_DEV_LIB
 
 // =========================================================================================
 // triangulation of the full-resolution disparity into X, Y, Z planes.

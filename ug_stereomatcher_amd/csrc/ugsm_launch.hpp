@@ -113,6 +113,13 @@ constexpr int kSmoothTileRowsMax = 36;  // (39 rows still fit two workgroups per
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows = 0, const Batch *bt = nullptr,
                          int tile_class = 0);
 int smooth_tile_rows(int W, int H, int latency, int pairs = 1);
+#ifdef UGSM_DEV_LIB
+// The same passes (+ box) on the 112-column tile, pipelined: persistent workgroups (one per CU) take tiles from `queue` (one zeroed counter
+// per pair of the launch) and prefetch the next tile's region by LDS-DMA while they compute the current one (k_smooth_pipe).  Bit-exact,
+// measured slower than k_smooth_fused (tools/kbench mode 17): development library only.
+void launch_smooth_pipe(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows, unsigned *queue, const Batch *bt = nullptr);
+extern int smooth_pipe_workgroups;
+#endif
 extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
 extern int blur_decimate_streaming;  // (development: UGSM_PYR_STREAM)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
