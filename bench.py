@@ -306,16 +306,22 @@ def main():
         ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
 
     def steady_state(n):
-        """Pairs/s between the completion of the first call after the slots have been filled once and the completion of the last call
-        before they drain, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
+        """Pairs/s between the completion of the first call after the slots have been filled once and the completion of the last
+        full-size call that still has `slots` full-size calls behind it, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
         from a drained pipe with all slots submitted in phase and ends by draining them, which costs about one pair's in-flight time
         whatever the length of the region -- 4 % of 96 steps, more of 20 -- and hides changes of a few per cent.
         None when the region is too short to have a middle."""
-        if len(done_t) != n or len(call_sizes) < 2 * slots + 2:
+        # only the calls of full size count: the tapered calls at the end hold less work in flight than the full ones at the start, and an
+        # interval that ends among them would be credited with work done before it began
+        full = 0
+        while full < len(call_sizes) and call_sizes[full] == call_sizes[0]:
+            full += 1
+        first, last = slots, full - slots - 1          # call indices: the pipe is full after call `slots`; `slots` full-size calls still follow call `last`
+        if len(done_t) != n or last - first < 2:
             return None
-        lo = sum(call_sizes[:slots + 1]) - 1                 # index of the last pair of call `slots` (0-based): the pipe is full
-        hi = n - sum(call_sizes[-slots:]) - 1                # index of the last pair before the final `slots` calls
-        if hi - lo < 2 or done_t[hi] <= done_t[lo]:
+        lo = sum(call_sizes[:first + 1]) - 1           # index of the last pair of call `first`
+        hi = sum(call_sizes[:last + 1]) - 1            # ... of call `last`
+        if done_t[hi] <= done_t[lo]:
             return None
         return (hi - lo) / (done_t[hi] - done_t[lo])
 

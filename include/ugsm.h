@@ -41,7 +41,7 @@ extern "C" {
 #define UGSM_ERR_STATE         7  /* e.g. fine phase without coarse phase */
 
 #define UGSM_MAX_LEVELS 32
-#define UGSM_MAX_BATCH 8   /* pairs per ugsm_submit_*_batch call */
+#define UGSM_MAX_BATCH 16  /* pairs per ugsm_submit_*_batch call */
 
 typedef struct ugsm_ctx ugsm_ctx;
 

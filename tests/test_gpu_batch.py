@@ -67,7 +67,7 @@ def _fovea_batch(c, lib, pairs, W, H, levels, F, offsets, want_pyr=False, slot=0
             c.free(p)
 
 
-@pytest.mark.parametrize("B", [1, 2, 4, 8])
+@pytest.mark.parametrize("B", [1, 2, 4, 8, 16])
 def test_full_batch_vs_oracle(lib, orc, B):
     """Every pair of a batch against the oracle: a size whose levels are all batched, an odd one whose coarse levels are smaller than a
     tile, on a one-slot and on a several-slot context (the latency and the several-slot kernel choices)."""
@@ -125,12 +125,12 @@ def test_full_batch_every_kernel_form_on_the_batched_levels(lib, orc, monkeypatc
         assert_bit_equal(got[b], exp[b], f"800x600 batch of {B}, {force}, pair {b}")
 
 
-@pytest.mark.parametrize("B", [1, 2, 4, 8])
+@pytest.mark.parametrize("B", [1, 2, 4, 8, 16])
 def test_foveated_batch_with_different_offsets_vs_oracle(lib, orc, B):
     """The foveated stack of every pair of a batch, every pair with its own window offset (centred, off-centre, clamped at the frame),
     pyramid stacks included, against the oracle's answer for that pair and that offset."""
     W, H, lv, F = 1280, 960, 12, 5
-    offs = [(0, 0), (-170, 90), (5000, -5000), (33, 17), (-64, -48), (250, 0), (0, -200), (-5000, 5000)][:B]
+    offs = ([(0, 0), (-170, 90), (5000, -5000), (33, 17), (-64, -48), (250, 0), (0, -200), (-5000, 5000)] + [(37 * j - 200, 150 - 29 * j) for j in range(8)])[:B]
     pairs = _pairs(W, H, B, 2100)
     with lib.Context(levels=lv, fovea_levels=F, slots=2, batch=B) as c:
         st, pl, pr = _fovea_batch(c, lib, pairs, W, H, lv, F, offs, want_pyr=True, slot=1)
@@ -209,9 +209,9 @@ def test_batch_bad_arguments(lib):
     import ctypes as C
     with lib.Context(levels=5, batch=2) as c:
         p = c.alloc(64 * 48 * 3 * 4)
-        ptrs = (C.c_void_p * 9)(*([p] * 9))
+        ptrs = (C.c_void_p * (lib.UGSM_MAX_BATCH + 1))(*([p] * (lib.UGSM_MAX_BATCH + 1)))
         assert c.lib.ugsm_submit_full_batch(c.handle, 0, 0, ptrs, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
-        assert c.lib.ugsm_submit_full_batch(c.handle, 0, 9, ptrs, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
+        assert c.lib.ugsm_submit_full_batch(c.handle, 0, lib.UGSM_MAX_BATCH + 1, ptrs, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
         assert c.lib.ugsm_submit_full_batch(c.handle, 0, 2, None, ptrs, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
         holes = (C.c_void_p * 2)(p, None)
         assert c.lib.ugsm_submit_full_batch(c.handle, 0, 2, ptrs, holes, 64, 48, 192, ptrs) == lib.UGSM_ERR_BAD_ARG
@@ -220,7 +220,7 @@ def test_batch_bad_arguments(lib):
         c.free(p)
     cfg = lib.Config()
     lib.load().ugsm_default_config(C.byref(cfg))
-    cfg.batch = 9
+    cfg.batch = lib.UGSM_MAX_BATCH + 1
     h = C.c_void_p()
     assert lib.load().ugsm_create(C.byref(cfg), C.byref(h)) == lib.UGSM_ERR_BAD_ARG
 
@@ -266,21 +266,16 @@ def test_two_contexts_in_one_process_with_stream_priority_pools(lib):
     shares its queues.  A host that runs two contexts gives them different pools (default: slots 0-3 at the greatest priority; 3: all at
     the least) and each then runs at the rate a context alone in the process reaches; results do not depend on any of it."""
     import time
-    import torch
     from ug_stereomatcher_amd import synth
     W, H, lv, slots, n = 1920, 1080, 14, 4, 96
-    dev = torch.device("cuda:0")
     L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 77)
-    dL, dR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
-    outs = [torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(2 * slots)]
-    torch.cuda.synchronize()
 
     def rate(c, o):
         def run(k):
             for i in range(k):
                 s = i % slots
                 c.check(c.lib.ugsm_wait(c.handle, s))
-                c.check(c.lib.ugsm_submit_full(c.handle, s, dL.data_ptr(), dR.data_ptr(), W, H, 3 * W, o[s].data_ptr()))
+                c.check(c.lib.ugsm_submit_full(c.handle, s, dL, dR, W, H, 3 * W, o[s]))
             c.check(c.lib.ugsm_wait_all(c.handle))
         run(2 * slots)
         best = 0.0
@@ -291,17 +286,21 @@ def test_two_contexts_in_one_process_with_stream_priority_pools(lib):
         return best
 
     with lib.Context(levels=lv, slots=slots) as a:
+        dL, dR = a.to_device(L), a.to_device(R)   # (device memory belongs to the process: both contexts use these buffers)
+        outs = [a.alloc(3 * W * H * 4) for _ in range(2 * slots)]
         alone = rate(a, outs[:slots])
-        ref = outs[0].clone()
+        ref = a.to_host(outs[0], (3, H, W))
         with lib.Context(levels=lv, slots=slots, stream_priority=3) as b:       # a pool of its own: the least priority
             rb = rate(b, outs[slots:])
             ra = rate(a, outs[:slots])
-            assert torch.equal(outs[slots].view(torch.int32), ref.view(torch.int32)), "results do not depend on the stream priorities"
+            assert_bit_equal(b.to_host(outs[slots], (3, H, W)), ref, "results do not depend on the stream priorities")
         with lib.Context(levels=lv, slots=slots, stream_priority=1) as d:       # the opt-out: the process default priority
             rd = rate(d, outs[slots:])
-            assert torch.equal(outs[slots].view(torch.int32), ref.view(torch.int32))
+            assert_bit_equal(d.to_host(outs[slots], (3, H, W)), ref, "results do not depend on the stream priorities")
+        for p in [dL, dR] + outs:
+            a.free(p)
     print(f"pairs/s at 1080p, four slots: context alone {alone:.0f}; second context in the least-priority pool {rb:.0f}, the first again {ra:.0f}; "
-          f"a context at the process default priority (torch holds the null stream's queue) {rd:.0f}")
+          f"a context at the process default priority (the null stream holds one of that pool's queues) {rd:.0f}")
     assert rb >= 0.85 * alone and ra >= 0.85 * alone, (alone, rb, ra)
     for bad in (4, -1):
         with pytest.raises(lib.UgsmError):

@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libugsm.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libugsm_dev.so")
-UGSM_MAX_BATCH = 8
+UGSM_MAX_BATCH = 16
 
 UGSM_OK = 0
 UGSM_ERR_BAD_ARG = 1

@@ -27,7 +27,7 @@ struct SeedMap {
 // as one tile's or one strip's chain, whatever the chip could do beside it; with B pairs marching through the levels in lockstep the
 // same launch carries B times the work: gridDim.y (gridDim.z / 3 where y is the image row) = pairs, and the kernel shifts its pointers
 // to its pair's planes before it does anything else.  Offsets are BYTES relative to the pointers of the launch, which are pair 0's.
-constexpr int kMaxBatch = 8;  // = UGSM_MAX_BATCH (include/ugsm.h)
+constexpr int kMaxBatch = 16;  // = UGSM_MAX_BATCH (include/ugsm.h)
 struct Batch {
     int n;                     // pairs in the launch; <= 1: one pair, nothing below is read
     int cx[kMaxBatch], cy[kMaxBatch];  // seeded launches: SeedMap.cx / cy of pair b (fovea windows of different pairs sit at different places)
