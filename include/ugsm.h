@@ -137,9 +137,11 @@ long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
  * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4);
  * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
  * seed_fused: 1 if the level's seeding rides on its first K-cost launch; smooth_tile_rows: height of k_smooth_fused's 112-column
- * tile where that tile is used (else 0). */
+ * tile where that tile is used (else 0).  With cfg->batch > 1 the plan is that of a call of cfg->batch pairs (ugsm_submit_*_batch): what
+ * counts as "in flight" is the batch, and the thresholds are compared with pairs_per_launch x the level. */
 typedef struct ugsm_level_plan {
-    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, latency_policy, reserved[1];
+    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, latency_policy;
+    int pairs_per_launch;  /* ABI 4: cfg->batch where a call of that many pairs runs this level as one launch for all of them, else 1 */
 } ugsm_level_plan;
 int ugsm_plan_level(const ugsm_config *cfg, int W, int H, ugsm_level_plan *out);
 int ugsm_plan_level_in_frame(const ugsm_config *cfg, int frame_w, int frame_h, int W, int H, ugsm_level_plan *out);

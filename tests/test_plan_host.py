@@ -58,7 +58,7 @@ def test_several_slots_with_small_frames_keep_the_latency_choices():
 def test_switches():
     assert _lib.plan_level(4928, 3264, kernel_path=1)["cost_kernel"] == STAGED
     assert _lib.plan_level(4928, 3264, march_min_pixels=-1) == dict(cost_kernel=TILED, smooth_kernel=TILED, smooth_rh=0, strip_rows=0, seed_fused=0,
-                                                                     smooth_tile_rows=36, latency_policy=1)
+                                                                     smooth_tile_rows=36, latency_policy=1, pairs_per_launch=1)
     assert _lib.plan_level(200, 150, frame=FRAME, small_max_pixels=-1, slots=4)["cost_kernel"] == TILED
     assert _lib.plan_level(300, 200, small_max_pixels=-1, slots=1)["cost_kernel"] == MARCH4   # a pair alone: the latency form takes over
     assert _lib.plan_level(300, 200, march_min_pixels=1)["cost_kernel"] == MARCH
@@ -124,3 +124,33 @@ def test_plan_follows_the_development_overrides_of_the_process(monkeypatch):
     monkeypatch.delenv("UGSM_POLICY")
     monkeypatch.setenv("UGSM_MARCH4", "0,0")
     assert all(_lib.plan_level(w, h, slots=1)["cost_kernel"] != MARCH4 for (w, h) in levels_16mp())
+
+
+def test_plan_of_a_batched_call():
+    """ugsm_config.batch (round 4): the plan is that of a call of `batch` pairs -- levels of at most 9 Mpx are one launch for all of
+    them, and every "does this launch fill the chip" threshold is compared with what the launch holds."""
+    W, H = 4928, 3264
+    ws, hs = _lib.level_dims(W, H, 14)
+    one = [_lib.plan_level(w, h, frame=(W, H), slots=4) for w, h in zip(ws, hs)]
+    b4 = [_lib.plan_level(w, h, frame=(W, H), slots=4, batch=4) for w, h in zip(ws, hs)]
+    assert [p["pairs_per_launch"] for p in one] == [1] * 14
+    assert [p["pairs_per_launch"] for p in b4] == [1] + [4] * 13            # level 0 (16.1 Mpx) pair by pair, levels 1-13 batched
+    assert b4[0] == dict(one[0], pairs_per_launch=1)                         # level 0: the launch of round 3
+    MARCH, SMALL = 1, 2
+    assert one[9]["cost_kernel"] == SMALL and b4[9]["cost_kernel"] == MARCH   # 216 x 142 = 30 672 pixels: four of them are past the 50 k threshold
+    assert b4[13]["cost_kernel"] == SMALL and b4[13]["smooth_kernel"] == SMALL
+    # the strips of a batched marching launch are sized for all its pairs' strips sharing the chip
+    assert b4[1]["strip_rows"] > 3 * one[1]["strip_rows"]
+    # the foveated stack, eight pairs per call: the 615 x 407 window is 2 Mpx per launch -- the channel-parallel marching K-cost and
+    # the 112-column K-smooth tile, where a single window runs 64 x 32 tiles
+    f1 = _lib.plan_level(615, 407, frame=(615, 407), slots=4)
+    f8 = _lib.plan_level(615, 407, frame=(615, 407), slots=4, batch=8)
+    assert f8["pairs_per_launch"] == 8 and f8["latency_policy"] == 1 and f8["cost_kernel"] == 4
+    assert f1["smooth_tile_rows"] == 0 and f8["smooth_tile_rows"] == 36
+    # a development override of the threshold
+    import os
+    os.environ["UGSM_BATCH_MAX_PIXELS"] = "-1"
+    try:
+        assert _lib.plan_level(615, 407, slots=4, batch=8)["pairs_per_launch"] == 1
+    finally:
+        del os.environ["UGSM_BATCH_MAX_PIXELS"]

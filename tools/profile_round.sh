@@ -1,26 +1,32 @@
 #!/bin/bash
 # Collects everything profiles/make_summaries.py needs, in ONE gpurun call:
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'
-#   python profiles/make_summaries.py gpurun_out/prof_r03 r03
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r04'
+#   python profiles/make_summaries.py gpurun_out/prof_r04 r04
 # Counter passes are separate rocprofv3 runs with at most 8 counters each (--kernel-trace only beside --pmc), each
 # behind its own timeout; a line is printed after every step so that the call never looks hung.
 export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
+PART=${2:-AB}   # A: the bench lines, the kernel trace, the counter passes; B: kbench, same-box A/Bs, breakdowns, rehearsals (two gpurun calls: each stays well inside the 20-minute limit)
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 step() { echo "[profile_round] $* ($(date +%T))"; }
+if [[ $PART == *A* ]]; then
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; step "bench default: $(cut -c1-160 $O/bench_default.json)"
-python bench.py --slots 1 --no-cpu-baseline --no-service > $O/bench_slots1.json 2>> $O/bench_default.err; step "bench slots1"
-python bench.py --workload 1080p --no-cpu-baseline --no-service > $O/bench_1080p.json 2>> $O/bench_default.err; step "bench 1080p"
-python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp"
+# the driver's protocol (BENCH_rNN.json) and round 3's configuration (single-pair calls), same box
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-service --profile-pairs 0 --single-pairs 0 > $O/bench_steps20.json 2>> $O/bench_default.err; step "bench --steps 20 --warmup 5: $(cut -c1-120 $O/bench_steps20.json)"
+python bench.py --batch 1 --no-cpu-baseline --no-service --profile-pairs 0 --single-pairs 0 > $O/bench_batch1.json 2>> $O/bench_default.err; step "bench --batch 1: $(cut -c1-120 $O/bench_batch1.json)"
+python bench.py --slots 1 --batch 1 --no-cpu-baseline --no-service > $O/bench_slots1.json 2>> $O/bench_default.err; step "bench slots1"
+python bench.py --workload 1080p --no-cpu-baseline --no-service > $O/bench_1080p.json 2>> $O/bench_default.err; step "bench 1080p: $(cut -c1-120 $O/bench_1080p.json)"
+python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp: $(cut -c1-120 $O/bench_fovea16mp.json)"
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours; 96 steps instead of
 # 384: the kernel trace of the longer region does not fit gpurun's 64 MiB of returned files)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
 # (UGSM_POLICY: a one-slot context would otherwise make the latency choices, not the ones of the 4-slot bench line)
-pmc() { name=$1; shift; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
+# (--batch 1: single-pair launches, whose grids identify the level)
+pmc() { name=$1; shift; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --batch 1 --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 pmc pmc_write WRITE_SIZE
 pmc pmc_fetch FETCH_SIZE
@@ -28,6 +34,8 @@ pmc pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_
 pmc pmc_sq2 GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
 pmc pmc_sq3 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64
 cd $R
+fi
+if [[ $PART == *B* ]]; then
 timeout -k 10 200 ./tools/kbench 4928 3264 10 2 > $O/kbench_16mp.txt 2>&1; step "kbench (marching vs tiled K-cost)"
 timeout -k 10 200 ./tools/kbench 4928 3264 10 5 > $O/kbench_smooth_16mp.txt 2>&1; step "kbench (marching vs tiled K-smooth)"
 { for sz in "54 36" "154 102" "436 289" "616 408"; do timeout -k 10 100 ./tools/kbench $sz 200 7 | grep -v "P=[0-4]"; done; } > $O/kbench_small.txt 2>&1; step "kbench (latency kernels of the coarse levels)"
@@ -37,10 +45,14 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 { for sz in "54 36" "154 102" "436 289"; do timeout -k 10 60 ./tools/kbench $sz 20 13; done; } > $O/kbench_graph.txt 2>&1; step "kbench (eager launches against a HIP graph, coarse level)"
 { for sz in "436 289" "615 407" "870 576" "1231 815" "1741 1153" "2463 1631"; do echo "== $sz"; timeout -k 10 60 ./tools/kbench $sz 100 14 | grep -v "rows=[1-9]"; done; } > $O/kbench_march4.txt 2>&1; step "kbench (k_cost_march4 against k_cost_march / split / small)"
 { for sz in "3 1" "4 1" "8 1" "4 0" "4 1 hhhh" "8 1 hhhhllll"; do timeout -k 5 60 ./tools/queue_probe $sz; done; } > $O/queue_probe.txt 2>&1; step "queue probe"
-{ timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "default:" "latency choices:UGSM_POLICY=latency" "default-priority streams:UGSM_STREAM_PRIO=nnnn" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 160 --rounds 2 "default:" "throughput choices:UGSM_POLICY=throughput" | grep -v "^round"; } > $O/ab_policies.txt 2>&1; step "same-box A/B of the policies"
+{ timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 4, levels <= 2.2 Mpx batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=2200000" "batches of 4, every level batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=20000000" "batches of 4, tiled pyramid kernel:BATCH=4;UGSM_PYR_STREAM=0" "two slots x 4:SLOTS=2;BATCH=4" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 8:SLOTS=2;BATCH=8" "batches of 8, throughput choices:BATCH=8;UGSM_POLICY=throughput" "batches of 8, tiled pyramid kernel:BATCH=8;UGSM_PYR_STREAM=0" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --size 1920 1080 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 16:SLOTS=2;BATCH=16" | grep -v "^round"; timeout -k 10 200 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "tiled pyramid kernel:UGSM_PYR_STREAM=0" | grep -v "^round"; } > $O/ab_batch.txt 2>&1; step "same-box A/B: batch sizes, batch threshold, pyramid kernel"
 timeout -k 10 100 ./tools/kbench_stamp 4928 3264 10 6 > $O/census_16mp.txt 2>&1; step "wave census of the marching K-cost"
-timeout -k 10 100 python tools/level_breakdown.py > $O/level_breakdown.txt 2>&1; step "per-level breakdown of one pair"
+{ timeout -k 10 100 python tools/level_breakdown.py; timeout -k 10 100 python tools/level_breakdown.py --batch 4 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --fovea 7; timeout -k 10 100 python tools/level_breakdown.py --fovea 7 --batch 8 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --size 1920 1080 --batch 8 --slots 4; } 2>&1 | grep -v amdgpu.ids > $O/level_breakdown.txt; step "per-level breakdown: one pair, a batch of 4, the foveated stack alone and as a batch of 8, 1080p as a batch of 8"
+timeout -k 10 200 ./tools/kbench 4928 3264 10 17 > $O/kbench_smooth_pipe.txt 2>&1; step "kbench (k_smooth_pipe against k_smooth_fused)"
+{ echo "# two gloo ranks on one MI355X (rehearsal of the N > 1 code path: both ranks share the card, each with its own four-slot context)"; for wl in full16mp fovea-shard; do echo "\$ UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 24 --warmup 4 --workload $wl --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0"; UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo MASTER_PORT=29611 timeout -k 10 200 python bench.py --gpus 2 --steps 24 --warmup 4 --workload $wl --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0 2>/dev/null | cut -c1-400; done; } > $O/rehearsal_2ranks.txt 2>&1; step "two-rank rehearsal over gloo"
+timeout -k 10 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_batch.py::test_two_contexts_in_one_process_with_stream_priority_pools -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -12 > $O/rccl_and_contexts.txt; step "one-rank RCCL shard test + two contexts"
 # (7 minutes; the instruction costs do not change with the kernels: only with VALUBENCH=1)
 if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"; fi
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
+fi
 ls $O

@@ -60,7 +60,7 @@ class Config(C.Structure):
 
 class LevelPlan(C.Structure):
     _fields_ = [("cost_kernel", C.c_int), ("smooth_kernel", C.c_int), ("smooth_rh", C.c_int), ("strip_rows", C.c_int), ("seed_fused", C.c_int),
-                ("smooth_tile_rows", C.c_int), ("latency_policy", C.c_int), ("reserved", C.c_int * 1)]
+                ("smooth_tile_rows", C.c_int), ("latency_policy", C.c_int), ("pairs_per_launch", C.c_int)]
 
 
 class KernelStat(C.Structure):
@@ -351,7 +351,8 @@ def plan_level(W: int, H: int, frame=None, **cfg_fields):
     st = lib.ugsm_plan_level_in_frame(C.byref(cfg), fw, fh, W, H, C.byref(out))
     if st != 0:
         raise UgsmError(st, "ugsm_plan_level")
-    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "latency_policy")}
+    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "latency_policy",
+                                              "pairs_per_launch")}
 
 
 def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):

@@ -1542,19 +1542,26 @@ int ugsm_plan_level_in_frame(const ugsm_config *cfg_in, int frame_w, int frame_h
     memset(out, 0, sizeof *out);
     if (probe.cfg.kernel_path == 1) {
         out->cost_kernel = out->smooth_kernel = 3;
+        out->pairs_per_launch = 1;
         return UGSM_OK;
     }
-    const bool lat = latency_mode(&probe, (long long)frame_w * frame_h);
+    // a context created for batches (ugsm_config.batch) is asked about a call of that many pairs: what is in flight is the batch, and a
+    // level of at most kBatchMaxPixels is one launch for all its pairs
+    const int nb = std::min(std::max(probe.cfg.batch, 1), kMaxBatch);
+    const bool lat = latency_mode(&probe, (long long)frame_w * frame_h * nb);
     out->latency_policy = lat ? 1 : 0;
-    const bool march = use_march(&probe, W, H, lat);
-    const int rh = small_rh(&probe, W, H, lat);
-    const bool march4 = use_march4(&probe, W, H, lat);
+    const int pairs = (nb > 1 && batch_level(&probe, W, H)) ? nb : 1;
+    const bool march = use_march(&probe, W, H, lat, pairs);
+    const int rh = small_rh(&probe, W, H, lat, pairs);
+    const bool march4 = use_march4(&probe, W, H, lat, pairs);
     out->cost_kernel = march4 ? 4 : (march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0));
-    out->smooth_kernel = (march && probe.cfg.march_smooth == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
+    out->smooth_kernel = (kDevLib && march && probe.cfg.march_smooth == 1 && nb == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
-    out->strip_rows = march4 ? march4_strip_rows(W, H) : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1, probe.march_mode <= -2)) : 0);
-    out->seed_fused = fuse_seed(&probe, W, H, lat) ? 1 : 0;
-    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H, lat) : 0;
+    out->strip_rows = march4 ? march4_strip_rows(W, H, pairs)
+                             : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1, probe.march_mode <= -2, pairs)) : 0);
+    out->seed_fused = fuse_seed(&probe, W, H, lat, pairs) ? 1 : 0;
+    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H, lat, pairs) : 0;
+    out->pairs_per_launch = pairs;
     return UGSM_OK;
 }
 int ugsm_threshold_schedule(int mi, float *out)
