@@ -195,7 +195,7 @@ int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, cons
 /* B pairs per call (round 4) -- BASELINE configs[4] is "a batch of 8 x 16 MP foveated pairs"; the reference's loop is 176 strictly
  * sequential iterations per pair (MatchGPULib.cpp:1741-1743), and on every level of 615 x 407 pixels and below each of them is a launch
  * that lasts as long as ONE tile's or strip's chain whatever the rest of the chip could do.  The n pairs of a batch (1 <= n <=
- * UGSM_MAX_BATCH, all W x H) march through the levels in lockstep on the slot's stream: every level of at most ~2 Mpx is ONE launch
+ * UGSM_MAX_BATCH, all W x H) march through the levels in lockstep on the slot's stream: every level of at most 9 Mpx is ONE launch
  * for all of them (a pair index in every kernel's grid), larger levels fill the chip pair by pair and are launched so.  Same
  * arithmetic, same results bit for bit as n single calls.  d_rgbL / d_rgbR / d_out (d_stack, d_pyrL, d_pyrR): HOST arrays of n
  * DEVICE pointers, buffers laid out as for ugsm_submit_full / ugsm_submit_foveated; off_x / off_y: n window offsets (NULL = centred);
@@ -218,7 +218,10 @@ int ugsm_slot_stream(ugsm_ctx *ctx, int slot, void **hip_stream);
  * top..F-1 on the full frame; d_state receives level F-1's (dx,dy,conf),
  * 3*fovH*fovW floats -- the 3 MB object broadcast over RCCL.  fine: levels
  * F-2..0 for the window at (off_x, off_y) from a (possibly received) d_state;
- * needs the pair's pyramids, so call ugsm_submit_pyramids (or coarse) first. */
+ * needs the pair's WHOLE pyramids in the slot, i.e. ugsm_submit_pyramids first (UGSM_ERR_STATE otherwise).  The one-shot foveated
+ * calls (ugsm_match_foveated, ugsm_submit_foveated[_batch|_host]) know their windows when they build the pyramids and store level 0
+ * only inside them (CreateFoveatedPyramid crops after a full build, MatchGPULib.cpp:1128-1190; here 193 MB per 16 MP image are never
+ * written), so their pyramids do NOT serve a later ugsm_submit_fovea_fine at another offset. */
 int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR,
                          int W, int H, int stride);
 int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state);
