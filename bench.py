@@ -376,8 +376,9 @@ def main():
         # and `value_repeats` (first entry: the region `value` comes from); x n_gpus for independent replicas
         "steady_state": {"value": (work * steady[0]) if steady[0] else None, "repeats": [(work * v) if v else None for v in steady[1:]],
                          "unit": "pairs/s", "calls": len(call_sizes), "call_sizes_head_tail": [call_sizes[:6], call_sizes[-6:]],
-                         "note": "host clock at the return of ugsm_wait(slot) for every pair, in submission order; the rate between the "
-                                 "completion of pair slots+1 and of pair steps-slots: no fill, no drain"},
+                         "note": "host clock at the return of ugsm_wait(slot) for every call's pairs, in submission order; the rate between the "
+                                 "completion of call `slots` (the pipe is full) and of the last full-size call that still has `slots` full-size "
+                                 "calls behind it: no fill, no drain, no tapered calls"},
         "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),
         "whole_pair_algorithmic_GBps": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F) * value / n_gpus / 1e9,
     }

@@ -54,5 +54,7 @@ timeout -k 10 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_batch.p
 # (7 minutes; the instruction costs do not change with the kernels: only with VALUBENCH=1)
 if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"; fi
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
+# the default line once more when part A's counter passes have been condensed (profiles/make_summaries.py) into this round's VALU model: `valu_roofline` then prices the kernels as built
+if [ -f profiles/${TAG}_valu_model.json ]; then python bench.py > $O/bench_default.json 2> $O/bench_default.err; step "bench default (with ${TAG}_valu_model.json): $(cut -c1-160 $O/bench_default.json)"; fi
 fi
 ls $O
