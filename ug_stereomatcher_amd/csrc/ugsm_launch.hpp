@@ -122,6 +122,7 @@ extern int smooth_pipe_workgroups;
 #endif
 extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
 extern int blur_decimate_streaming;  // (development: UGSM_PYR_STREAM)
+extern long long blur_decimate_streaming_min;  // (development: UGSM_PYR_STREAM_MIN)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
 void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt = nullptr);

@@ -474,6 +474,7 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     if (const char *e = getenv("UGSM_BATCH_MAX_PIXELS")) k.batch_max_px = atoll(e);
     if (set_globals) geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);  // (a process-wide tuning variable, like UGSM_MARCH_AGE)
     if (set_globals) geti("UGSM_PYR_STREAM", blur_decimate_streaming);
+    if (const char *e = set_globals ? getenv("UGSM_PYR_STREAM_MIN") : nullptr) blur_decimate_streaming_min = atoll(e);
     if (const char *e = set_globals ? getenv("UGSM_MARCH_AGE") : nullptr) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a + b < 1000) {
