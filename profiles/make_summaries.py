@@ -59,6 +59,19 @@ traffic = {k: v / traffic_n[k] for k, v in traffic.items()}
 lines.append("")
 lines.append("Mean HBM bytes per launch over all launches of a pair (what `roofline.traffic` in the bench line quotes): "
              + ", ".join(f"{k} {v / 1e6:.2f} MB" for k, v in sorted(traffic.items())))
+# round 4: the foveated call's k_pyr_base stores level 0 inside the fovea window only (a WRITE_SIZE pass of `bench.py --workload fovea16mp`)
+try:
+    fov = load("pmc_write_fovea")
+    for k in fov:
+        if k.startswith("k_pyr_base") or k.startswith("k_blur_decimate2<16"):
+            v = fov[k]["WRITE_SIZE"]
+            lines.append("" if k.startswith("k_blur") else "\n## The foveated call (round 4: level 0 stored inside the fovea window only)\n\n"
+                         "`rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py --workload fovea16mp --steps 4 --warmup 1 --slots 1 --batch 1 "
+                         "--no-cpu-baseline --no-events`:\n")
+            lines.append(f"* `{k}`: {len(v)} launches, WRITE_SIZE {sum(v) * 1024 / len(v) / 1e6:.1f} MB per launch"
+                         + (" (full mode, table above: 338.1 MB -- levels 1 and 2 are written whole, level 0 only in the window's tiles)" if k.startswith("k_pyr") else ""))
+except Exception:
+    pass
 open(f"{out}/{tag}_hbm_traffic.md", "w").write("\n".join(lines) + "\n")
 # VALU issue rate of the two hot kernels at level 0: SQ_INSTS_VALU (pass sq1) per SIMD cycle (SQ_BUSY_CU_CYCLES of pass sq2
 # x 4 SIMDs), largest grid of each kernel.  Times the mean issue cost of the mix (tools/valubench: 3.0 cycles for plain
