@@ -264,44 +264,40 @@ def test_two_contexts_in_one_process_with_stream_priority_pools(lib):
     """ugsm_config.stream_priority: HIP deals streams onto four hardware queues PER PRIORITY LEVEL, and two
     streams on one queue run strictly one after the other -- so a second context whose slots sit in the same pool as the first one's
     shares its queues.  A host that runs two contexts gives them different pools (default: slots 0-3 at the greatest priority; 3: all at
-    the least) and each then runs at the rate a context alone in the process reaches; results do not depend on any of it."""
-    import time
-    from ug_stereomatcher_amd import synth
-    W, H, lv, slots, n = 1920, 1080, 14, 4, 96
-    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 77)
-
-    def rate(c, o):
-        def run(k):
-            for i in range(k):
-                s = i % slots
-                c.check(c.lib.ugsm_wait(c.handle, s))
-                c.check(c.lib.ugsm_submit_full(c.handle, s, dL, dR, W, H, 3 * W, o[s]))
-            c.check(c.lib.ugsm_wait_all(c.handle))
-        run(2 * slots)
-        best = 0.0
-        for _ in range(3):
-            t0 = time.perf_counter()
-            run(n)
-            best = max(best, n / (time.perf_counter() - t0))
-        return best
-
-    with lib.Context(levels=lv, slots=slots) as a:
-        dL, dR = a.to_device(L), a.to_device(R)   # (device memory belongs to the process: both contexts use these buffers)
-        outs = [a.alloc(3 * W * H * 4) for _ in range(2 * slots)]
-        alone = rate(a, outs[:slots])
-        ref = a.to_host(outs[0], (3, H, W))
-        with lib.Context(levels=lv, slots=slots, stream_priority=3) as b:       # a pool of its own: the least priority
-            rb = rate(b, outs[slots:])
-            ra = rate(a, outs[:slots])
-            assert_bit_equal(b.to_host(outs[slots], (3, H, W)), ref, "results do not depend on the stream priorities")
-        with lib.Context(levels=lv, slots=slots, stream_priority=1) as d:       # the opt-out: the process default priority
-            rd = rate(d, outs[slots:])
-            assert_bit_equal(d.to_host(outs[slots], (3, H, W)), ref, "results do not depend on the stream priorities")
-        for p in [dL, dR] + outs:
-            a.free(p)
-    print(f"pairs/s at 1080p, four slots: context alone {alone:.0f}; second context in the least-priority pool {rb:.0f}, the first again {ra:.0f}; "
-          f"a context at the process default priority (the null stream holds one of that pool's queues) {rd:.0f}")
-    assert rb >= 0.85 * alone and ra >= 0.85 * alone, (alone, rb, ra)
+    the least) and each then runs at the rate a context alone in the process reaches; results do not depend on any of it.  The rates are
+    measured by tests/two_contexts_child.py in a FRESH process: which queue a stream lands on depends on every stream the process has
+    created before (this pytest process has created hundreds)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "two_contexts_child.py")], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0 and "TWO_CONTEXTS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     for bad in (4, -1):
         with pytest.raises(lib.UgsmError):
-            lib.Context(levels=lv, stream_priority=bad)
+            lib.Context(levels=14, stream_priority=bad)
+
+
+def test_window_only_pyramids_do_not_serve_a_later_fine_phase(lib):
+    """Round 4: the one-shot foveated calls store level 0 inside their windows only, so their pyramids must not be taken for whole ones --
+    a fine phase at another offset needs ugsm_submit_pyramids first (UGSM_ERR_STATE otherwise), and gets the right answer then."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv, F = 1280, 960, 12, 5
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 91)
+    fw, fh = lib.fovea_dims(W, H, lv, F)
+    with lib.Context(levels=lv, fovea_levels=F) as c:
+        dL, dR = c.to_device(L), c.to_device(R)
+        st = [c.alloc(3 * F * fh * fw * 4) for _ in range(3)]
+        state = c.alloc(3 * fh * fw * 4)
+        c.check(c.lib.ugsm_submit_foveated(c.handle, 0, dL, dR, W, H, 3 * W, 0, 0, st[0], None, None))
+        assert c.lib.ugsm_submit_fovea_fine(c.handle, 0, state, 200, -100, st[1]) == lib.UGSM_ERR_STATE
+        assert c.lib.ugsm_submit_fovea_coarse(c.handle, 0, state) == lib.UGSM_ERR_STATE
+        c.check(c.lib.ugsm_submit_pyramids(c.handle, 0, dL, dR, W, H, 3 * W))
+        c.check(c.lib.ugsm_submit_fovea_coarse(c.handle, 0, state))
+        c.check(c.lib.ugsm_submit_fovea_fine(c.handle, 0, state, 200, -100, st[1]))
+        c.check(c.lib.ugsm_submit_foveated(c.handle, 0, dL, dR, W, H, 3 * W, 200, -100, st[2], None, None))
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        assert_bit_equal(c.to_host(st[1], (3, F, fh, fw)), c.to_host(st[2], (3, F, fh, fw)), "split phases on whole pyramids vs the one-shot call")
+        for p in [dL, dR, state] + st:
+            c.free(p)

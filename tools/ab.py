@@ -26,22 +26,36 @@ W, H = args.size
 if args.child:
     # one context per process: HIP deals a process's streams onto its hardware queues in creation order, and a second context's
     # streams share queues with the first one's (a context measured second in the same process ran 15 % slower whatever its settings)
-    import torch
+    # NO_TORCH=1: device buffers through the C-ABI and no torch in the process -- libugsm.so then runs on the HIP runtime it links
+    # (/opt/rocm), not on the one PyTorch's wheel bundles and loads first (ug_stereomatcher_amd/_lib.py, _share_torch_hip_runtime)
+    no_torch = os.environ.get("NO_TORCH") == "1"
+    if no_torch:
+        os.environ["UGSM_NO_TORCH_RUNTIME"] = "1"
+    else:
+        import torch
+        dev = torch.device("cuda:0")
     from ug_stereomatcher_amd import _lib, synth
-    dev = torch.device("cuda:0")
     B = int(os.environ.get("BATCH", args.batch))
     args.slots = int(os.environ.get("SLOTS", args.slots))
     args.streams = int(os.environ.get("STREAMS", args.streams))
-    pairs = []
-    for j in range(max(args.slots, 2)):
-        L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + j)
-        pairs.append((torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)))
+    class Buf:   # a device buffer with torch's data_ptr() face
+        def __init__(self, p):
+            self.p = p
+
+        def data_ptr(self):
+            return self.p
     F = args.fovea
     fw, fh = _lib.fovea_dims(W, H, args.levels, F) if F else (W, H)
-    outs = [[torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(args.slots)]
-    torch.cuda.synchronize()
+    host_pairs = [synth.make_pair(W, H, synth.BASE_SEED + j)[:2] for j in range(max(args.slots, 2))]
     with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams, batch=B) as c:
         lib, h = c.lib, c.handle
+        if no_torch:
+            pairs = [(Buf(c.to_device(L)), Buf(c.to_device(R))) for L, R in host_pairs]
+            outs = [[Buf(c.alloc(4 * 3 * (F * fh * fw if F else H * W))) for _ in range(B)] for _ in range(args.slots)]
+        else:
+            pairs = [(torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)) for L, R in host_pairs]
+            outs = [[torch.empty((3, F, fh, fw) if F else (3, H, W), dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(args.slots)]
+            torch.cuda.synchronize()
 
         def run(n):
             for i in range((n + B - 1) // B):          # n pairs, B per call

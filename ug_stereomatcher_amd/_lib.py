@@ -71,6 +71,26 @@ class KernelStat(C.Structure):
 _libs = {}
 
 
+def _share_torch_hip_runtime():
+    """PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  A process that loads libugsm.so FIRST (which brings in
+    /opt/rocm's runtime) and imports torch afterwards ends up with two HIP runtimes, and the second one finds no GPU ("No HIP GPUs are
+    available").  When torch is installed, its runtime is therefore loaded first, globally, and libugsm.so binds to it -- the order
+    bench.py and the tools have always used (they import torch first).  A host without torch (the ROS node) is not affected.
+    UGSM_NO_TORCH_RUNTIME=1 switches this off."""
+    if os.environ.get("UGSM_NO_TORCH_RUNTIME") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # (best effort: without it the library still works, only a later `import torch` would not see the GPU)
+
+
 def load(dev: bool = False):
     """Loads libugsm.so (dev: libugsm_dev.so); raises if it has not been built (python __graft_entry__.py / make -C csrc)."""
     if dev in _libs:
@@ -78,6 +98,8 @@ def load(dev: bool = False):
     path = DEV_LIB_PATH if dev else LIB_PATH
     if not os.path.exists(path):
         raise UgsmError(UGSM_ERR_NO_DEVICE, f"{path} not built: run `make -C ug_stereomatcher_amd/csrc`")
+    if not _libs:
+        _share_torch_hip_runtime()
     lib = C.CDLL(path)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     i = C.c_int
