@@ -263,6 +263,12 @@ def main():
     call_sizes = []         # pairs per call of the region being timed, in submission order
     B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
     TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "1"))   # a call takes at most remaining / (TAPER x slots) pairs
+    # The first round of calls of a region is staggered in size -- slot c starts with at most ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for
+    # B = 4 on four slots -- so that the slots do not march through the levels in phase from a drained pipe (four slots submitted together
+    # and in step lose ~15 %, DESIGN.md section 9 of round 3; same box, 20 steps: 172 against 169 pairs/s, 162 for 4, 3, 2, 1).
+    # UGSM_BENCH_HEAD="a,b,..." overrides (experiments).
+    HEAD = ([int(v) for v in os.environ["UGSM_BENCH_HEAD"].split(",") if v] if "UGSM_BENCH_HEAD" in os.environ
+            else [-(-B * (c + 2) // (slots + 1)) for c in range(slots)])
 
     def wait_slot(s, stamp):
         ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?  (also: the slot's fine phase has consumed states[s])
@@ -300,6 +306,8 @@ def main():
         k = call = 0
         while k < n:
             nb = max(1, min(B, int((n - k) / (TAPER * slots))))
+            if call < len(HEAD):
+                nb = max(1, min(nb, HEAD[call], n - k))
             submit(k, slot=call % slots, stamp=stamp, n=nb)
             call_sizes.append(nb)
             k += nb
@@ -309,19 +317,19 @@ def main():
         ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
 
     def steady_state(n):
-        """Pairs/s between the completion of the first call after the slots have been filled once and the completion of the last
-        full-size call that still has `slots` full-size calls behind it, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
+        """Pairs/s between the completion of the first call that has the pipe full of full-size calls behind it and the completion of the
+        last such call, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
         from a drained pipe with all slots submitted in phase and ends by draining them, which costs about one pair's in-flight time
         whatever the length of the region -- 4 % of 96 steps, more of 20 -- and hides changes of a few per cent.
         None when the region is too short to have a middle."""
-        # only the calls of full size count: the tapered calls at the end hold less work in flight than the full ones at the start, and an
-        # interval that ends among them would be credited with work done before it began
-        full = 0
-        while full < len(call_sizes) and call_sizes[full] == call_sizes[0]:
-            full += 1
-        first, last = slots, full - slots - 1          # call indices: the pipe is full after call `slots`; `slots` full-size calls still follow call `last`
-        if len(done_t) != n or last - first < 2:
+        # the interval runs from the completion of a call to the completion of a later call, both with only FULL-size calls in flight behind
+        # them (and the pipe full): the staggered calls at the start and the tapered ones at the end hold less work in flight, and an
+        # interval that touched them would be credited with work done outside it
+        Bfull = max(call_sizes) if call_sizes else 0
+        ok = [j for j in range(slots, len(call_sizes) - slots) if all(call_sizes[i] == Bfull for i in range(j, j + slots + 1))]
+        if len(done_t) != n or len(ok) < 3:
             return None
+        first, last = ok[0], ok[-1]
         lo = sum(call_sizes[:first + 1]) - 1           # index of the last pair of call `first`
         hi = sum(call_sizes[:last + 1]) - 1            # ... of call `last`
         if done_t[hi] <= done_t[lo]:
@@ -377,8 +385,8 @@ def main():
         "steady_state": {"value": (work * steady[0]) if steady[0] else None, "repeats": [(work * v) if v else None for v in steady[1:]],
                          "unit": "pairs/s", "calls": len(call_sizes), "call_sizes_head_tail": [call_sizes[:6], call_sizes[-6:]],
                          "note": "host clock at the return of ugsm_wait(slot) for every call's pairs, in submission order; the rate between the "
-                                 "completion of call `slots` (the pipe is full) and of the last full-size call that still has `slots` full-size "
-                                 "calls behind it: no fill, no drain, no tapered calls"},
+                                 "completions of the first and the last call that have the pipe full of full-size calls behind them: no fill, "
+                                 "no drain, no staggered or tapered calls"},
         "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),
         "whole_pair_algorithmic_GBps": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F) * value / n_gpus / 1e9,
     }
