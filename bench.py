@@ -165,6 +165,39 @@ def cpu_baseline(wl: dict, runs: int = 3):
             "host_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": cpu_model(), "all_cores": allc, "one_thread": one}
 
 
+def plan_calls(n: int, slots: int, B: int, taper: float = 1.0, head=None):
+    """Sizes of the calls that take n pairs through `slots` slots with at most B pairs per call (ugsm_submit_*_batch), in submission order.
+    A call takes as many pairs as the work still queued allows without starving the other slots: min(B, remaining / (taper x slots)), at
+    least 1 -- a host that batches what has piled up and goes back to single pairs when little is left, so that the region does not end with
+    one slot grinding through a whole batch alone.  The first round of calls is staggered in size -- slot c starts with at most
+    ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for B = 4 on four slots -- so that the slots do not march through the levels in phase
+    from a drained pipe (same box, 20 steps: 172 against 169 pairs/s; 162 for 4, 3, 2, 1).  `head` overrides the stagger (experiments)."""
+    if head is None:
+        head = [-(-B * (c + 2) // (slots + 1)) for c in range(slots)]
+    sizes, k = [], 0
+    while k < n:
+        nb = max(1, min(B, int((n - k) / (taper * slots))))
+        if len(sizes) < len(head):
+            nb = max(1, min(nb, head[len(sizes)], n - k))
+        sizes.append(nb)
+        k += nb
+    return sizes
+
+
+def steady_window(call_sizes, slots: int):
+    """(lo, hi): indices of the LAST PAIR of the first and of the last call that have the pipe full of FULL-size calls behind them (the call
+    itself and the `slots` calls after it are of the region's largest size, and at least `slots` calls precede it), or None when the region has
+    no such middle.  The rate between those two completions counts no fill, no drain and no staggered or tapered call: such calls hold
+    less work in flight, and an interval that touched them would be credited with work done outside it."""
+    if not call_sizes:
+        return None
+    full = max(call_sizes)
+    ok = [j for j in range(slots, len(call_sizes) - slots) if all(call_sizes[i] == full for i in range(j, j + slots + 1))]
+    if len(ok) < 3:
+        return None
+    return sum(call_sizes[:ok[0] + 1]) - 1, sum(call_sizes[:ok[-1] + 1]) - 1
+
+
 def spawn_ranks(args) -> int:
     """`--gpus N` without a launcher: start one rank per GPU the way the driver does, from a process that has not touched
     the GPU, and hand back the child's exit code."""
@@ -263,12 +296,7 @@ def main():
     call_sizes = []         # pairs per call of the region being timed, in submission order
     B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
     TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "1"))   # a call takes at most remaining / (TAPER x slots) pairs
-    # The first round of calls of a region is staggered in size -- slot c starts with at most ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for
-    # B = 4 on four slots -- so that the slots do not march through the levels in phase from a drained pipe (four slots submitted together
-    # and in step lose ~15 %, DESIGN.md section 9 of round 3; same box, 20 steps: 172 against 169 pairs/s, 162 for 4, 3, 2, 1).
-    # UGSM_BENCH_HEAD="a,b,..." overrides (experiments).
-    HEAD = ([int(v) for v in os.environ["UGSM_BENCH_HEAD"].split(",") if v] if "UGSM_BENCH_HEAD" in os.environ
-            else [-(-B * (c + 2) // (slots + 1)) for c in range(slots)])
+    HEAD = [int(v) for v in os.environ["UGSM_BENCH_HEAD"].split(",") if v] if "UGSM_BENCH_HEAD" in os.environ else None   # (experiments; default: plan_calls' stagger)
 
     def wait_slot(s, stamp):
         ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?  (also: the slot's fine phase has consumed states[s])
@@ -299,42 +327,25 @@ def main():
             ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s][0], rank)
 
     def run(n, stamp=False):
-        """n pairs through the slots.  With --batch B a call takes up to B pairs, as many as the work still queued allows without
-        starving the other slots: min(B, remaining / (2 x slots)), at least 1 -- a host that batches what has piled up, and goes back to
-        single pairs when little is left, so that the region does not end with one slot grinding through a whole batch alone."""
-        del call_sizes[:]
-        k = call = 0
-        while k < n:
-            nb = max(1, min(B, int((n - k) / (TAPER * slots))))
-            if call < len(HEAD):
-                nb = max(1, min(nb, HEAD[call], n - k))
+        """n pairs through the slots, call sizes by plan_calls (batches while a backlog exists, staggered at the start, tapered at the end)."""
+        call_sizes[:] = plan_calls(n, slots, B, TAPER, HEAD)
+        k = 0
+        for call, nb in enumerate(call_sizes):
             submit(k, slot=call % slots, stamp=stamp, n=nb)
-            call_sizes.append(nb)
             k += nb
-            call += 1
-        for c in range(max(0, call - slots), call):   # the last calls, in the order they were submitted
+        for c in range(max(0, len(call_sizes) - slots), len(call_sizes)):   # the last calls, in the order they were submitted
             wait_slot(c % slots, stamp)
         ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
 
     def steady_state(n):
-        """Pairs/s between the completion of the first call that has the pipe full of full-size calls behind it and the completion of the
-        last such call, of the region just timed (SURVEY 8d defines the metric as steady state with the slots full): the region starts
-        from a drained pipe with all slots submitted in phase and ends by draining them, which costs about one pair's in-flight time
-        whatever the length of the region -- 4 % of 96 steps, more of 20 -- and hides changes of a few per cent.
-        None when the region is too short to have a middle."""
-        # the interval runs from the completion of a call to the completion of a later call, both with only FULL-size calls in flight behind
-        # them (and the pipe full): the staggered calls at the start and the tapered ones at the end hold less work in flight, and an
-        # interval that touched them would be credited with work done outside it
-        Bfull = max(call_sizes) if call_sizes else 0
-        ok = [j for j in range(slots, len(call_sizes) - slots) if all(call_sizes[i] == Bfull for i in range(j, j + slots + 1))]
-        if len(done_t) != n or len(ok) < 3:
+        """Pairs/s between the completions of the first and the last call of the region just timed that have the pipe full of full-size calls
+        behind them (steady_window; SURVEY 8d defines the metric as steady state with the slots full): the region starts from a drained pipe
+        and ends by draining it, which costs about one call's in-flight time whatever its length -- 4 % of 96 steps, more of 20 -- and hides
+        changes of a few per cent (VERDICT r03 weak #5).  None when the region is too short to have a middle."""
+        win = steady_window(call_sizes, slots)
+        if len(done_t) != n or win is None or done_t[win[1]] <= done_t[win[0]]:
             return None
-        first, last = ok[0], ok[-1]
-        lo = sum(call_sizes[:first + 1]) - 1           # index of the last pair of call `first`
-        hi = sum(call_sizes[:last + 1]) - 1            # ... of call `last`
-        if done_t[hi] <= done_t[lo]:
-            return None
-        return (hi - lo) / (done_t[hi] - done_t[lo])
+        return (win[1] - win[0]) / (done_t[win[1]] - done_t[win[0]])
 
     def timed(n):
         torch.cuda.synchronize()
