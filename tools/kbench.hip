@@ -543,6 +543,34 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 18) {  // how two kernels on two streams share the chip: alone, and side by side
+        hipStream_t s2; int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipStream_t s1; CK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, hi)); CK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, hi));
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        auto kc = [&](hipStream_t q, float *dst) { launch_cost_march(q, iL, iR, A, d, dst, W, H, 1.0f, 1, 0, 1, 0, rb); };
+        auto ks = [&](hipStream_t q, float *dst) { launch_smooth_fused(q, d, dst, W, H, 5, 1, 36); };
+        auto k4 = [&](hipStream_t q, float *dst) { launch_cost_march4(q, iL, iR, A, d, dst, W, H, 1.0f, 1, 0, rb, SeedMap{0, 0, 0, 0}); };
+        auto wall = [&](auto fa, auto fb, bool both) {
+            for (int i = 0; i < 2; i++) { fa(s1, o); if (both) fb(s2, o2); }
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < reps; i++) { fa(s1, o); if (both) fb(s2, o2); }
+            CK(hipDeviceSynchronize());
+            return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+        };
+        for (int round = 0; round < 2; round++) {
+            const double c = wall(kc, kc, false), sm = wall(ks, ks, false), m4 = wall(k4, k4, false);
+            printf("alone (us per launch): K-cost march %.1f   K-smooth p5+box %.1f   K-cost march4 %.1f\n", c, sm, m4);
+            const double cs = wall(kc, ks, true), cc = wall(kc, kc, true), ss = wall(ks, ks, true), s4 = wall(k4, ks, true);
+            printf("side by side on two streams (us per pair of launches; the sum of the two alone in brackets):\n");
+            printf("  K-cost march  + K-smooth  %.1f (%.1f)  -> %.2f of the sum\n", cs, c + sm, cs / (c + sm));
+            printf("  K-cost march4 + K-smooth  %.1f (%.1f)  -> %.2f of the sum\n", s4, m4 + sm, s4 / (m4 + sm));
+            printf("  K-cost march  + K-cost    %.1f (%.1f)  -> %.2f\n", cc, 2 * c, cc / (2 * c));
+            printf("  K-smooth      + K-smooth  %.1f (%.1f)  -> %.2f\n", ss, 2 * sm, ss / (2 * sm));
+        }
+        return 0;
+    }
     timeit("k_smooth_fused p5", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 0); });
     timeit("k_smooth_fused p5+box", [&]() { launch_smooth_fused(st, d, o, W, H, 5, 1); });
     {
