@@ -559,7 +559,9 @@ int main(int argc, char **argv)
             CK(hipDeviceSynchronize());
             return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
         };
-        for (int round = 0; round < 2; round++) {
+        for (int round = 0; round < 3; round++) {
+            march4_small_registers = round == 2;  // third round: k_cost_march4 compiled for 8 waves per SIMD (<= 64 VGPRs): it fits beside two K-smooth workgroups
+            if (round == 2) printf("k_cost_march4 at <= 64 VGPRs:\n");
             const double c = wall(kc, kc, false), sm = wall(ks, ks, false), m4 = wall(k4, k4, false);
             printf("alone (us per launch): K-cost march %.1f   K-smooth p5+box %.1f   K-cost march4 %.1f\n", c, sm, m4);
             const double cs = wall(kc, ks, true), cc = wall(kc, kc, true), ss = wall(ks, ks, true), s4 = wall(k4, ks, true);

@@ -277,7 +277,10 @@ __device__ __forceinline__ void epilogue_wave(const float *__restrict__ d3, floa
 }  // namespace m4
 
 // grid: one workgroup of four waves per strip of m4::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
-__global__ __launch_bounds__(256, 4) void k_cost_march4(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3, float *__restrict__ nd3,
+// WAVES: the occupancy the register allocation is made for -- 4 waves per SIMD in the product (70 VGPRs); 8 (<= 64 VGPRs, a few spilled) is the
+// development form that fits beside two resident K-smooth workgroups on a CU (tools/kbench mode 18)
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_cost_march4(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3, float *__restrict__ nd3,
                                                        int W, int H, float thr, int blend, int strips_x, int n_strips, int Hs,
                                                        const unsigned *__restrict__ range_bad, SeedMap sm, Batch bt)
 {
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(256, 4) void k_cost_march4(Img3 L, Img3 R, const fl
 #undef UGSM_M4_DISPATCH
 }
 
+#ifdef UGSM_DEV_KERNELS
+int march4_small_registers = 0;  // (tools/kbench)
+#endif
 // Strip height: every strip resident at once (four workgroups of four waves per CU: one wave of every workgroup per SIMD), the
 // shortest strips that still fit -- a launch lasts (rows + halo + prologue) row steps.
 int march4_strip_rows(int W, int H, int pairs)
@@ -341,7 +347,13 @@ void launch_cost_march4(hipStream_t st, Img3 L, Img3 R, const float *A3, const f
     const int Hs = rows > 0 ? rows : march4_strip_rows(W, H, pairs);
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    hipLaunchKernelGGL(k_cost_march4, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
+#ifdef UGSM_DEV_KERNELS
+    if (march4_small_registers) {
+        hipLaunchKernelGGL(k_cost_march4<8>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL(k_cost_march4<4>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
 }
 
 }  // namespace ugsm
