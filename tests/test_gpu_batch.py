@@ -301,3 +301,37 @@ def test_window_only_pyramids_do_not_serve_a_later_fine_phase(lib):
         assert_bit_equal(c.to_host(st[1], (3, F, fh, fw)), c.to_host(st[2], (3, F, fh, fw)), "split phases on whole pyramids vs the one-shot call")
         for p in [dL, dR, state] + st:
             c.free(p)
+
+
+@pytest.mark.parametrize("knobs", [{"UGSM_PYR_BASE_STREAM": "2"}, {"UGSM_PYR_BASE_STREAM": "0", "UGSM_PYR_STREAM": "0"}, {}], ids=["streaming", "tiled", "default"])
+def test_both_forms_of_the_pyramid_kernels(lib, orc, monkeypatch, knobs):
+    """Round 4's streaming pyramid kernels (k_pyr_base_march: foveated calls by default; k_blur_decimate2: every factor-2 level) and the
+    LDS-tiled ones they stand beside, each forced onto full AND foveated calls, single and batched, at sizes that are not multiples of
+    anything: pyramid stacks (the levels themselves) and disparities against the oracle."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for (W, H, lv, F) in [(333, 251, 9, 4), (1283, 731, 12, 6)]:
+        B = 3
+        offs = [(0, 0), (W // 7, -H // 9), (-W, H)]
+        pairs = _pairs(W, H, B, 4100 + W)
+        with lib.Context(levels=lv, fovea_levels=F, slots=2, batch=B) as c:
+            full = _full_batch(c, pairs, W, H)
+            st, pl, pr = _fovea_batch(c, lib, pairs, W, H, lv, F, offs, want_pyr=True)
+            lvl = c.alloc(3 * W * H * 4)
+            dL = c.to_device(pairs[0][0])
+            got_levels = []
+            ws, hs = lib.level_dims(W, H, lv)
+            for i in range(min(lv, 5)):
+                c.check(c.lib.ugsm_stage_pyramid(c.handle, dL, W, H, 3 * W, i, lvl))
+                got_levels.append(c.to_host(lvl, (3, hs[i], ws[i])))
+            c.free(lvl)
+            c.free(dL)
+        pyr = orc.pyramid(orc.rgb_to_planes(pairs[0][0]), lv)
+        for i, g in enumerate(got_levels):
+            assert_bit_equal(g, pyr[i], f"{W}x{H} {knobs}: pyramid level {i}")
+        for b in range(B):
+            assert_bit_equal(full[b], orc.match_full(pairs[b][0], pairs[b][1], lv), f"{W}x{H} {knobs}: full, pair {b}")
+            est, epl, epr = orc.match_foveated(pairs[b][0], pairs[b][1], lv, F, offs[b][0], offs[b][1], want_pyr=True)
+            assert_bit_equal(st[b], est, f"{W}x{H} {knobs}: foveated stack, pair {b}")
+            assert_bit_equal(pl[b], epl, f"{W}x{H} {knobs}: left pyramid stack, pair {b}")
+            assert_bit_equal(pr[b], epr, f"{W}x{H} {knobs}: right pyramid stack, pair {b}")

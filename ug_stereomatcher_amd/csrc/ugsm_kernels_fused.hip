@@ -1831,12 +1831,147 @@ __global__ __launch_bounds__(256) void k_pyr_base(const uint8_t *__restrict__ rg
     if (bad && range_bad) *range_bad = 1u;
 }
 
+// K-pyr-base, streaming form (round 4): the same three levels from the same rgb8 input with the same arithmetic, without LDS.  The tiled
+// kernel above is bound by its LDS passes (ablations, tools/kbench mode 9: 44 us of 132 without them at 16 MP); here ONE WAVE owns a strip of
+// 60 image columns and marches down HS rows: lane l holds column X0 + l, a row is three byte loads per lane; the dense row pass of every
+// channel is the systolic DPP chain of the marching K-cost (taps in the reference's order, the window centred on column c complete in lane
+// c + 2); the column pass slides a window of five row-pass values per channel down the rows and is evaluated only at the rows that are a
+// sampling site of level 1 or level 2 -- both levels sample the SAME blurred image (MatchGPULib.cpp:1071-1096), so one value serves both.
+// A lane's column is fixed for the strip: whether it is a sampling site of level 1 (floor((i + .5f) * (float)SCALE)) or of level 2
+// (2 i + 1), and which output column it feeds, is worked out once; the row's sites are wave-uniform.  Level 0 leaves from the loaded values.
+__device__ __forceinline__ int pyr_site_index(const int pos, const float sf, const int n_src, const int n_dst)  // i with tex_index((i + .5f) * sf, n_src) == pos, or -1
+{
+    const int i0 = (int)((float)pos / sf);
+#pragma unroll
+    for (int d = -2; d <= 2; d++) {
+        const int i = i0 + d;
+        if (i >= 0 && i < n_dst && tex_index(((float)i + 0.5f) * sf, n_src) == pos) return i;
+    }
+    return -1;
+}
+template <int HS>
+__global__ __launch_bounds__(256) void k_pyr_base_march(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ lvl0,
+                                                        float *__restrict__ lvl1, int W1, int H1, float *__restrict__ lvl2, int W2, int H2,
+                                                        unsigned *__restrict__ range_bad, int strips_x, int n_strips, Batch bt, PyrWindow win)
+{
+    if (bt.n > 1) {  // this workgroup's image of the batch (blockIdx.y)
+        const int b = (int)blockIdx.y;
+        rgb = shifted(rgb, bt.img[b]);
+        lvl0 = shifted(lvl0, bt.out[b]);
+        lvl1 = shifted(lvl1, bt.out[b]);
+        lvl2 = shifted(lvl2, bt.out[b]);
+        if (range_bad) range_bad += bt.cx[b];
+        win.x0 = (int)(bt.in[b] & 0xffffffffll);
+        win.y0 = (int)(bt.in[b] >> 32);
+    }
+    constexpr int VXS = 60;
+    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (wv >= n_strips) return;
+    const int sy = wv / strips_x, sx = wv - sy * strips_x;
+    const int lane = threadIdx.x & 63;
+    const int pc = sx * VXS - 2 + lane;        // the column whose pixel this lane holds
+    const int cc = pc - 2;                     // ... and the column whose row-pass window is complete in this lane
+    const int y0 = sy * HS;
+    const int y1 = min(y0 + HS, H);            // centre rows y0 .. y1 - 1
+    const float sf1 = (float)1.41421356, sf2 = 2.0f;
+    const bool cin = pc >= 0 && pc < W;
+    const bool own = lane >= 2 && lane < 2 + VXS && pc < W;  // columns sx * 60 .. + 59: this lane stores their level-0 pixels
+    const bool centre = lane >= 4 && cc < W;   // lanes 4 .. 63 hold the windows of columns sx * 60 .. + 59
+    const int i1 = centre ? pyr_site_index(cc, sf1, W, W1) : -1;
+    const int i2 = (centre && (cc & 1) && (cc >> 1) < W2 && tex_index(((float)(cc >> 1) + 0.5f) * sf2, W) == cc) ? (cc >> 1) : -1;
+    // level 0 is stored where the call reads it: everywhere (win.w <= 0) or in the strips that touch the fovea window
+    const bool store0 = win.w <= 0 || (sx * VXS < win.x0 + win.w && sx * VXS + VXS > win.x0 && y0 < win.y0 + win.h && y1 > win.y0);
+    const size_t n0 = (size_t)W * H, n1 = (size_t)W1 * H1, n2 = (size_t)W2 * H2;
+    const uint8_t *const col = rgb + 3 * (size_t)clampi(pc, 0, W - 1);
+    auto load = [&](const int y, unsigned (&b)[3]) {
+        const uint8_t *p = col + (size_t)clampi(y, 0, H - 1) * stride;
+        b[0] = p[0];
+        b[1] = p[1];
+        b[2] = p[2];
+    };
+    float w[3][5];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int u = 0; u < 5; u++) w[k][u] = 0.0f;
+    bool bad = false;
+    unsigned bcur[3], bnx1[3], bnx2[3];
+    load(y0 - 2, bcur);
+    load(y0 - 1, bnx1);
+    // the next level-1 row whose sampling site lies at or below y0, and that site (the sites increase strictly: a row is the site of one j at most)
+    int jn = max((int)((float)y0 / sf1) - 2, 0);
+    int sn = tex_index(((float)jn + 0.5f) * sf1, H);
+    while (sn < y0 && jn < H1) {
+        jn++;
+        sn = tex_index(((float)jn + 0.5f) * sf1, H);
+    }
+    for (int y = y0 - 2; y < y1 + 2; y++) {
+        load(y + 2, bnx2);  // two rows ahead of the arithmetic
+        const bool yin = y >= 0 && y < H;
+        const int cr = y - 2;  // the row whose column window is complete once row y is in
+        // (wave-uniform) is cr a sampling row of level 1 / level 2?
+        int j1 = -1;
+        if (cr >= y0 && cr < y1 && jn < H1 && cr == sn) {
+            j1 = jn;
+            jn++;
+            sn = tex_index(((float)jn + 0.5f) * sf1, H);
+        }
+        const int j2 = (cr >= y0 && cr < y1 && (cr & 1) && (cr >> 1) < H2) ? (cr >> 1) : -1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float v = (cin && yin) ? (float)bcur[k] : 0.0f;  // zero padding (U2/U3)
+            if (store0 && own && y >= y0 && y < y1) lvl0[k * n0 + (size_t)y * W + pc] = v;
+            // row pass (level-0 values are >= 0: tap5p = tap5 without its "0 +"), the partial sum travels one lane to the right per tap
+            const float a0 = v * UGSM_G0, a1 = v * UGSM_G1, a2 = v * UGSM_G2;
+            const float p2 = lane_below(a0) + a1;
+            const float p3 = lane_below(p2) + a2;
+            const float p4 = lane_below(p3) + a1;
+            w[k][0] = w[k][1];
+            w[k][1] = w[k][2];
+            w[k][2] = w[k][3];
+            w[k][3] = w[k][4];
+            w[k][4] = lane_below(p4) + a0;
+        }
+        if (j1 >= 0 || j2 >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float o = tap5p(w[k][0], w[k][1], w[k][2], w[k][3], w[k][4]);
+                if (j1 >= 0 && i1 >= 0) {
+                    lvl1[k * n1 + (size_t)j1 * W1 + i1] = o;
+                    bad |= !range_ok(o);
+                }
+                if (j2 >= 0 && i2 >= 0) {
+                    lvl2[k * n2 + (size_t)j2 * W2 + i2] = o;
+                    bad |= !range_ok(o);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            bcur[k] = bnx1[k];
+            bnx1[k] = bnx2[k];
+        }
+    }
+    if (bad && range_bad) *range_bad = 1u;
+}
+int pyr_base_streaming = 1;  // (development: UGSM_PYR_BASE_STREAM=0 -> the LDS-tiled k_pyr_base)
+
 void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *lvl0, float *lvl1, int W1, int H1, float *lvl2, int W2,
                      int H2, unsigned *range_bad, const Batch *bt, PyrWindow win)
 {
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
+    // Streaming form for the foveated calls only (win.w > 0: level 0 is stored in the window's strips alone).  Where level 0 is written
+    // whole -- 193 of 338 MB per 16 MP image -- the tiled kernel's aligned 16-byte stores win: 132 against 151 us per image, 16 MP full mode
+    // 183.7 against 179.4 pairs/s; foveated batches 880 -> 903 pairs/s with it (tools/ab.py, same box).  UGSM_PYR_BASE_STREAM=2: everywhere.
+    if ((pyr_base_streaming == 1 && win.w > 0) || pyr_base_streaming == 2) {
+        constexpr int HS = 32;
+        const int strips_x = (W + 59) / 60, n_strips = strips_x * ((H + HS - 1) / HS);
+        hipLaunchKernelGGL(k_pyr_base_march<HS>, dim3((n_strips + 3) / 4, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
+                           H2, range_bad, strips_x, n_strips, B, win);
+        return;
+    }
     const int tiles_x = (W + BTX - 1) / BTX, n_tiles = tiles_x * ((H + BTY - 1) / BTY);
     hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B, win);
 }

@@ -122,6 +122,7 @@ extern int smooth_pipe_workgroups;
 #endif
 extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
 extern int blur_decimate_streaming;  // (development: UGSM_PYR_STREAM)
+extern int pyr_base_streaming;       // (development: UGSM_PYR_BASE_STREAM)
 extern long long blur_decimate_streaming_min;  // (development: UGSM_PYR_STREAM_MIN)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
