@@ -283,7 +283,8 @@ int ugsm_stage_weighted_difference(ugsm_ctx *ctx, const float *d_new3, const flo
 /* The LR-consistency check (ugsm_config.lr_check_threshold; no reference counterpart) on two device (dx, dy, conf) fields: zeroes
  * d_left3's confidence where d_right3 does not point back within tau; *marked (host, may be NULL) = number of pixels marked. */
 int ugsm_stage_lr_check(ugsm_ctx *ctx, float *d_left3, const float *d_right3, int W, int H, float tau, long long *marked);
-/* Pixels the LR check of the last full-mode call on `slot` marked (-1: the call ran without the check).  Valid after ugsm_wait. */
+/* Pixels the LR check of the last full-mode call on `slot` marked (-1: the call ran without the check; a batched call, which such a
+ * context runs pair by pair: of its last pair).  Valid after ugsm_wait. */
 long long ugsm_last_lr_marked(ugsm_ctx *ctx, int slot);
 /* Iterations each level of the last call on `slot` actually ran (early_exit_threshold > 0 can stop a level early);
  * per_level[UGSM_MAX_LEVELS], -1 for levels not run.  ugsm_stage_iterate records its count at index 0. */
