@@ -1979,7 +1979,8 @@ void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int 
 int blur_decimate_streaming = 1;  // (development: UGSM_PYR_STREAM=0 -> the tiled kernel for the factor-2 levels too)
 long long blur_decimate_streaming_min = 0;  // (development: UGSM_PYR_STREAM_MIN: launches of fewer output pixels keep the tiled kernel)
 // bt (optional): bt->n IMAGES in one launch -- image j reads src3 + in[j], writes dst3 + out[j] and reports into range_bad[cx[j]]
-void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt)
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt,
+                          long long stream_min)
 {
     Batch one{};
     one.n = 1;
@@ -1997,7 +1998,7 @@ void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float
     }
 #endif
     const long long out_px = (long long)W2 * H2 * images;
-    if (sf == 2.0f && blur_decimate_streaming && out_px >= blur_decimate_streaming_min) {  // every level from the third on: the streaming form
+    if (sf == 2.0f && blur_decimate_streaming && out_px >= std::max(blur_decimate_streaming_min, stream_min)) {  // every level from the third on: the streaming form
         const int hs = out_px >= 400000 ? 16 : (out_px >= 40000 ? 8 : 4);  // short strips where there are few: a launch lasts as long as one wave
         const int strips_x = (W2 + 29) / 30, n_strips = strips_x * ((H2 + hs - 1) / hs);
         const dim3 grid((3 * n_strips + 3) / 4, images);

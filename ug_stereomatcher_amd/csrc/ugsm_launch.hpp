@@ -126,7 +126,9 @@ extern int pyr_base_streaming;       // (development: UGSM_PYR_BASE_STREAM)
 extern long long blur_decimate_streaming_min;  // (development: UGSM_PYR_STREAM_MIN)
 // zero-padded blur evaluated at the decimation sites, LDS-tiled
 // (range_bad: see launch_range_scan below; every level value written is checked as it is produced; may be null)
-void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt = nullptr);
+// stream_min: launches of fewer output pixels keep the LDS-tiled kernel for a factor-2 level too (0 = the streaming kernel k_blur_decimate2 always)
+void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf, unsigned *range_bad, const Batch *bt = nullptr,
+                          long long stream_min = 0);
 // The part of level 0 a foveated call reads: the fovea window (w x h at (x0, y0), level-0 pixels); w <= 0: everything (full mode).  In a
 // batched launch the origin of image b's window is bt->in[b] = (y0 << 32) | x0.
 struct PyrWindow {

@@ -564,6 +564,11 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
         for (int j = 0; j < nb; j++) bt0.in[j] = ((long long)win->y0[j] << 32) | (unsigned)win->x0[j];
     const PyrWindow pw = win ? PyrWindow{win->x0[0], win->y0[0], win->w, win->h} : PyrWindow{0, 0, 0, 0};
     const Batch *const pb = nb > 1 ? &bt : nullptr;
+    // One full-mode pair alone on the chip (a one-slot context): the streaming factor-2 kernel's many short workgroups on the side stream get
+    // in the way of the main stream's latency-bound launches -- 112.3 pairs/s with it on every level, 114.4 with it on the launches of
+    // >= 1.5 M outputs only, 114.1 without it (tools/ab.py, same box); foveated calls and everything with more in flight gain from it
+    // on every level (a lone foveated pair +1.8 %, batches of eight +3.3 %).
+    const long long stream_min = (ctx->cfg.slots == 1 && nb == 1 && !win) ? 1500000 : 0;
     s.cur_level = 0;
     if (base) {
         Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H * nb);
@@ -582,14 +587,14 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[1] * s.h[1] * nb);
             float sf = (float)kScale;
             if (ref) launch_blur_decimate_ref(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf);
-            else launch_blur_decimate(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad, pb);
+            else launch_blur_decimate(pst, pyr + s.off[0], s.w[0], s.h[0], pyr + s.off[1], s.w[1], s.h[1], sf, s.range_bad, pb, stream_min);
         }
         if (i + 2 < levels && !(base && i == 0)) {
             s.cur_level = i + 2;
             Timer t(ctx, &s, si, KC_PYR, (double)s.w[i + 2] * s.h[i + 2] * nb);
             float sf = (float)(0.000 + (int)(kScale * kScale + 0.5));  // :1090
             if (ref) launch_blur_decimate_ref(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf);
-            else launch_blur_decimate(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad, pb);
+            else launch_blur_decimate(pst, pyr + s.off[i], s.w[i], s.h[i], pyr + s.off[i + 2], s.w[i + 2], s.h[i + 2], sf, s.range_bad, pb, stream_min);
         }
     }
     s.cur_level = kNoLevel;
