@@ -565,9 +565,31 @@ def main():
                 return (time.perf_counter() - t0) / n
             piped(2 * slots)
             t_piped = min(piped(12 * slots) for _ in range(2))
+            # ... and in batches (ugsm_submit_full_batch_host): every slot takes Bh pairs per call, each pair with page-locked buffers of its own
+            Bh = 2
+            t_piped_b = None
+            if B > 1:
+                hbb = [hb[sl:sl + 1] + [(ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W))) for _ in range(Bh - 1)]
+                       for sl in range(slots)]
+                for group in hbb:
+                    for (a_, b_, _) in group[1:]:
+                        a_[...] = L
+                        b_[...] = R
+
+                def piped_b(n):
+                    t0 = time.perf_counter()
+                    for k in range(n // Bh):
+                        sl = k % slots
+                        ctx.check(ctx.lib.ugsm_wait(ctx.handle, sl))
+                        ctx.submit_full_batch_host(sl, [g[0] for g in hbb[sl]], [g[1] for g in hbb[sl]], W, H, stride, [g[2] for g in hbb[sl]])
+                    ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
+                    return (time.perf_counter() - t0) / (n // Bh * Bh)
+                piped_b(2 * slots * Bh)
+                t_piped_b = min(piped_b(12 * slots * Bh) for _ in range(2))
             result["pcie_inclusive"] = {"pageable_ms_per_pair": 1e3 * t_page, "pageable_pairs_per_s": 1.0 / t_page,
                                         "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
                                         "pinned_in_flight_pairs_per_s": 1.0 / t_piped, "pinned_in_flight_slots": slots,
+                                        "pinned_in_flight_batched_pairs_per_s": (1.0 / t_piped_b) if t_piped_b else None, "pinned_in_flight_batch": Bh,
                                         "pinned_in_flight_GBps_over_pcie": (2 * H * stride + 12 * W * H) / t_piped / 1e9,
                                         "note": "ugsm_match_full on a one-slot context, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
                                                 "(193 MB); median of 3 calls; pageable = fresh result planes for every call, as the reference "

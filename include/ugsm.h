@@ -206,6 +206,14 @@ int ugsm_submit_full_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const 
 int ugsm_submit_foveated_batch(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *d_rgbL, const uint8_t *const *d_rgbR,
                                int W, int H, int stride, const int *off_x, const int *off_y, float *const *d_stack,
                                float *const *d_pyrL, float *const *d_pyrR);
+/* The same from PAGE-LOCKED host memory (as ugsm_submit_full_host / ugsm_submit_foveated_host): the uploads of all n pairs, one batched
+ * match and the downloads of all results are enqueued on the slot's stream and the call returns; ugsm_wait(slot) before the results are read
+ * or the slot is used again.  Every buffer page-locked, else UGSM_ERR_BAD_ARG.  (No pyramid stacks in the foveated form.) */
+int ugsm_submit_full_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *rgbL, const uint8_t *const *rgbR,
+                                int W, int H, int stride, float *const *dispH, float *const *dispV, float *const *dispC);
+int ugsm_submit_foveated_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *rgbL, const uint8_t *const *rgbR,
+                                    int W, int H, int stride, const int *off_x, const int *off_y, float *const *stackH,
+                                    float *const *stackV, float *const *stackC);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
 int ugsm_wait_all(ugsm_ctx *ctx);
 /* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the

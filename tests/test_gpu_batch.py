@@ -335,3 +335,36 @@ def test_both_forms_of_the_pyramid_kernels(lib, orc, monkeypatch, knobs):
             assert_bit_equal(st[b], est, f"{W}x{H} {knobs}: foveated stack, pair {b}")
             assert_bit_equal(pl[b], epl, f"{W}x{H} {knobs}: left pyramid stack, pair {b}")
             assert_bit_equal(pr[b], epr, f"{W}x{H} {knobs}: right pyramid stack, pair {b}")
+
+
+def test_batches_from_page_locked_host_memory(lib, orc):
+    """ugsm_submit_full_batch_host / ugsm_submit_foveated_batch_host: uploads, one batched match and downloads enqueued on the slot's stream;
+    page-locked images and results (pageable ones are refused); every pair against the oracle; two slots in flight."""
+    import ctypes as C
+    W, H, lv, F, B = 640, 480, 12, 5, 3
+    pairs = _pairs(W, H, 2 * B, 5200)
+    offs = [(0, 0), (90, -60), (-2000, 2000)]
+    fw, fh = lib.fovea_dims(W, H, lv, F)
+    with lib.Context(levels=lv, fovea_levels=F, slots=2, batch=B) as c:
+        hL = [c.host_array((H, W, 3), np.uint8) for _ in pairs]
+        hR = [c.host_array((H, W, 3), np.uint8) for _ in pairs]
+        for (L, R), a, b in zip(pairs, hL, hR):
+            a[...] = L
+            b[...] = R
+        outs = [c.host_array((3, H, W)) for _ in pairs]
+        for s in range(2):
+            c.submit_full_batch_host(s, hL[s * B:(s + 1) * B], hR[s * B:(s + 1) * B], W, H, 3 * W, outs[s * B:(s + 1) * B])
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        for b, (L, R) in enumerate(pairs):
+            assert_bit_equal(outs[b], orc.match_full(L, R, lv), f"full batch from host memory, pair {b}")
+        stacks = [c.host_array((3, F, fh, fw)) for _ in range(B)]
+        c.submit_foveated_batch_host(1, hL[:B], hR[:B], W, H, 3 * W, offs, stacks)
+        c.check(c.lib.ugsm_wait(c.handle, 1))
+        for b in range(B):
+            est, _, _ = orc.match_foveated(pairs[b][0], pairs[b][1], lv, F, offs[b][0], offs[b][1])
+            assert_bit_equal(stacks[b], est, f"foveated batch from host memory, pair {b}, offset {offs[b]}")
+        # pageable buffers are refused, not copied synchronously
+        pageable = np.empty((3, H, W), np.float32)
+        bad = (C.c_void_p * B)(*[pageable[0].ctypes.data] * B)
+        good = lambda arrs: (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
+        assert c.lib.ugsm_submit_full_batch_host(c.handle, 0, B, good(hL[:B]), good(hR[:B]), W, H, 3 * W, bad, bad, bad) == lib.UGSM_ERR_BAD_ARG

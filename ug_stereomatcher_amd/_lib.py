@@ -34,7 +34,7 @@ EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_is_dev_library", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
     "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full", "ugsm_submit_full_host", "ugsm_submit_foveated_host",
-    "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_submit_full_batch", "ugsm_submit_foveated_batch",
+    "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_submit_full_batch", "ugsm_submit_foveated_batch", "ugsm_submit_full_batch_host", "ugsm_submit_foveated_batch_host",
     "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
@@ -133,6 +133,8 @@ def load(dev: bool = False):
     pp = C.POINTER(vp)
     lib.ugsm_submit_full_batch.argtypes = [vp, i, i, pp, pp, i, i, i, pp]
     lib.ugsm_submit_foveated_batch.argtypes = [vp, i, i, pp, pp, i, i, i, ip, ip, pp, pp, pp]
+    lib.ugsm_submit_full_batch_host.argtypes = [vp, i, i, pp, pp, i, i, i, pp, pp, pp]
+    lib.ugsm_submit_foveated_batch_host.argtypes = [vp, i, i, pp, pp, i, i, i, ip, ip, pp, pp, pp]
     lib.ugsm_wait.argtypes = [vp, i]
     lib.ugsm_wait_all.argtypes = [vp]
     lib.ugsm_submit_pyramids.argtypes = [vp, i, vp, vp, i, i, i]
@@ -344,6 +346,22 @@ class Context:
         self.check(self.lib.ugsm_submit_foveated_batch(self._h, slot, n, self._ptrs(d_rgbL), self._ptrs(d_rgbR), W, H, stride, ox, oy, self._ptrs(d_stack),
                                                        self._ptrs(d_pyrL) if d_pyrL is not None else None,
                                                        self._ptrs(d_pyrR) if d_pyrR is not None else None))
+
+    def submit_full_batch_host(self, slot: int, rgbL, rgbR, W: int, H: int, stride: int, outs):
+        """rgbL / rgbR: lists of page-locked uint8 arrays (host_array); outs: list of page-locked (3, H, W) float32 arrays."""
+        n = len(rgbL)
+        self.check(self.lib.ugsm_submit_full_batch_host(self._h, slot, n, self._ptrs([a.ctypes.data for a in rgbL]), self._ptrs([a.ctypes.data for a in rgbR]),
+                                                        W, H, stride, self._ptrs([o[0].ctypes.data for o in outs]), self._ptrs([o[1].ctypes.data for o in outs]),
+                                                        self._ptrs([o[2].ctypes.data for o in outs])))
+
+    def submit_foveated_batch_host(self, slot: int, rgbL, rgbR, W: int, H: int, stride: int, offsets, stacks):
+        """stacks: list of page-locked (3, F, fovH, fovW) float32 arrays."""
+        n = len(rgbL)
+        ox = (C.c_int * n)(*[int(o[0]) for o in offsets]) if offsets is not None else None
+        oy = (C.c_int * n)(*[int(o[1]) for o in offsets]) if offsets is not None else None
+        self.check(self.lib.ugsm_submit_foveated_batch_host(self._h, slot, n, self._ptrs([a.ctypes.data for a in rgbL]), self._ptrs([a.ctypes.data for a in rgbR]),
+                                                            W, H, stride, ox, oy, self._ptrs([t[0].ctypes.data for t in stacks]),
+                                                            self._ptrs([t[1].ctypes.data for t in stacks]), self._ptrs([t[2].ctypes.data for t in stacks])))
 
     def kernel_stats(self):
         """One dict per (kernel, pyramid level) with harvested launches; level -1 = not tied to a level."""

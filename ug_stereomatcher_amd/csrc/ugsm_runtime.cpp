@@ -1844,6 +1844,112 @@ int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, cons
     return match_foveated_on_slot(ctx, slot, rgbL, rgbR, W, H, stride, off_x, off_y, stackH, stackV, stackC, pyrL, pyrR, false);
 }
 
+// ---- batches from page-locked host memory (round 4): the uploads of all pairs, ONE batched match, the downloads of all pairs, enqueued on
+// the slot's stream.  The images are staged in the slot (pair b at rgbL / rgbR + b * image bytes), the results in hout.
+static bool all_pinned(const void *const *p, int n)
+{
+    for (int b = 0; b < n; b++)
+        if (!p[b] || !is_pinned(p[b])) return false;
+    return true;
+}
+static int stage_in_batch(ugsm_ctx *ctx, Slot &s, int n, const uint8_t *const *rgbL, const uint8_t *const *rgbR, int W, int H, int stride,
+                          const uint8_t **dL, const uint8_t **dR)
+{
+    if (W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
+    if (stride < 3 * W) return UGSM_ERR_SIZE_MISMATCH;
+    const size_t bytes = ((size_t)stride * H + 255) & ~(size_t)255;
+    if (bytes * n > s.rgb_cap) {
+        size_t c = s.rgb_cap;
+        UCHK(grow(ctx, s.rgbL, c, bytes * n));
+        UCHK(grow(ctx, s.rgbR, s.rgb_cap, bytes * n));
+    }
+    for (int b = 0; b < n; b++) {
+        dL[b] = s.rgbL + b * bytes;
+        dR[b] = s.rgbR + b * bytes;
+        HIPCHK(ctx, hipMemcpyAsync(s.rgbL + b * bytes, rgbL[b], (size_t)stride * H, hipMemcpyHostToDevice, s.st));
+        HIPCHK(ctx, hipMemcpyAsync(s.rgbR + b * bytes, rgbR[b], (size_t)stride * H, hipMemcpyHostToDevice, s.st));
+    }
+    return UGSM_OK;
+}
+
+int ugsm_submit_full_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *rgbL, const uint8_t *const *rgbR, int W, int H, int stride,
+                                float *const *dispH, float *const *dispV, float *const *dispC)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (n < 1 || n > UGSM_MAX_BATCH || !rgbL || !rgbR || !dispH || !dispV || !dispC) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (!all_pinned((const void *const *)rgbL, n) || !all_pinned((const void *const *)rgbR, n) || !all_pinned((const void *const *)dispH, n) ||
+        !all_pinned((const void *const *)dispV, n) || !all_pinned((const void *const *)dispC, n)) {
+        ctx->err = "ugsm_submit_full_batch_host: every host buffer must be page-locked (ugsm_host_alloc, hipHostMalloc or hipHostRegister)";
+        return UGSM_ERR_BAD_ARG;
+    }
+    if (n == 1 || batch_runs_pair_by_pair(ctx)) {
+        for (int b = 0; b < n; b++) UCHK(match_full_on_slot(ctx, slot, rgbL[b], rgbR[b], W, H, stride, dispH[b], dispV[b], dispC[b], false));
+        return UGSM_OK;
+    }
+    const uint8_t *dL[UGSM_MAX_BATCH], *dR[UGSM_MAX_BATCH];
+    UCHK(stage_in_batch(ctx, *s, n, rgbL, rgbR, W, H, stride, dL, dR));
+    const size_t px = (size_t)W * H, per = (3 * px + 63) & ~(size_t)63;
+    UCHK(grow(ctx, s->hout, s->hout_cap, std::max(per * n, s->hout_cap)));
+    float *out[UGSM_MAX_BATCH];
+    for (int b = 0; b < n; b++) out[b] = s->hout + b * per;
+    UCHK(enqueue_pyramids(ctx, *s, slot, dL, dR, n, W, H, stride));
+    s->lr_ran = false;
+    UCHK(enqueue_full(ctx, *s, slot, out));
+    for (int b = 0; b < n; b++) {
+        float *const dst[3] = {dispH[b], dispV[b], dispC[b]};
+        UCHK(copy_out_planes(ctx, *s, out[b], px, dst));  // (page-locked destinations: three asynchronous copies)
+    }
+    return mark_done(ctx, *s);
+}
+
+int ugsm_submit_foveated_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_t *const *rgbL, const uint8_t *const *rgbR, int W, int H, int stride,
+                                    const int *off_x, const int *off_y, float *const *stackH, float *const *stackV, float *const *stackC)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s));
+    if (n < 1 || n > UGSM_MAX_BATCH || !rgbL || !rgbR || !stackH || !stackV || !stackC) return UGSM_ERR_BAD_ARG;
+    const int F = ctx->cfg.fovea_levels;
+    if (F < 2) return UGSM_ERR_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (!all_pinned((const void *const *)rgbL, n) || !all_pinned((const void *const *)rgbR, n) || !all_pinned((const void *const *)stackH, n) ||
+        !all_pinned((const void *const *)stackV, n) || !all_pinned((const void *const *)stackC, n)) {
+        ctx->err = "ugsm_submit_foveated_batch_host: every host buffer must be page-locked (ugsm_host_alloc, hipHostMalloc or hipHostRegister)";
+        return UGSM_ERR_BAD_ARG;
+    }
+    int zeros[UGSM_MAX_BATCH] = {0};
+    const int *ox = off_x ? off_x : zeros, *oy = off_y ? off_y : zeros;
+    if (n == 1 || batch_runs_pair_by_pair(ctx)) {
+        for (int b = 0; b < n; b++)
+            UCHK(match_foveated_on_slot(ctx, slot, rgbL[b], rgbR[b], W, H, stride, ox[b], oy[b], stackH[b], stackV[b], stackC[b], nullptr, nullptr, false));
+        return UGSM_OK;
+    }
+    int fw, fh;
+    UCHK(ugsm_fovea_dims(W, H, ctx->cfg.levels, F, &fw, &fh));
+    const uint8_t *dL[UGSM_MAX_BATCH], *dR[UGSM_MAX_BATCH];
+    UCHK(stage_in_batch(ctx, *s, n, rgbL, rgbR, W, H, stride, dL, dR));
+    const size_t fn = (size_t)fw * fh, stackn = (size_t)F * fn;
+    const size_t st_per = (3 * fn + 63) & ~(size_t)63, sk_per = (3 * stackn + 63) & ~(size_t)63;  // hout: [states n x st_per][stacks n x sk_per]
+    UCHK(grow(ctx, s->hout, s->hout_cap, std::max(n * (st_per + sk_per), s->hout_cap)));
+    float *state[UGSM_MAX_BATCH], *stack[UGSM_MAX_BATCH];
+    for (int b = 0; b < n; b++) {
+        state[b] = s->hout + b * st_per;
+        stack[b] = s->hout + n * st_per + b * sk_per;
+    }
+    FoveaWin win;
+    UCHK(fovea_windows(ctx, W, H, n, ox, oy, win));
+    UCHK(enqueue_pyramids(ctx, *s, slot, dL, dR, n, W, H, stride, -1, &win));
+    UCHK(enqueue_fovea_coarse(ctx, *s, slot, state));
+    UCHK(enqueue_fovea_fine(ctx, *s, slot, state, ox, oy, stack, nullptr, nullptr));
+    for (int b = 0; b < n; b++) {
+        HIPCHK(ctx, hipMemcpyAsync(stackH[b], stack[b], stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(ctx, hipMemcpyAsync(stackV[b], stack[b] + stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(ctx, hipMemcpyAsync(stackC[b], stack[b] + 2 * stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    }
+    return mark_done(ctx, *s);
+}
+
 // match(L, R, fov == 1), MatchGPULib.cpp:354-360: foveated matching, then hierarchicalDisparity on the stacks
 int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
                              float *outH, float *outV, float *outC)
