@@ -14,9 +14,9 @@ How the line is put together (rank 0 prints ONE JSON line):
   value, ms_per_step  -- the timed region: W warm-up steps, then exactly K steps between two
                   barrier + synchronize brackets, NO event recording (bracketing launches with HIP events
                   costs the instrumented stream ~7 %).  value_repeats: the same K steps timed twice more.
-  roofline, kernels, single_pair -- a SEPARATE pass after the timed region: `--profile-pairs` pairs submitted
-                  one at a time on slot 0 with every launch bracketed by HIP events on that stream, so the
-                  durations are uncontended (what rocprofv3 --kernel-trace reports for the same kernels, since
+  roofline, kernels, event_pass -- a SEPARATE pass after the timed region: `--profile-pairs` CALLS (of `--batch` pairs each, the
+                  timed region's full-size calls) submitted one at a time on slot 0 with every launch bracketed by HIP events on
+                  that stream, so the durations are uncontended (what rocprofv3 --kernel-trace reports for the same kernels, since
                   the profiler serialises launches).  roofline = the kernel with the largest total time
                   (the per-iteration cost kernel of the large levels): algorithmic bytes (48 B per
                   pixel-iteration, SURVEY.md 8d) / duration, over all its launches and for level 0 alone;
@@ -222,7 +222,7 @@ def main():
                     "full mode, 8 for the foveated stack, 16 for 1080p (tools/ab.py, profiles/r04_ab_batch.txt)")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-pairs", type=int, default=3, help="pairs of the single-pair event pass after the timed region (0 = skip)")
+    ap.add_argument("--profile-pairs", type=int, default=3, help="calls (of --batch pairs each) of the event pass after the timed region (0 = skip)")
     ap.add_argument("--repeats", type=int, default=2, help="extra timed repetitions of the K steps (value_repeats)")
     ap.add_argument("--no-service", action="store_true", help="skip the PCIe-inclusive service-call leg")
     ap.add_argument("--single-pairs", type=int, default=12, help="pairs of the un-instrumented one-slot leg (single_pair_no_events; 0 = skip)")
@@ -402,18 +402,22 @@ def main():
         "whole_pair_algorithmic_GBps": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F) * value / n_gpus / 1e9,
     }
 
-    # ---- single-pair event pass: uncontended kernel durations (rank 0) ------------------------------------------------
+    # ---- event pass: uncontended kernel durations of the launches the timed region makes (rank 0) -------------------------------
+    # One CALL at a time on slot 0 -- a full-size call of B pairs, as the timed region submits them (round 4; rounds 1-3: single pairs) --
+    # with every launch bracketed by HIP events on its stream: the kernels and grids are those of the timed region and of
+    # `rocprofv3 --kernel-trace --stats` of this command, whose average durations these must agree with.
     if rank == 0 and args.profile_pairs > 0 and mode != "fovea-shard":
         ctx.set_profile_events(2)
         ctx.reset_kernel_stats()
         t0 = time.perf_counter()
         for k in range(args.profile_pairs):
-            submit(k, slot=0)
+            submit(k * B, slot=0, n=B)
             ctx.check(ctx.lib.ugsm_wait(ctx.handle, 0))
-        t_single = (time.perf_counter() - t0) / args.profile_pairs
+        in_slot[0] = 0
+        t_single = (time.perf_counter() - t0) / (args.profile_pairs * B)
         ctx.set_profile_events(0)
         stats = ctx.kernel_stats()
-        n_pairs = args.profile_pairs
+        n_pairs = args.profile_pairs * B
         by_name = {}
         for s in stats:
             e = by_name.setdefault(s["name"], {"launches": 0, "total_ms": 0.0, "pixel_launches": 0.0, "levels": {}})
@@ -438,8 +442,9 @@ def main():
             kernels.append(row)
         result["kernels"] = kernels
         kernel_ms = sum(e["total_ms"] for e in by_name.values()) / n_pairs
-        result["single_pair"] = {"ms_per_pair_wall": 1e3 * t_single, "pairs_per_s": 1.0 / t_single, "kernel_ms_per_pair": kernel_ms,
-                                 "pairs": n_pairs, "note": "one pair in flight, every launch bracketed by HIP events on its stream"}
+        result["event_pass"] = {"ms_per_pair_wall": 1e3 * t_single, "pairs_per_s": 1.0 / t_single, "kernel_ms_per_pair": kernel_ms,
+                                "pairs": n_pairs, "pairs_per_call": B,
+                                "note": "one call of pairs_per_call pairs in flight, every launch bracketed by HIP events on its stream"}
         # the dominant kernel: the cost kernel that carries most of the pair's pixel-iterations (the marching kernel of the large
         # levels; the LDS-tiled one only serves the latency-bound small levels)
         dom = max((k for k in kernels if k["name"].startswith("k_cost")), key=lambda k: by_name[k["name"]]["pixel_launches"], default=None)
@@ -472,9 +477,9 @@ def main():
                         [st for lv, st in e["levels"].items() if st["launches"] and st["pixel_launches"] / st["launches"] >= 200000])),
                 "traffic_source": (f"profiles/pmc_traffic.json ({prof.get('_tag', '?')}: PMC passes of tools/profile_round.sh, not measured in this run)"
                                    if traffic is not None else None),
-                "note": "algorithmic bytes (48 B per pixel-iteration x pixels of the launch) / HIP-event duration on the launching stream, "
-                        "single-pair pass after the timed region (uncontended: agrees with rocprofv3 --kernel-trace --stats of this command, "
-                        "which serialises launches); the kernel is bound by VALU issue, see valu_roofline"}
+                "note": "algorithmic bytes (48 B per pixel-iteration x pixels of the launch, all its pairs) / HIP-event duration on the launching "
+                        "stream, one call at a time after the timed region, the launches of the timed region (uncontended: agrees with rocprofv3 "
+                        "--kernel-trace --stats of this command, which serialises launches); the kernel is bound by VALU issue, see valu_roofline"}
             vpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_valu_model.json")
             if os.path.exists(vpath) and dom.get("level0") and args.workload == "full16mp":
                 try:
