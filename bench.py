@@ -372,6 +372,16 @@ def main():
     for _ in range(max(0, args.repeats)):
         repeats.append(work * args.steps / timed(args.steps))
         steady.append(steady_state(args.steps))
+    # A region too short to have a middle (the driver's --steps 20 with calls of four pairs is all fill and drain) gets its steady-state
+    # figure from one more region, long enough to have one, run after the regions `value` and `value_repeats` come from and outside them.
+    steady_region, steady_steps = "the timed region of `value`", args.steps
+    if steady_window(plan_calls(args.steps, slots, B, TAPER, HEAD), slots) is None:   # (the same answer on every rank: timed() holds barriers)
+        steady_steps = max(args.steps, 48 * B, 12 * slots * B)
+        timed(steady_steps)
+        steady[0] = steady_state(steady_steps)
+        steady_region = (f"a further region of {steady_steps} steps after the timed ones (the timed region of {args.steps} steps has no call with the pipe "
+                         "full of full-size calls on both sides); `value` and `value_repeats` do not include it")
+    steady_calls = list(call_sizes)
     pi = _lib.pixel_iterations(W, H, 14, 0 if mode == "full" else F)
 
     result = {
@@ -394,7 +404,8 @@ def main():
         # this rank's pairs/s between the completions of pair slots + 1 and pair steps - slots, inside the same timed regions as `value`
         # and `value_repeats` (first entry: the region `value` comes from); x n_gpus for independent replicas
         "steady_state": {"value": (work * steady[0]) if steady[0] else None, "repeats": [(work * v) if v else None for v in steady[1:]],
-                         "unit": "pairs/s", "calls": len(call_sizes), "call_sizes_head_tail": [call_sizes[:6], call_sizes[-6:]],
+                         "unit": "pairs/s", "region": steady_region, "steps": steady_steps, "calls": len(steady_calls),
+                         "call_sizes_head_tail": [steady_calls[:6], steady_calls[-6:]],
                          "note": "host clock at the return of ugsm_wait(slot) for every call's pairs, in submission order; the rate between the "
                                  "completions of the first and the last call that have the pipe full of full-size calls behind them: no fill, "
                                  "no drain, no staggered or tapered calls"},

@@ -36,3 +36,13 @@ def test_steady_window():
     j_hi = next(j for j in range(len(s)) if sum(s[:j + 1]) - 1 == hi)
     assert all(v == 4 for v in s[first:j_hi + 5]) and s[j_hi + 5] < 4
     assert bench.steady_window([], 4) is None and bench.steady_window([4] * 7, 4) is None
+
+
+def test_the_further_region_of_a_short_run_always_has_a_middle():
+    # bench.py: a region without a steady window (the driver's --steps 20) is followed by one of max(steps, 48 B, 12 slots B) steps
+    for slots in (1, 2, 4):
+        for B in (1, 2, 4, 8, 16):
+            for steps in (1, 5, 20):
+                n = max(steps, 48 * B, 12 * slots * B)
+                win = bench.steady_window(bench.plan_calls(n, slots, B), slots)
+                assert win is not None and win[1] - win[0] >= 8 * B, (slots, B, steps, win)
