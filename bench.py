@@ -165,18 +165,20 @@ def cpu_baseline(wl: dict, runs: int = 3):
             "host_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": cpu_model(), "all_cores": allc, "one_thread": one}
 
 
-def plan_calls(n: int, slots: int, B: int, taper: float = 1.0, head=None):
-    """Sizes of the calls that take n pairs through `slots` slots with at most B pairs per call (ugsm_submit_*_batch), in submission order.
-    A call takes as many pairs as the work still queued allows without starving the other slots: min(B, remaining / (taper x slots)), at
-    least 1 -- a host that batches what has piled up and goes back to single pairs when little is left, so that the region does not end with
-    one slot grinding through a whole batch alone.  The first round of calls is staggered in size -- slot c starts with at most
-    ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for B = 4 on four slots -- so that the slots do not march through the levels in phase
-    from a drained pipe (same box, 20 steps: 172 against 169 pairs/s; 162 for 4, 3, 2, 1).  `head` overrides the stagger (experiments)."""
+def plan_calls(n: int, slots: int, B: int, taper: float = 0.0, head=None):
+    """Sizes of the calls that take n pairs through `slots` slots with at most B pairs per call (ugsm_submit_*_batch), in submission order:
+    a host that batches what has piled up -- full-size calls while B pairs are left, the rest in one call.  The first round of calls is
+    staggered in size -- slot c starts with at most ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for B = 4 on four slots -- so that the
+    slots do not march through the levels in phase from a drained pipe (same box, 20 steps: 172 against 169 pairs/s; 162 for 4, 3, 2, 1).
+    `taper` > 0 shrinks the calls towards the end, min(B, remaining / (taper x slots)): the default of the first half of round 4
+    (taper 1), measured again with the staggered start in place and dropped -- same box, full-size calls to the end against taper 1:
+    178.1 against 172.0 pairs/s over 20 steps, 181.4 / 178.7 over 40, 184.2 / 181.1 over 96, 184.9 / 184.5 over 384
+    (tools/exp/taper.sh).  `head` overrides the stagger (experiments)."""
     if head is None:
         head = [-(-B * (c + 2) // (slots + 1)) for c in range(slots)]
     sizes, k = [], 0
     while k < n:
-        nb = max(1, min(B, int((n - k) / (taper * slots))))
+        nb = min(B, n - k) if taper <= 0 else max(1, min(B, n - k, int((n - k) / (taper * slots))))
         if len(sizes) < len(head):
             nb = max(1, min(nb, head[len(sizes)], n - k))
         sizes.append(nb)
@@ -226,10 +228,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=2, help="extra timed repetitions of the K steps (value_repeats)")
     ap.add_argument("--no-service", action="store_true", help="skip the PCIe-inclusive service-call leg")
     ap.add_argument("--single-pairs", type=int, default=12, help="pairs of the un-instrumented one-slot leg (single_pair_no_events; 0 = skip)")
-    ap.add_argument("--no-events", action="store_true", help="same as --profile-pairs 0 --no-service --repeats 0 --single-pairs 0 (bare throughput line)")
+    ap.add_argument("--steady-steps", type=int, default=-1, help="steps of the further region `steady_state` is taken from when the timed region is too short to "
+                    "have a steady window (-1 = max(steps, 48 x batch, 12 x slots x batch); 0 = no further region: steady_state null)")
+    ap.add_argument("--no-events", action="store_true", help="same as --profile-pairs 0 --no-service --repeats 0 --single-pairs 0 --steady-steps 0 (bare throughput line)")
     args = ap.parse_args()
     if args.no_events:
-        args.profile_pairs, args.no_service, args.repeats, args.single_pairs = 0, True, 0, 0
+        args.profile_pairs, args.no_service, args.repeats, args.single_pairs, args.steady_steps = 0, True, 0, 0, 0
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1 on the way
@@ -295,7 +299,7 @@ def main():
     in_slot = [0] * slots   # pairs of the call each slot holds
     call_sizes = []         # pairs per call of the region being timed, in submission order
     B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
-    TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "1"))   # a call takes at most remaining / (TAPER x slots) pairs
+    TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "0"))   # > 0: a call takes at most remaining / (TAPER x slots) pairs (experiments)
     HEAD = [int(v) for v in os.environ["UGSM_BENCH_HEAD"].split(",") if v] if "UGSM_BENCH_HEAD" in os.environ else None   # (experiments; default: plan_calls' stagger)
 
     def wait_slot(s, stamp):
@@ -327,8 +331,11 @@ def main():
             ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s][0], rank)
 
     def run(n, stamp=False):
-        """n pairs through the slots, call sizes by plan_calls (batches while a backlog exists, staggered at the start, tapered at the end)."""
+        """n pairs through the slots, call sizes by plan_calls (batches while a backlog exists, staggered at the start)."""
         call_sizes[:] = plan_calls(n, slots, B, TAPER, HEAD)
+        if os.environ.get("UGSM_BENCH_PLAN") and n == args.steps:   # (experiments: the timed region's calls given outright)
+            call_sizes[:] = [int(v) for v in os.environ["UGSM_BENCH_PLAN"].split(",")]
+            assert sum(call_sizes) == n and max(call_sizes) <= B
         k = 0
         for call, nb in enumerate(call_sizes):
             submit(k, slot=call % slots, stamp=stamp, n=nb)
@@ -375,8 +382,8 @@ def main():
     # A region too short to have a middle (the driver's --steps 20 with calls of four pairs is all fill and drain) gets its steady-state
     # figure from one more region, long enough to have one, run after the regions `value` and `value_repeats` come from and outside them.
     steady_region, steady_steps = "the timed region of `value`", args.steps
-    if steady_window(plan_calls(args.steps, slots, B, TAPER, HEAD), slots) is None:   # (the same answer on every rank: timed() holds barriers)
-        steady_steps = max(args.steps, 48 * B, 12 * slots * B)
+    if args.steady_steps != 0 and steady_window(plan_calls(args.steps, slots, B, TAPER, HEAD), slots) is None:   # (the same answer on every rank: timed() holds barriers)
+        steady_steps = args.steady_steps if args.steady_steps > 0 else max(args.steps, 48 * B, 12 * slots * B)
         timed(steady_steps)
         steady[0] = steady_state(steady_steps)
         steady_region = (f"a further region of {steady_steps} steps after the timed ones (the timed region of {args.steps} steps has no call with the pipe "
