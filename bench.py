@@ -15,9 +15,10 @@ How the line is put together (rank 0 prints ONE JSON line):
                   barrier + synchronize brackets, NO event recording (bracketing launches with HIP events
                   costs the instrumented stream ~7 %).  value_repeats: the same K steps timed twice more.
   roofline, kernels, event_pass -- a SEPARATE pass after the timed region: `--profile-pairs` CALLS (of `--batch` pairs each, the
-                  timed region's full-size calls) submitted one at a time on slot 0 with every launch bracketed by HIP events on
-                  that stream, so the durations are uncontended (what rocprofv3 --kernel-trace reports for the same kernels, since
-                  the profiler serialises launches).  roofline = the kernel with the largest total time
+                  timed region's full-size calls) submitted one at a time on slot 0; every launch carries two HIP events IN its
+                  dispatch on that stream (hipExtLaunchKernelGGL: the kernel's own begin and end, what rocprofv3 --kernel-trace
+                  reports for the same launches; rounds 1-3 and the first half of round 4 recorded the events AROUND the launch,
+                  which adds the gaps to its neighbours: 6 us per launch), so the durations are uncontended.  roofline = the kernel with the largest total time
                   (the per-iteration cost kernel of the large levels): algorithmic bytes (48 B per
                   pixel-iteration, SURVEY.md 8d) / duration, over all its launches and for level 0 alone;
                   HBM peak 8 TB/s.  kernels[] carries the same for every kernel (K-smooth: 24 B per pixel).
@@ -422,7 +423,7 @@ def main():
 
     # ---- event pass: uncontended kernel durations of the launches the timed region makes (rank 0) -------------------------------
     # One CALL at a time on slot 0 -- a full-size call of B pairs, as the timed region submits them (round 4; rounds 1-3: single pairs) --
-    # with every launch bracketed by HIP events on its stream: the kernels and grids are those of the timed region and of
+    # with two HIP events in every launch's dispatch (its own begin and end): the kernels and grids are those of the timed region and of
     # `rocprofv3 --kernel-trace --stats` of this command, whose average durations these must agree with.
     if rank == 0 and args.profile_pairs > 0 and mode != "fovea-shard":
         ctx.set_profile_events(2)
@@ -462,7 +463,8 @@ def main():
         kernel_ms = sum(e["total_ms"] for e in by_name.values()) / n_pairs
         result["event_pass"] = {"ms_per_pair_wall": 1e3 * t_single, "pairs_per_s": 1.0 / t_single, "kernel_ms_per_pair": kernel_ms,
                                 "pairs": n_pairs, "pairs_per_call": B,
-                                "note": "one call of pairs_per_call pairs in flight, every launch bracketed by HIP events on its stream"}
+                                "note": "one call of pairs_per_call pairs in flight; every launch carries two HIP events in its dispatch on its stream (hipExtLaunchKernelGGL: "
+                                        "the kernel's own begin and end timestamps)"}
         # the dominant kernel: the cost kernel that carries most of the pair's pixel-iterations (the marching kernel of the large
         # levels; the LDS-tiled one only serves the latency-bound small levels)
         dom = max((k for k in kernels if k["name"].startswith("k_cost")), key=lambda k: by_name[k["name"]]["pixel_launches"], default=None)

@@ -60,7 +60,7 @@ typedef struct ugsm_config {
     int fovea_levels;
     int slots;
     int kernel_path;
-    int profile_events; /* slot 0 brackets kernels with HIP events: 1 = the cost kernel only, 2 = every kernel class */
+    int profile_events; /* slot 0 times its launches with HIP events carried in the dispatch (the kernel's own begin and end): 1 = the cost kernel only, 2 = every kernel class */
     int march_min_pixels; /* levels of at least this many pixels run K-cost as the marching kernel (one wave per strip of
                              columns, no LDS); 0 = default threshold, < 0 = never (the LDS-tiled kernel everywhere) */
     int march_np;         /* ignored since ABI 3 (kept for layout): the two-pixels-per-lane development form of the marching kernel

@@ -122,7 +122,8 @@ json.dump({"_tag": tag, "full16mp": traffic, "clock_GHz_level0": clock, "valu_in
                     "SQ_INSTS_VALU of the largest grid of each kernel (the level-0 launch), mean per dispatch"},
           open(f"{out}/pmc_traffic.json", "w"), indent=1)
 an = os.path.join(out, "analyze_trace.py")
-subprocess.check_call([sys.executable, an, base + "/trace", "--out", f"{out}/{tag}_trace_summary.md"], stdout=subprocess.DEVNULL)
+bl = ["--bench-line", base + "/bench_under_rocprof.json"] if os.path.exists(base + "/bench_under_rocprof.json") else []
+subprocess.check_call([sys.executable, an, base + "/trace", "--out", f"{out}/{tag}_trace_summary.md"] + bl, stdout=subprocess.DEVNULL)
 with open(f"{out}/{tag}_pmc_summary.md", "w") as fo:
     fo.write(f"# {tag}: SQ counters (separate PMC passes, single slot, 5 pairs; mean per dispatch)\n")
     for d in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):

@@ -22,8 +22,9 @@ python bench.py --workload 1080p --no-cpu-baseline --no-service > $O/bench_1080p
 python bench.py --workload fovea16mp --no-cpu-baseline --no-service > $O/bench_fovea16mp.json 2>> $O/bench_default.err; step "bench fovea16mp: $(cut -c1-120 $O/bench_fovea16mp.json)"
 cd /tmp && export TMPDIR=/tmp
 # the SAME command as the default bench line (minus the CPU and service legs, which launch no kernels of ours; 96 steps instead of
-# 384: the kernel trace of the longer region does not fit gpurun's 64 MiB of returned files)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-service > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
+# 384: the kernel trace of the longer region does not fit gpurun's 64 MiB of returned files; without the one-slot leg, whose latency-policy
+# launches -- k_cost_march at levels 0-2 only -- are not the timed region's and would weigh on the kernel's mean)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-service --single-pairs 0 > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
 # (UGSM_POLICY: a one-slot context would otherwise make the latency choices, not the ones of the 4-slot bench line)
 # The HBM-traffic passes run the timed region's launches (batches of four: `roofline.traffic` is per launch, like `roofline.achieved`); the
 # SQ passes run single-pair launches (PMC_BATCH=1), whose grids identify the level (`valu_insts_level0`: the largest grid).

@@ -1171,8 +1171,8 @@ void launch_smooth_pipe(hipStream_t st, const float *s3, float *o3, int W, int H
     }
     const int tiles_x = (W + 111) / 112, n_tiles = tiles_x * ((H + sty - 1) / sty);
     const int wgs = std::min(n_tiles, smooth_pipe_workgroups);
-    if (sty == STY) hipLaunchKernelGGL((k_smooth_pipe<STY, true>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
-    else hipLaunchKernelGGL((k_smooth_pipe<STY, false>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
+    if (sty == STY) UGSM_LAUNCH((k_smooth_pipe<STY, true>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
+    else UGSM_LAUNCH((k_smooth_pipe<STY, false>), dim3(wgs, pairs), dim3(1024), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, queue, B);
 }
 #endif  // UGSM_DEV_LIB
 
@@ -1276,7 +1276,7 @@ void launch_triangulate(hipStream_t st, const float *dispx, const float *dispy, 
 {
     Proj a, b;
     for (int k = 0; k < 12; k++) { a.m[k] = P1[k]; b.m[k] = P2[k]; }
-    hipLaunchKernelGGL(k_triangulate, dim3((W + 255) / 256, H), dim3(256), 0, st, dispx, dispy, W, H, a, b, xyz);
+    UGSM_LAUNCH(k_triangulate, dim3((W + 255) / 256, H), dim3(256), 0, st, dispx, dispy, W, H, a, b, xyz);
 }
 
 void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *stacky, int fovW, int fovH, int src_level, int left_margin,
@@ -1284,7 +1284,7 @@ void launch_triangulate_fovea(hipStream_t st, const float *stackx, const float *
 {
     Proj a, b;
     for (int k = 0; k < 12; k++) { a.m[k] = P1[k]; b.m[k] = P2[k]; }
-    hipLaunchKernelGGL(k_triangulate_fovea, dim3((fovW + 255) / 256, fovH), dim3(256), 0, st, stackx, stacky, fovW, fovH, src_level, left_margin,
+    UGSM_LAUNCH(k_triangulate_fovea, dim3((fovW + 255) / 256, fovH), dim3(256), 0, st, stackx, stacky, fovW, fovH, src_level, left_margin,
                        upper_margin, scale, a, b, xyz);
 }
 
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_upsample_paste(const float *__restrict_
 void launch_upsample_paste(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, const float *fovH_, const float *fovV_,
                            const float *fovC_, int fovW, int fovH, int org_x, int org_y)
 {
-    hipLaunchKernelGGL(k_upsample_paste, dim3((W2 + 255) / 256, H2), dim3(256), 0, st, src3, W, H, dst3, W2, H2, fovH_, fovV_, fovC_, fovW, fovH,
+    UGSM_LAUNCH(k_upsample_paste, dim3((W2 + 255) / 256, H2), dim3(256), 0, st, src3, W, H, dst3, W2, H2, fovH_, fovV_, fovC_, fovW, fovH,
                        org_x, org_y);
 }
 
@@ -1338,7 +1338,7 @@ __global__ void k_poly_probe(const float *__restrict__ c, const float *__restric
 }
 void launch_poly_probe(hipStream_t st, const float *c, const float *l, const float *r, const float *thr, float *delta, float *corr, float *third, int n)
 {
-    hipLaunchKernelGGL(k_poly_probe, dim3((n + 255) / 256), dim3(256), 0, st, c, l, r, thr, delta, corr, third, n);
+    UGSM_LAUNCH(k_poly_probe, dim3((n + 255) / 256), dim3(256), 0, st, c, l, r, thr, delta, corr, third, n);
 }
 
 // test hook (tests only): the shared-reciprocal division exactly as k_smooth_fused applies it (fast form,
@@ -1362,7 +1362,7 @@ __global__ void k_div3_probe(const float *__restrict__ a0, const float *__restri
 }
 void launch_div3_probe(hipStream_t st, const float *a0, const float *a1, const float *a2, const float *s, float *q0, float *q1, float *q2, int n)
 {
-    hipLaunchKernelGGL(k_div3_probe, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, a2, s, q0, q1, q2, n);
+    UGSM_LAUNCH(k_div3_probe, dim3((n + 255) / 256), dim3(256), 0, st, a0, a1, a2, s, q0, q1, q2, n);
 }
 #endif  // UGSM_DEV_LIB
 
@@ -1373,7 +1373,7 @@ void launch_cost_fused(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
     const int tiles_x = (W + TX - 1) / TX, n_tiles = tiles_x * ((H + TY - 1) / TY);
     // two threads per quad (k_cost_split): same speed as k_cost_fused on the big levels, 15-25 % shorter launches
     // on the latency-bound coarse ones (12.0 vs 16.3 us at 53x34, 18.7 vs 22.0 us at 615x407)
-    hipLaunchKernelGGL(k_cost_split<0>, dim3(n_tiles), dim3(512), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles);
+    UGSM_LAUNCH(k_cost_split<0>, dim3(n_tiles), dim3(512), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles);
 }
 
 #ifndef UGSM_SMOOTH_MID_NT
@@ -1405,8 +1405,8 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     if (sty < 1 || sty > STY) sty = STY;
     const size_t bytes = 3 * (size_t)(sty + 14) * LW * sizeof(float);
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + sty - 1) / sty);
-    if (sty == STY) hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, true>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
-    else hipLaunchKernelGGL((k_smooth_fused<STX, STY, NT, 0, false>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
+    if (sty == STY) UGSM_LAUNCH((k_smooth_fused<STX, STY, NT, 0, true>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
+    else UGSM_LAUNCH((k_smooth_fused<STX, STY, NT, 0, false>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
 }
 
 // Tile height of the 112-column K-smooth tile for a W x H level.  The kernel's tile may be any height up to kSmoothTileRowsMax (36); two
@@ -1968,12 +1968,12 @@ void launch_pyr_base(hipStream_t st, const uint8_t *rgb, int stride, int W, int 
     if ((pyr_base_streaming == 1 && win.w > 0) || pyr_base_streaming == 2) {
         constexpr int HS = 32;
         const int strips_x = (W + 59) / 60, n_strips = strips_x * ((H + HS - 1) / HS);
-        hipLaunchKernelGGL(k_pyr_base_march<HS>, dim3((n_strips + 3) / 4, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
+        UGSM_LAUNCH(k_pyr_base_march<HS>, dim3((n_strips + 3) / 4, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2,
                            H2, range_bad, strips_x, n_strips, B, win);
         return;
     }
     const int tiles_x = (W + BTX - 1) / BTX, n_tiles = tiles_x * ((H + BTY - 1) / BTY);
-    hipLaunchKernelGGL(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B, win);
+    UGSM_LAUNCH(k_pyr_base<0>, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, rgb, stride, W, H, lvl0, lvl1, W1, H1, lvl2, W2, H2, range_bad, tiles_x, n_tiles, B, win);
 }
 
 int blur_decimate_streaming = 1;  // (development: UGSM_PYR_STREAM=0 -> the tiled kernel for the factor-2 levels too)
@@ -2002,13 +2002,13 @@ void launch_blur_decimate(hipStream_t st, const float *src3, int W, int H, float
         const int hs = out_px >= 400000 ? 16 : (out_px >= 40000 ? 8 : 4);  // short strips where there are few: a launch lasts as long as one wave
         const int strips_x = (W2 + 29) / 30, n_strips = strips_x * ((H2 + hs - 1) / hs);
         const dim3 grid((3 * n_strips + 3) / 4, images);
-        if (hs == 16) hipLaunchKernelGGL(k_blur_decimate2<16>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
-        else if (hs == 8) hipLaunchKernelGGL(k_blur_decimate2<8>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
-        else hipLaunchKernelGGL(k_blur_decimate2<4>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        if (hs == 16) UGSM_LAUNCH(k_blur_decimate2<16>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        else if (hs == 8) UGSM_LAUNCH(k_blur_decimate2<8>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
+        else UGSM_LAUNCH(k_blur_decimate2<4>, grid, dim3(256), 0, st, src3, W, H, dst3, W2, H2, range_bad, strips_x, n_strips, B);
         return;
     }
     const int tiles_x = (W2 + PTX - 1) / PTX, n_tiles = tiles_x * ((H2 + PTY - 1) / PTY);
-    hipLaunchKernelGGL(k_blur_decimate_tiled, dim3(n_tiles, images, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles, B);
+    UGSM_LAUNCH(k_blur_decimate_tiled, dim3(n_tiles, images, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf, range_bad, tiles_x, n_tiles, B);
 }
 
 void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3, const Batch *bt)
@@ -2017,7 +2017,7 @@ void launch_sqblur_clamp(hipStream_t st, Img3 src, int W, int H, float *dst3, co
     one.n = 1;
     const Batch &B = bt ? *bt : one;
     const int tiles_x = (W + PTX - 1) / PTX, n_tiles = tiles_x * ((H + PTY - 1) / PTY);
-    hipLaunchKernelGGL(k_sqblur_tiled, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, src, W, H, dst3, tiles_x, n_tiles, B);
+    UGSM_LAUNCH(k_sqblur_tiled, dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(256), 0, st, src, W, H, dst3, tiles_x, n_tiles, B);
 }
 
 }  // namespace ugsm

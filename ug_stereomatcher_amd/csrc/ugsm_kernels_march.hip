@@ -604,12 +604,12 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     }
 #ifdef UGSM_DEV_KERNELS
     if (fmad) {
-        hipLaunchKernelGGL((k_cost_march<NP, true>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
+        UGSM_LAUNCH((k_cost_march<NP, true>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
         return;
     }
 #endif
     (void)fmad;
-    hipLaunchKernelGGL((k_cost_march<NP, false>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
+    UGSM_LAUNCH((k_cost_march<NP, false>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
 }
 
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
@@ -937,7 +937,7 @@ static void launch_smooth_march_t(hipStream_t st, const float *s3, float *o3, in
     }
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-    hipLaunchKernelGGL((k_smooth_march<NP, PASSES, BOX>), dim3((n_strips + MARCH_WPB - 1) / MARCH_WPB), dim3(64 * MARCH_WPB), 0, st, s3, o3, W, H,
+    UGSM_LAUNCH((k_smooth_march<NP, PASSES, BOX>), dim3((n_strips + MARCH_WPB - 1) / MARCH_WPB), dim3(64 * MARCH_WPB), 0, st, s3, o3, W, H,
                        strips_x, n_strips, Hs);
 }
 
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256) void k_range_scan(const float *__restrict__ p,
 void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad)
 {
     const size_t blocks = (count + 255) / 256;
-    hipLaunchKernelGGL(k_range_scan, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, p, count, range_bad);
+    UGSM_LAUNCH(k_range_scan, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, p, count, range_bad);
 }
 
 // =========================================================================================
@@ -1029,8 +1029,8 @@ __global__ __launch_bounds__(64) void k_wdiff_total(const double *__restrict__ r
 // out3 (device): S_dx, S_dy, C; rowsum: 3 * H doubles of scratch
 void launch_weighted_difference(hipStream_t st, const float *newd3, const float *oldd3, int W, int H, double *rowsum, double *out3)
 {
-    hipLaunchKernelGGL(k_wdiff_rows, dim3(H), dim3(64), 0, st, newd3, oldd3, W, H, rowsum);
-    hipLaunchKernelGGL(k_wdiff_total, dim3(1), dim3(64), 0, st, rowsum, H, out3);
+    UGSM_LAUNCH(k_wdiff_rows, dim3(H), dim3(64), 0, st, newd3, oldd3, W, H, rowsum);
+    UGSM_LAUNCH(k_wdiff_total, dim3(1), dim3(64), 0, st, rowsum, H, out3);
 }
 
 #ifdef UGSM_DEV_LIB
@@ -1042,7 +1042,7 @@ __global__ void k_div_probe(const float *__restrict__ n, const float *__restrict
 }
 void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, int count)
 {
-    hipLaunchKernelGGL(k_div_probe, dim3((count + 255) / 256), dim3(256), 0, st, n, d, q, count);
+    UGSM_LAUNCH(k_div_probe, dim3((count + 255) / 256), dim3(256), 0, st, n, d, q, count);
 }
 #endif  // UGSM_DEV_LIB
 

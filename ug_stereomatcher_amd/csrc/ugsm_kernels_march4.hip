@@ -349,11 +349,11 @@ void launch_cost_march4(hipStream_t st, Img3 L, Img3 R, const float *A3, const f
     const int n_strips = strips_x * strips_y;
 #ifdef UGSM_DEV_KERNELS
     if (march4_small_registers) {
-        hipLaunchKernelGGL(k_cost_march4<8>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
+        UGSM_LAUNCH(k_cost_march4<8>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
         return;
     }
 #endif
-    hipLaunchKernelGGL(k_cost_march4<4>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
+    UGSM_LAUNCH(k_cost_march4<4>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
 }
 
 }  // namespace ugsm

@@ -64,14 +64,14 @@ void launch_seed(hipStream_t st, const float *src3, int Ws, int Hs, float *dst3,
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
-    hipLaunchKernelGGL(k_seed, grid2(Wd, Hd, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src3, Ws, Hs, dst3, Wd, Hd, cx, cy, B);
+    UGSM_LAUNCH(k_seed, grid2(Wd, Hd, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src3, Ws, Hs, dst3, Wd, Hd, cx, cy, B);
 }
 void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch, const Batch *bt)
 {
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
-    hipLaunchKernelGGL(k_copy_view, grid2(W, H, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src, W, H, dst, dst_plane, dst_pitch, B);
+    UGSM_LAUNCH(k_copy_view, grid2(W, H, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src, W, H, dst, dst_plane, dst_pitch, B);
 }
 // --------------------------------------------------------------------------------------
 // LR-consistency check (BASELINE.json north_star; the reference has none: SURVEY.md 0.4 -- the build's own definition, DESIGN.md
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_lr_check(float *__restrict__ left3, con
 }
 void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, int H, float tau, unsigned long long *marked)
 {
-    hipLaunchKernelGGL(k_lr_check, grid2(W, H), dim3(256), 0, st, left3, right3, W, H, tau, marked);
+    UGSM_LAUNCH(k_lr_check, grid2(W, H), dim3(256), 0, st, left3, right3, W, H, tau, marked);
 }
 
 // --------------------------------------------------------------------------------------
@@ -119,7 +119,7 @@ __global__ void k_rgb_planes(const uint8_t *__restrict__ rgb, int stride, int W,
 
 void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes)
 {
-    hipLaunchKernelGGL(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
+    UGSM_LAUNCH(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
 }
 
 #ifdef UGSM_DEV_LIB  // kernel_path 1, one kernel per reference stage: the A/B reference of the fused kernels -- in libugsm_dev.so only
@@ -321,28 +321,28 @@ __global__ void k_box(const float *__restrict__ s3, float *__restrict__ o3, int 
 
 void launch_blur_decimate_ref(hipStream_t st, const float *src3, int W, int H, float *dst3, int W2, int H2, float sf)
 {
-    hipLaunchKernelGGL(k_blur_decimate, grid2(W2, H2, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);
+    UGSM_LAUNCH(k_blur_decimate, grid2(W2, H2, 3), dim3(256), 0, st, src3, W, H, dst3, W2, H2, sf);
 }
 void launch_sqblur_clamp_ref(hipStream_t st, Img3 src, int W, int H, float *dst3)
 {
-    hipLaunchKernelGGL(k_sqblur_clamp, grid2(W, H, 3), dim3(256), 0, st, src, W, H, dst3);
+    UGSM_LAUNCH(k_sqblur_clamp, grid2(W, H, 3), dim3(256), 0, st, src, W, H, dst3);
 }
 void launch_warp_ref(hipStream_t st, Img3 R, const float *d3, int W, int H, float *Rw3)
 {
-    hipLaunchKernelGGL(k_warp, grid2(W, H), dim3(256), 0, st, R, d3, W, H, Rw3);
+    UGSM_LAUNCH(k_warp, grid2(W, H), dim3(256), 0, st, R, d3, W, H, Rw3);
 }
 void launch_cost_ref(hipStream_t st, Img3 L, const float *Rw3, const float *A3, const float *B3, const float *d3, float *nd3,
                      int W, int H, float thr, int blend, float *dbg8)
 {
-    hipLaunchKernelGGL(k_cost_ref, grid2(W, H), dim3(256), 0, st, L, Rw3, A3, B3, d3, nd3, W, H, thr, blend, dbg8);
+    UGSM_LAUNCH(k_cost_ref, grid2(W, H), dim3(256), 0, st, L, Rw3, A3, B3, d3, nd3, W, H, thr, blend, dbg8);
 }
 void launch_smooth_pass_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
 {
-    hipLaunchKernelGGL(k_smooth_pass, grid2(W, H), dim3(256), 0, st, s3, o3, W, H);
+    UGSM_LAUNCH(k_smooth_pass, grid2(W, H), dim3(256), 0, st, s3, o3, W, H);
 }
 void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
 {
-    hipLaunchKernelGGL(k_box, grid2(W, H, 3), dim3(256), 0, st, s3, o3, W, H);
+    UGSM_LAUNCH(k_box, grid2(W, H, 3), dim3(256), 0, st, s3, o3, W, H);
 }
 #endif  // UGSM_DEV_LIB
 

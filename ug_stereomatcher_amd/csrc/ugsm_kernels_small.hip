@@ -363,7 +363,7 @@ static void launch_cost_small_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     const int tiles_x = (W + TXS - 1) / TXS, n_tiles = tiles_x * ((H + TYS - 1) / TYS);
     constexpr size_t bytes = 3 * (size_t)G::CH_FLOATS * sizeof(float);
     static_assert(bytes <= 64 * 1024, "stays under the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_cost_small<TXS, TYS>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(G::NT), bytes, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles, B);
+    UGSM_LAUNCH((k_cost_small<TXS, TYS>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(G::NT), bytes, st, L, R, A3, d3, nd3, W, H, thr, blend, tiles_x, n_tiles, B);
 }
 
 void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, const Batch *bt)
@@ -556,7 +556,7 @@ void launch_iter_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
     const int tiles_x = (W + TXS - 1) / TXS, n_tiles = tiles_x * ((H + TYS - 1) / TYS);
     constexpr size_t bytes = (size_t)I::LDS_FLOATS * sizeof(float);
     static_assert(bytes <= 64 * 1024, "stays under the default dynamic LDS limit");
-    hipLaunchKernelGGL((k_iter_small<TXS, TYS>), dim3(n_tiles), dim3(I::NT), bytes, st, L, R, A3, c3, nd3, W, H, thr, blend, passes, tiles_x, n_tiles);
+    UGSM_LAUNCH((k_iter_small<TXS, TYS>), dim3(n_tiles), dim3(I::NT), bytes, st, L, R, A3, c3, nd3, W, H, thr, blend, passes, tiles_x, n_tiles);
 }
 
 #endif  // UGSM_DEV_LIB
@@ -700,7 +700,7 @@ static void launch_smooth_small_t(hipStream_t st, const float *s3, float *o3, in
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
-    hipLaunchKernelGGL((k_smooth_small<RH>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(32 * RH), 0, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, B);
+    UGSM_LAUNCH((k_smooth_small<RH>), dim3(n_tiles, B.n > 1 ? B.n : 1), dim3(32 * RH), 0, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, B);
 }
 
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh, const Batch *bt)

@@ -2,10 +2,28 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
 namespace ugsm {
+
+// Per-launch timing (ugsm_config.profile_events): when the submitting thread has a probe set, the next launch carries the probe's two
+// events IN its dispatch (hipExtLaunchKernelGGL: the kernel's own begin and end timestamps, what rocprofv3's kernel trace reports), not
+// two hipEventRecord markers around it, whose interval also holds the gaps to the neighbouring launches (6 us per launch on this stack:
+// 8 % of the dominant kernel's mean duration; profiles/r04_trace_summary.md).  Only the first launch of a bracket is timed (every
+// bracket of the runtime holds one); n counts them.
+struct LaunchProbe {
+    hipEvent_t a, b;
+    int n;
+};
+inline thread_local LaunchProbe *g_probe = nullptr;
+#define UGSM_LAUNCH(kern, grid, block, shmem, st, ...)                                                                \
+    do {                                                                                                              \
+        ::ugsm::LaunchProbe *probe_ = ::ugsm::g_probe;                                                                \
+        if (probe_ && probe_->n++ == 0) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, probe_->a, probe_->b, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                           \
+    } while (0)
 
 // A 3-plane float image view: plane k starts at p + k*plane, rows are `pitch` floats
 // apart.  Pyramid levels are dense (pitch == width); fovea crops of the pyramid

@@ -379,6 +379,7 @@ struct Timer {
     Slot *s;
     bool on;
     EvRec rec;
+    LaunchProbe probe;
     Timer(ugsm_ctx *c, Slot *sl, int slot_idx, int kclass, double pixels) : ctx(c), s(sl)
     {
         // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
@@ -398,12 +399,18 @@ struct Timer {
                 return;
             }
         }
-        (void)hipEventRecord(rec.a, s->st);
+        probe = LaunchProbe{rec.a, rec.b, 0};  // the bracket's launch carries the two events in its dispatch (ugsm_launch.hpp)
+        g_probe = &probe;
     }
     ~Timer()
     {
         if (!on) return;
-        (void)hipEventRecord(rec.b, s->st);
+        g_probe = nullptr;
+        if (probe.n == 0) {  // (nothing was launched inside the bracket)
+            s->pool.push_back(rec.a);
+            s->pool.push_back(rec.b);
+            return;
+        }
         s->pending.push_back(rec);
     }
 };
@@ -576,8 +583,10 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
                         nb > 1 ? &bt0 : nullptr, pw);
     } else {
         // (pyramids of fewer than three levels, and kernel_path 1: image by image)
-        Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H * nb);
-        for (int b = 0; b < nb; b++) launch_rgb_planes(pst, rgb[b], stride, s.W, s.H, pyr + b * s.pyr_stride + s.off[0]);
+        for (int b = 0; b < nb; b++) {
+            Timer t(ctx, &s, si, KC_MISC, (double)s.W * s.H);
+            launch_rgb_planes(pst, rgb[b], stride, s.W, s.H, pyr + b * s.pyr_stride + s.off[0]);
+        }
     }
     // CreatePyramidFromImage, MatchGPULib.cpp:1063-1106: level 1 from level 0 (sf=(float)SCALE),
     // level i+2 from level i (sf=2.0f).  Levels are produced in dependency order.
