@@ -221,8 +221,9 @@ def main():
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams the slots are dealt onto (ugsm_config.streams; 0 = one per slot)")
     ap.add_argument("--batch", type=int, default=0, help="pairs per call at most (ugsm_submit_*_batch: the pairs of a call march through the levels in lockstep, "
-                    "one launch per level of <= 9 Mpx for all of them); 1 = the single-pair calls of rounds 1-3; 0 = by the workload: 4 for 16 MP "
-                    "full mode, 8 for the foveated stack, 16 for 1080p (tools/ab.py, profiles/r04_ab_batch.txt)")
+                    "one launch per level of <= 9 Mpx for all of them); 1 = the single-pair calls of rounds 1-3; 0 = by the workload: 8 for 16 MP "
+                    "full mode and for the foveated stack, 16 for 1080p (tools/ab.py, profiles/r04_ab_batch.txt; 16 MP full mode: 4 in the "
+                    "round's first half -- 8 is +0.5 %% over 384 steps, +1.3 %% over 20, profiles/r04_ab_plan.txt)")
     ap.add_argument("--kernel-path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-pairs", type=int, default=3, help="calls (of --batch pairs each) of the event pass after the timed region (0 = skip)")
@@ -265,7 +266,7 @@ def main():
     wl = WORKLOADS[args.workload]
     W, H, mode = wl["W"], wl["H"], wl["mode"]
     if args.batch <= 0:
-        args.batch = {"full16mp": 4, "fovea16mp": 8, "1080p": 16}.get(args.workload, 1)
+        args.batch = {"full16mp": 8, "fovea16mp": 8, "1080p": 16}.get(args.workload, 1)
     slots = max(1, args.slots)
     F = 7
     ctx = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, profile_events=0, streams=args.streams,

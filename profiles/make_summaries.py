@@ -36,8 +36,8 @@ def load(d):
 from ug_stereomatcher_amd import _lib  # noqa: E402
 pi = _lib.pixel_iterations(4928, 3264, 14, 0)
 rd, wr, fe = load("pmc_rdreq"), load("pmc_write"), load("pmc_fetch")
-lines = [f"# {tag}: HBM traffic per kernel (PMC, separate passes; `bench.py --steps 4 --warmup 1 --slots 1 --batch 4`: the launches of the timed "
-         "region -- levels 1-13 carry four pairs per launch, level 0 one)\n",
+lines = [f"# {tag}: HBM traffic per kernel (PMC, separate passes; `bench.py --steps 8 --warmup 0 --slots 1 --batch 8`: the launches of the timed "
+         "region -- levels 1-13 carry eight pairs per launch, level 0 one)\n",
          "Read bytes = 32*RDREQ_32B + 64*(RDREQ - RDREQ_32B - RDREQ_128B) + 128*RDREQ_128B (TCC_EA0_*_sum).  FETCH_SIZE is shown "
          "beside it doubled: on gfx950 it tallies 128-B requests at 64 B, i.e. exactly half (MI355X_MICROARCH.md, HBM section) -- the two "
          "agree.  Write bytes = WRITE_SIZE x 1024.  Algorithmic = 48 B x pixels of the launch (SURVEY.md 8d).\n",

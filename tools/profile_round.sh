@@ -26,9 +26,9 @@ cd /tmp && export TMPDIR=/tmp
 # launches -- k_cost_march at levels 0-2 only -- are not the timed region's and would weigh on the kernel's mean)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/trace -o runc --output-format csv -- python3 $R/bench.py --steps 96 --warmup 8 --no-cpu-baseline --no-service --single-pairs 0 > $O/bench_under_rocprof.json 2> $O/trace.err; step "kernel trace"
 # (UGSM_POLICY: a one-slot context would otherwise make the latency choices, not the ones of the 4-slot bench line)
-# The HBM-traffic passes run the timed region's launches (batches of four: `roofline.traffic` is per launch, like `roofline.achieved`); the
+# The HBM-traffic passes run the timed region's launches (full-size calls of eight pairs, nothing else: `roofline.traffic` is per launch, like `roofline.achieved`); the
 # SQ passes run single-pair launches (PMC_BATCH=1), whose grids identify the level (`valu_insts_level0`: the largest grid).
-pmc() { name=$1; shift; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --slots 1 --batch ${PMC_BATCH:-4} --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
+pmc() { name=$1; shift; b=${PMC_BATCH:-8}; UGSM_POLICY=throughput timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" -d $O/$name -o runc --output-format csv -- python3 $R/bench.py --steps $((b > 4 ? b : 4)) --warmup $((b > 1 ? 0 : 1)) --slots 1 --batch $b --no-cpu-baseline --no-events > $O/$name.json 2> $O/$name.err; step "pmc $name"; }
 pmc pmc_rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_128B_sum
 pmc pmc_write WRITE_SIZE
 pmc pmc_fetch FETCH_SIZE
