@@ -215,7 +215,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=384, help="pairs of the timed region (a short region under-reports: filling and draining the four slots costs about "
-                    "one pair's in-flight time, 24 ms at 16 MP -- 4 %% of 96 steps, 1 %% of 384; 4000 steps: 171 pairs/s where 96 give 167)")
+                    "one call's in-flight time whatever its length -- 3 %% of the driver's 20 steps, under 1 %% of 384; `steady_state` is the "
+                    "figure without it)")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="full16mp", choices=sorted(WORKLOADS))
     ap.add_argument("--slots", type=int, default=4, help="pairs in flight per GPU")
