@@ -5,15 +5,16 @@
 
 One "step" = one synthetic 16 MP (4928x3264) stereo pair through the full-resolution 14-level
 pyramid path (BASELINE.json configs[2], the configuration `metric` is quoted on), inputs already
-resident in HBM, `--slots` pairs in flight on separate HIP streams.  For N > 1 the driver launches
+resident in HBM, `--slots` calls of up to `--batch` pairs each in flight on separate HIP streams.  For N > 1 the driver launches
 one rank per GPU (torch.distributed.run); run without a launcher, `--gpus N` starts the ranks itself.
 Pairs are independent, so ranks share nothing on the data path ("weak" scaling, no collective); the
 barrier and the max-over-ranks reduction go over RCCL.
 
 How the line is put together (rank 0 prints ONE JSON line):
   value, ms_per_step  -- the timed region: W warm-up steps, then exactly K steps between two
-                  barrier + synchronize brackets, NO event recording (bracketing launches with HIP events
-                  costs the instrumented stream ~7 %).  value_repeats: the same K steps timed twice more.
+                  barrier + synchronize brackets, NO event recording.  value_repeats: the same K steps timed twice more.
+  steady_state -- the rate between the completions of the first and the last call that have the pipe full of full-size calls
+                  behind them, inside the same regions (a region too short to have such calls: from one further region).
   roofline, kernels, event_pass -- a SEPARATE pass after the timed region: `--profile-pairs` CALLS (of `--batch` pairs each, the
                   timed region's full-size calls) submitted one at a time on slot 0; every launch carries two HIP events IN its
                   dispatch on that stream (hipExtLaunchKernelGGL: the kernel's own begin and end, what rocprofv3 --kernel-trace
@@ -24,7 +25,7 @@ How the line is put together (rank 0 prints ONE JSON line):
                   HBM peak 8 TB/s.  kernels[] carries the same for every kernel (K-smooth: 24 B per pixel).
   valu_roofline -- both hot kernels are bound by VALU issue, not bytes: the modelled VALU time of
                   the level-0 launch (instruction counts of the kernel x per-instruction issue cost measured in
-                  actual cycles, profiles/r02_valu_model.json) against its measured duration.
+                  actual cycles, profiles/<PROFILE_TAG>_valu_model.json) against its measured duration.
   pcie_inclusive -- the drop-in service call (ugsm_match_full: host buffers in and out), pageable and
                   page-locked; never `value`.  device_copy_GBps: a 1 GiB device-to-device copy.
   cpu_baseline -- the CPU oracle (a port: the reference has no CPU matcher) timed on this host, rank 0 /
