@@ -261,3 +261,44 @@ def test_several_slots_queued_on_one_stream(lib, orc, slots, streams):
         assert_bit_equal(c.to_host(outs[0], (3, H, W)), refs[1], "full behind foveated")
         with pytest.raises(lib.UgsmError):
             lib.Context(levels=lv, slots=2, streams=-1)
+
+
+def test_kernel_stats_are_the_kernels_own_durations(lib):
+    """profile_events: the two HIP events of a launch ride in its dispatch (hipExtLaunchKernelGGL, UGSM_LAUNCH), so a launch's entry in
+    ugsm_get_kernel_stats is the kernel's own begin-to-end time -- the sum over a call's launches is what the call's stream was busy, just
+    under the call's un-instrumented wall time -- and not the interval between two markers around the launch, which also holds the gaps to
+    the neighbouring launches (round 3 and before: the sum exceeded the wall time by the 750 launches' gaps)."""
+    import time
+    from ug_stereomatcher_amd import synth
+    W, H = 2464, 1632
+    L, R, _, _ = synth.make_pair(W, H, 77)
+    with lib.Context(levels=14, profile_events=0) as c:
+        dL, dR, dO = c.to_device(L), c.to_device(R), c.alloc(3 * W * H * 4)
+
+        def call():
+            c.check(c.lib.ugsm_submit_full(c.handle, 0, dL, dR, W, H, 3 * W, dO))
+            c.check(c.lib.ugsm_wait(c.handle, 0))
+        for _ in range(3):
+            call()
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            call()
+            walls.append((time.perf_counter() - t0) * 1e3)
+        wall = sorted(walls)[len(walls) // 2]
+        c.reset_kernel_stats()
+        c.set_profile_events(2)
+        n = 4
+        for _ in range(n):
+            call()
+        st = c.kernel_stats()
+        c.set_profile_events(0)
+        kernel_ms = sum(s["total_ms"] for s in st) / n
+        launches = sum(s["launches"] for s in st) // n
+        for p in (dL, dR, dO):
+            c.free(p)
+    assert launches > 400                      # every kernel class of the 14 levels
+    assert all(s["total_ms"] > 0 for s in st)  # no launch without its two timestamps
+    # (measured: 4.43 ms of 4.95 ms; with markers around its 488 launches the sum read 3-6 us more per launch, i.e. above the wall time)
+    assert 0.60 * wall < kernel_ms < 1.10 * wall, (kernel_ms, wall, launches)
+    print(f"kernel time {kernel_ms:.3f} ms of {wall:.3f} ms wall per call, {launches} launches")
