@@ -25,7 +25,14 @@
 extern "C" {
 #endif
 
-#define UGSM_ABI_VERSION 4  /* 4: ugsm_config grew (batch, stream_priority), ugsm_submit_full_batch, ugsm_submit_foveated_batch; kernel_path 1,
+/* libugsm.so is built with -fvisibility=hidden: what this header declares is everything the library exports (nm -D lists ugsm_* only). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+#define UGSM_ABI_VERSION 5  /* 5: the queue (ugsm_enqueue_*, ugsm_flush, ugsm_next_done, ugsm_queue_depth, ugsm_queue_plan, ugsm_poll; UGSM_PENDING / UGSM_EMPTY),
+                               RCCL inside the library (ugsm_shard_*), hidden visibility for everything else
+                               4: ugsm_config grew (batch, stream_priority), ugsm_submit_full_batch, ugsm_submit_foveated_batch; kernel_path 1,
                                march_smooth and the probe entry points moved to libugsm_dev.so (include/ugsm_dev.h)
                                3: ugsm_config grew (lr_check_threshold, streams), ugsm_stage_lr_check, ugsm_slot_stream, ugsm_last_lr_marked,
                                ugsm_submit_full_host, ugsm_submit_foveated_host, ugsm_plan_level_in_frame */
@@ -39,6 +46,8 @@ extern "C" {
 #define UGSM_ERR_DEVICE        5  /* a HIP call failed; see ugsm_last_error */
 #define UGSM_ERR_NOMEM         6
 #define UGSM_ERR_STATE         7  /* e.g. fine phase without coarse phase */
+#define UGSM_PENDING           8  /* not an error: ugsm_poll / ugsm_next_done(block = 0) -- the work asked about has not finished yet */
+#define UGSM_EMPTY             9  /* not an error: ugsm_next_done -- every pair enqueued so far has been reported */
 
 #define UGSM_MAX_LEVELS 32
 #define UGSM_MAX_BATCH 16  /* pairs per ugsm_submit_*_batch call */
@@ -220,6 +229,84 @@ int ugsm_wait_all(ugsm_ctx *ctx);
  * RCCL collective of the fovea shard -- order them after the slot's work ON THE DEVICE (record an event on this stream, make the
  * other stream wait for it) instead of blocking in ugsm_wait.  The stream stays owned by the context. */
 int ugsm_slot_stream(ugsm_ctx *ctx, int slot, void **hip_stream);
+/* Non-blocking ugsm_wait: UGSM_OK when everything enqueued on `slot` has finished (its launch statistics are harvested, as by
+ * ugsm_wait), UGSM_PENDING while it has not. */
+int ugsm_poll(ugsm_ctx *ctx, int slot);
+
+/* ---- the queue: the library owns the slots (round 5) -------------------------------------------------------------------------------
+ *
+ * What a host needs for THROUGHPUT is not "a call of n pairs on slot s" but "here is another pair; tell me when it is done": which
+ * pairs share a call, which slot takes it and when a slot is free again is the library's business.  (Rounds 3-4 kept that logic in the
+ * benchmark harness -- bench.py's plan_calls / run / submit -- where no user of this header could reach it.)  The reference node's
+ * topic path (UG_GPU_matcher.cpp:126-185,414-494: one blocking match() per synchronised image pair inside a single-threaded
+ * ros::spin, :749-752) becomes enqueue-on-arrival + publish-on-completion with `frames_in_flight` pairs outstanding
+ * (ros/UG_GPU_matcher_ugsm.cpp, ug_stereomatcher_amd/service.py); results are reported strictly in the order the pairs were enqueued.
+ *
+ * ugsm_enqueue_* appends one pair to the context's backlog and returns; it never waits for that pair.  Calls are formed from the
+ * backlog by one rule ("batch what has piled up"):
+ *   - a call goes out as soon as `target` pairs of one kind (mode, memory kind, W x H, stride) wait, where target = ugsm_config.batch,
+ *     except for the first `slots` calls after the queue was idle, which are staggered -- call c takes ceil(batch (c + 2) / (slots + 1))
+ *     pairs (4, 5, 7, 8 for batch 8 on four slots) so that the slots do not march through the pyramid levels in phase from a drained
+ *     pipe ("The queue");
+ *   - ugsm_flush, or a blocking ugsm_next_done, declares that nothing more is coming for now: whatever waits goes out in calls of at
+ *     most `target` pairs as slots come free, without waiting for a call to fill.  A host that wants every frame started at once calls
+ *     ugsm_flush after every ugsm_enqueue_*: calls then hold one pair while slots are free and grow by themselves under load;
+ *   - a pair of another kind than the ones waiting sends those out first (a call holds pairs of one kind).
+ * Slots are used in rotation; a free slot is preferred, else the call waits (inside ugsm_enqueue_*: back-pressure) for the slot that
+ * holds the oldest call.  At most (slots + 1) x batch pairs are outstanding -- enqueued and not yet reported by ugsm_next_done -- at
+ * any time: a host that recycles (slots + 1) x batch result buffers in enqueue order never overwrites a result it has not been told
+ * about.  A host that lets completions pile up unfetched until that many are outstanding gets UGSM_ERR_STATE from ugsm_enqueue_*
+ * (nothing is enqueued; fetch with ugsm_next_done and try again).
+ * The library makes progress only inside its own entry points (no thread of its own): calls go out and completions are noticed during
+ * ugsm_enqueue_*, ugsm_flush and ugsm_next_done.  While pairs are outstanding the slots belong to the queue: the slot-level entry points
+ * (ugsm_submit_*, ugsm_match_*, ugsm_stage_*) answer UGSM_ERR_STATE until every pair has been reported.
+ * Results are identical, bit for bit, to single calls of ugsm_submit_full / ugsm_submit_foveated on the same inputs, however the pairs
+ * were grouped. */
+typedef struct ugsm_completion {
+    uint64_t tag;          /* the host's name for the pair (ugsm_enqueue_*) */
+    int status;            /* UGSM_OK, or the status of the library call the pair went out in */
+    int slot;              /* slot that ran it */
+    int call_pairs;        /* pairs of that call ... */
+    int reserved;
+    long long call_index;  /* ... and its running number since ugsm_create */
+    long long done_ns;     /* CLOCK_MONOTONIC, nanoseconds, when the library noticed the call complete */
+    float *result[5];      /* ugsm_enqueue_*_managed only (else NULL): page-locked planes owned by the library, valid until the NEXT
+                              ugsm_next_done on this context -- full mode: dispH, dispV, dispC (H x W each); foveated: stackH, stackV, stackC
+                              ((F fovH) x fovW each), then the L and R pyramid stacks ((F 3 fovH) x fovW) if they were asked for */
+} ugsm_completion;
+
+/* Device buffers (as ugsm_submit_full / ugsm_submit_foveated; d_pyrL / d_pyrR may be NULL).  Inputs and outputs must stay valid and
+ * untouched until the pair's tag has been reported by ugsm_next_done. */
+int ugsm_enqueue_full(ugsm_ctx *ctx, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, float *d_out, uint64_t tag);
+int ugsm_enqueue_foveated(ugsm_ctx *ctx, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int off_x, int off_y,
+                          float *d_stack, float *d_pyrL, float *d_pyrR, uint64_t tag);
+/* PAGE-LOCKED host buffers (as ugsm_submit_full_host / ugsm_submit_foveated_host; UGSM_ERR_BAD_ARG if any is not): uploads, match
+ * and downloads are enqueued with the call the pair goes out in.  Same lifetime rule. */
+int ugsm_enqueue_full_host(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH, float *dispV,
+                           float *dispC, uint64_t tag);
+int ugsm_enqueue_foveated_host(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                               float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR, uint64_t tag);
+/* Any host memory in, library-owned results out: the images are copied into page-locked staging memory of the context BEFORE the call
+ * returns (the caller's buffers -- a ROS message's payload -- may be freed at once), the results land in page-locked planes the library
+ * lends to the host through ugsm_completion.result.  This is what the node's topic path uses: no page-locked memory to manage, no
+ * result planes to allocate per frame (the reference mallocs and frees 193 MB per 16 MP frame, UG_GPU_matcher.cpp:414-418,487-489).
+ * want_pyramids: also return the L / R fovea pyramid stacks (matchStackPyramid, MatchGPULib.cpp:534-700). */
+int ugsm_enqueue_full_managed(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, uint64_t tag);
+int ugsm_enqueue_foveated_managed(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                                  int want_pyramids, uint64_t tag);
+/* "Nothing more is coming for now": every pair waiting at this moment goes out as slots allow, without waiting for its call to fill.
+ * Never blocks: pairs no slot is free for stay queued and go out inside a later ugsm_enqueue_* / ugsm_next_done. */
+int ugsm_flush(ugsm_ctx *ctx);
+/* The oldest pair not yet reported.  UGSM_OK: *out filled (out->status tells how its call went).  block = 0: UGSM_PENDING if that pair
+ * has not finished (or has not gone out yet), UGSM_EMPTY if there is none.  block != 0: implies ugsm_flush, waits for the pair;
+ * UGSM_EMPTY only if nothing is outstanding. */
+int ugsm_next_done(ugsm_ctx *ctx, ugsm_completion *out, int block);
+/* Pairs waiting in the backlog, pairs in calls that are in flight (as far as the library has noticed), completions not yet fetched. */
+int ugsm_queue_depth(ugsm_ctx *ctx, int *waiting, int *in_flight, int *unreported);
+/* Host only: the calls the queue of a context created with `cfg` (NULL = defaults) forms from a burst of n_pairs pairs of one kind
+ * enqueued back to back from idle and then flushed -- sizes[0 .. return value) (cap entries at most are written; the return value is
+ * the number of calls, or -1 for bad arguments).  20 pairs, batch 8, four slots: 4, 5, 7, 4. */
+int ugsm_queue_plan(const ugsm_config *cfg, int n_pairs, int *sizes, int cap);
 
 /* Fovea sharding over several GPUs (north-star; no reference counterpart: the
  * reference has one centred fovea on one GPU).  coarse: pyramids + levels
@@ -235,6 +322,43 @@ int ugsm_submit_pyramids(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const u
 int ugsm_submit_fovea_coarse(ugsm_ctx *ctx, int slot, float *d_state);
 int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int off_x, int off_y,
                            float *d_stack);
+
+/* ---- the fovea shard with its exchange inside the library (round 5): RCCL on the slot's own stream ---------------------------------
+ *
+ * One process (or one context) per GPU; the contexts of a shard form ONE RCCL communicator.  ugsm_submit_fovea_shard enqueues, on the
+ * slot's stream and nowhere else: the pair's pyramids; on rank `src_rank` the coarse full-frame levels top .. F-1
+ * (ugsm_submit_fovea_coarse); ncclBroadcast of level F-1's (dx, dy, conf) -- 3 x fovH x fovW floats, 3.0 MB at 16 MP -- from src_rank;
+ * the fine levels F-2 .. 0 of THIS rank's window (off_x, off_y) into d_stack (ugsm_submit_fovea_fine).  No event, no second stream,
+ * no host synchronisation: stream order is the whole protocol, and the call returns after enqueueing (ugsm_wait / ugsm_poll as usual).
+ * Every rank must make the same sequence of shard calls on the same slot numbers (collectives match by order).  With the centre window
+ * the result equals ugsm_submit_foveated's, bit for bit.  The reference has one centred fovea on one GPU (MatchGPULib.cpp:1173-1176),
+ * seeded from level F-1 (:1230-1240, :1283-1293); the window offset and the shard are this build's (BASELINE.json north_star).
+ * librccl.so.1 is loaded on first use (dlopen: a host that never shards does not pay for a 570 MB library); UGSM_ERR_NO_DEVICE when it
+ * cannot be found, UGSM_ERR_DEVICE + ugsm_last_error for RCCL failures. */
+#define UGSM_SHARD_ID_BYTES 128  /* sizeof(ncclUniqueId) */
+/* Rank 0 makes an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by whatever means the host has (a ROS parameter, a
+ * file, MPI, torch.distributed's store): out-of-band, once. */
+int ugsm_shard_unique_id(void *id128);
+/* One process per GPU: joins the communicator `id128` names as rank `rank` of `world` (ncclCommInitRank).  Collective: returns when
+ * all ranks have joined.  A context belongs to at most one communicator (UGSM_ERR_STATE otherwise). */
+int ugsm_shard_init(ugsm_ctx *ctx, const void *id128, int rank, int world);
+/* One process that owns several GPUs: ctxs[0 .. n) (each created on its own device) become ranks 0 .. n-1 of one communicator
+ * (ncclCommInitAll).  The shard calls of the n contexts must then come from ONE HOST THREAD PER CONTEXT (a collective waits for its
+ * peers; the library cannot wrap a step in ncclGroupStart / ncclGroupEnd because a grouped broadcast is only launched at the group's
+ * end, i.e. after the fine phase that must follow it on the stream). */
+int ugsm_shard_init_all(ugsm_ctx *const *ctxs, int n);
+int ugsm_shard_rank(const ugsm_ctx *ctx, int *rank, int *world);
+/* Number of ranks RCCL itself counts: an ncclAllReduce(sum) of one 1 per rank on slot 0's stream, waited for.  = world when the
+ * communicator really spans that many ranks. */
+int ugsm_shard_count_ranks(ugsm_ctx *ctx, int *ranks);
+int ugsm_submit_fovea_shard(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int off_x,
+                            int off_y, float *d_stack, int src_rank);
+/* Optional: every rank's fovea stack (3 x (F fovH) x fovW floats, 21 MB at 16 MP) to the one consumer rank -- ncclSend on the others,
+ * ncclRecv x (world - 1) + one device copy on dst_rank, on the slot's stream (ordered after the slot's shard call).  d_all (dst_rank
+ * only, else NULL): world x stack_floats. */
+int ugsm_shard_gather(ugsm_ctx *ctx, int slot, const float *d_stack, long long stack_floats, float *d_all, int dst_rank);
+/* Leaves the communicator (ncclCommDestroy); ugsm_destroy does it too. */
+int ugsm_shard_finalize(ugsm_ctx *ctx);
 
 /* ---- next row: triangulation of the full-resolution disparity ---------- */
 
@@ -329,6 +453,9 @@ int ugsm_host_free(ugsm_ctx *ctx, void *h_ptr);
 int ugsm_copy_to_device(ugsm_ctx *ctx, void *d_dst, const void *h_src, long long bytes);
 int ugsm_copy_to_host(ugsm_ctx *ctx, void *h_dst, const void *d_src, long long bytes);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

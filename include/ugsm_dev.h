@@ -14,6 +14,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* The fused kernels' exact arithmetic shortcuts (f32 first quotient of PolyDisparity, x/3 by two
  * FMAs) evaluated on caller-supplied operands: delta/corr = PolyDisparity(c,l,r,thr)
@@ -32,6 +35,9 @@ int ugsm_stage_div3_probe(ugsm_ctx *ctx, const float *d_a0, const float *d_a1, c
  * q[i] must equal the IEEE binary32 quotient n[i] / d[i] bit for bit for operands that are 0 or in [2^-62, 2^37]. */
 int ugsm_stage_div_probe(ugsm_ctx *ctx, const float *d_n, const float *d_d, float *d_q, int n);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,32 @@ def orc():
     return oracle
 
 
+def _oracle_16mp(orc, seed_off, with_stack):
+    from ug_stereomatcher_amd import synth
+    W, H = 4928, 3264
+    L, R, dx, dy = synth.make_pair(W, H, synth.BASE_SEED + seed_off)
+    orc.set_num_threads(16)
+    try:
+        full = orc.match_full(L, R, 14)
+        stack = orc.match_foveated(L, R, 14, 7)[0] if with_stack else None   # (3, F, fovH, fovW)
+    finally:
+        orc.set_num_threads(8)
+    return dict(W=W, H=H, L=L, R=R, dx=dx, dy=dy, full=full, stack=stack)
+
+
+@pytest.fixture(scope="session")
+def oracle_16mp(orc):
+    """The 16 MP synthetic pair of BASELINE configs[2] / configs[3] (bench.py's first pair) and the live oracle's answers for it (full
+    pyramid: about 3 s on the GPU box's 16 threads; foveated stack: under a second), shared by every full-size parity test."""
+    return _oracle_16mp(orc, 2, True)
+
+
+@pytest.fixture(scope="session")
+def oracle_16mp_b(orc):
+    """bench.py's second 16 MP pair (seed + 16) and the oracle's full-mode answer for it."""
+    return _oracle_16mp(orc, 2 + 16, False)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name))
 

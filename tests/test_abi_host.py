@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     so = C.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
-    assert lib.load().ugsm_abi_version() == 4
+    assert lib.load().ugsm_abi_version() == 5
     assert lib.load().ugsm_is_dev_library() == 0
 
 
@@ -41,7 +41,7 @@ def test_dev_header_symbols_are_exported_by_the_dev_library_only(lib):
         assert not hasattr(prod, name), f"{name} is a development entry point but libugsm.so exports it"
     for name in lib.EXPORTS:
         assert hasattr(dev, name)
-    assert lib.load(dev=True).ugsm_is_dev_library() == 1 and lib.load(dev=True).ugsm_abi_version() == 4
+    assert lib.load(dev=True).ugsm_is_dev_library() == 1 and lib.load(dev=True).ugsm_abi_version() == 5
 
 
 def test_product_library_holds_no_development_kernel(lib):

@@ -422,20 +422,7 @@ def test_1080p_vs_oracle_bit_exact(lib, orc):
     assert_bit_equal(out, ref, "1080p full vs oracle")
 
 
-@pytest.fixture(scope="module")
-def oracle_16mp(orc):
-    """The 16 MP synthetic pair of BASELINE configs[2] / configs[3] and the live oracle's answers for it (full pyramid: about 3 s on
-    the GPU box's 16 threads; foveated stack: under a second), shared by the tests below."""
-    from ug_stereomatcher_amd import synth
-    W, H = 4928, 3264
-    L, R, dx, dy = synth.make_pair(W, H, synth.BASE_SEED + 2)
-    orc.set_num_threads(16)
-    try:
-        full = orc.match_full(L, R, 14)
-        stack, _, _ = orc.match_foveated(L, R, 14, 7)   # (3, F, fovH, fovW)
-    finally:
-        orc.set_num_threads(8)
-    return dict(W=W, H=H, L=L, R=R, dx=dx, dy=dy, full=full, stack=stack)
+# (oracle_16mp: the 16 MP pair and the oracle's answers for it -- tests/conftest.py, shared with test_gpu_queue.py)
 
 
 def test_16mp_throughput_policy_vs_oracle_bit_exact(lib, oracle_16mp):

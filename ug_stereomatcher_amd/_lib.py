@@ -27,6 +27,9 @@ UGSM_ERR_NO_DEVICE = 4
 UGSM_ERR_DEVICE = 5
 UGSM_ERR_NOMEM = 6
 UGSM_ERR_STATE = 7
+UGSM_PENDING = 8   # not an error: not finished yet (ugsm_poll, ugsm_next_done with block = 0)
+UGSM_EMPTY = 9     # not an error: nothing outstanding (ugsm_next_done)
+UGSM_SHARD_ID_BYTES = 128
 UGSM_MAX_LEVELS = 32
 
 # every symbol include/ugsm.h declares (tests check the library exports all of them)
@@ -40,6 +43,12 @@ EXPORTS = [
     "ugsm_stage_iterate", "ugsm_stage_seed", "ugsm_stage_smooth", "ugsm_stage_weighted_difference", "ugsm_last_iterations", "ugsm_get_kernel_stats",
     "ugsm_stage_lr_check", "ugsm_last_lr_marked", "ugsm_slot_stream",
     "ugsm_reset_kernel_stats", "ugsm_set_profile_events", "ugsm_dev_alloc", "ugsm_dev_free", "ugsm_host_alloc", "ugsm_host_free", "ugsm_copy_to_device", "ugsm_copy_to_host",
+    # ABI 5: the queue ...
+    "ugsm_poll", "ugsm_enqueue_full", "ugsm_enqueue_foveated", "ugsm_enqueue_full_host", "ugsm_enqueue_foveated_host", "ugsm_enqueue_full_managed",
+    "ugsm_enqueue_foveated_managed", "ugsm_flush", "ugsm_next_done", "ugsm_queue_depth", "ugsm_queue_plan",
+    # ... and RCCL inside the library
+    "ugsm_shard_unique_id", "ugsm_shard_init", "ugsm_shard_init_all", "ugsm_shard_rank", "ugsm_shard_count_ranks", "ugsm_submit_fovea_shard",
+    "ugsm_shard_gather", "ugsm_shard_finalize",
 ]
 # ... and what include/ugsm_dev.h adds (libugsm_dev.so only)
 DEV_EXPORTS = ["ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe"]
@@ -66,6 +75,11 @@ class LevelPlan(C.Structure):
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("level", C.c_int), ("reserved", C.c_int), ("launches", C.c_longlong),
                 ("total_ms", C.c_double), ("pixel_launches", C.c_double)]
+
+
+class Completion(C.Structure):
+    _fields_ = [("tag", C.c_uint64), ("status", C.c_int), ("slot", C.c_int), ("call_pairs", C.c_int), ("reserved", C.c_int),
+                ("call_index", C.c_longlong), ("done_ns", C.c_longlong), ("result", C.POINTER(C.c_float) * 5)]
 
 
 _libs = {}
@@ -167,6 +181,26 @@ def load(dev: bool = False):
     lib.ugsm_host_free.argtypes = [vp, vp]
     lib.ugsm_copy_to_device.argtypes = [vp, vp, vp, C.c_longlong]
     lib.ugsm_copy_to_host.argtypes = [vp, vp, vp, C.c_longlong]
+    u64 = C.c_uint64
+    lib.ugsm_poll.argtypes = [vp, i]
+    lib.ugsm_enqueue_full.argtypes = [vp, vp, vp, i, i, i, vp, u64]
+    lib.ugsm_enqueue_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, u64]
+    lib.ugsm_enqueue_full_host.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, u64]
+    lib.ugsm_enqueue_foveated_host.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp, u64]
+    lib.ugsm_enqueue_full_managed.argtypes = [vp, vp, vp, i, i, i, u64]
+    lib.ugsm_enqueue_foveated_managed.argtypes = [vp, vp, vp, i, i, i, i, i, i, u64]
+    lib.ugsm_flush.argtypes = [vp]
+    lib.ugsm_next_done.argtypes = [vp, C.POINTER(Completion), i]
+    lib.ugsm_queue_depth.argtypes = [vp, ip, ip, ip]
+    lib.ugsm_queue_plan.argtypes = [C.POINTER(Config), i, ip, i]
+    lib.ugsm_shard_unique_id.argtypes = [vp]
+    lib.ugsm_shard_init.argtypes = [vp, vp, i, i]
+    lib.ugsm_shard_init_all.argtypes = [C.POINTER(vp), i]
+    lib.ugsm_shard_rank.argtypes = [vp, ip, ip]
+    lib.ugsm_shard_count_ranks.argtypes = [vp, ip]
+    lib.ugsm_submit_fovea_shard.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, i]
+    lib.ugsm_shard_gather.argtypes = [vp, i, vp, C.c_longlong, vp, i]
+    lib.ugsm_shard_finalize.argtypes = [vp]
     if bool(lib.ugsm_is_dev_library()) != bool(dev):
         raise UgsmError(UGSM_ERR_STATE, f"{path} is not the {'development' if dev else 'product'} build")
     _libs[dev] = lib
@@ -363,6 +397,92 @@ class Context:
                                                             W, H, stride, ox, oy, self._ptrs([t[0].ctypes.data for t in stacks]),
                                                             self._ptrs([t[1].ctypes.data for t in stacks]), self._ptrs([t[2].ctypes.data for t in stacks])))
 
+    # ---- the queue (ugsm_enqueue_* / ugsm_flush / ugsm_next_done): the library owns the slots ----------------------------------------
+    def enqueue_full(self, d_rgbL: int, d_rgbR: int, W: int, H: int, stride: int, d_out: int, tag: int):
+        self.check(self.lib.ugsm_enqueue_full(self._h, d_rgbL, d_rgbR, W, H, stride, d_out, tag))
+
+    def enqueue_foveated(self, d_rgbL: int, d_rgbR: int, W: int, H: int, stride: int, off, d_stack: int, tag: int, d_pyrL=None, d_pyrR=None):
+        self.check(self.lib.ugsm_enqueue_foveated(self._h, d_rgbL, d_rgbR, W, H, stride, int(off[0]), int(off[1]), d_stack, d_pyrL, d_pyrR, tag))
+
+    def enqueue_full_host(self, rgbL: np.ndarray, rgbR: np.ndarray, out3: np.ndarray, tag: int):
+        """rgbL / rgbR: page-locked (H, W, 3) uint8 (host_array); out3: page-locked (3, H, W) float32."""
+        H, W = rgbL.shape[:2]
+        self.check(self.lib.ugsm_enqueue_full_host(self._h, rgbL.ctypes.data, rgbR.ctypes.data, W, H, rgbL.strides[0], out3[0].ctypes.data,
+                                                   out3[1].ctypes.data, out3[2].ctypes.data, tag))
+
+    def enqueue_foveated_host(self, rgbL: np.ndarray, rgbR: np.ndarray, off, stack3: np.ndarray, tag: int, pyrL=None, pyrR=None):
+        H, W = rgbL.shape[:2]
+        self.check(self.lib.ugsm_enqueue_foveated_host(self._h, rgbL.ctypes.data, rgbR.ctypes.data, W, H, rgbL.strides[0], int(off[0]), int(off[1]),
+                                                       stack3[0].ctypes.data, stack3[1].ctypes.data, stack3[2].ctypes.data,
+                                                       pyrL.ctypes.data if pyrL is not None else None, pyrR.ctypes.data if pyrR is not None else None, tag))
+
+    def enqueue_full_managed(self, rgbL: np.ndarray, rgbR: np.ndarray, tag: int):
+        """Any host memory: the images are copied before the call returns; the results come back in ugsm_completion.result."""
+        H, W = rgbL.shape[:2]
+        self.check(self.lib.ugsm_enqueue_full_managed(self._h, rgbL.ctypes.data, rgbR.ctypes.data, W, H, rgbL.strides[0], tag))
+
+    def enqueue_foveated_managed(self, rgbL: np.ndarray, rgbR: np.ndarray, off, want_pyramids: bool, tag: int):
+        H, W = rgbL.shape[:2]
+        self.check(self.lib.ugsm_enqueue_foveated_managed(self._h, rgbL.ctypes.data, rgbR.ctypes.data, W, H, rgbL.strides[0], int(off[0]), int(off[1]),
+                                                          1 if want_pyramids else 0, tag))
+
+    def flush(self):
+        self.check(self.lib.ugsm_flush(self._h))
+
+    def next_done(self, block: bool = True):
+        """The oldest pair not yet reported as a Completion, or None (block=False: not finished yet, or nothing outstanding; block=True:
+        nothing outstanding).  A completion whose call failed raises."""
+        c = Completion()
+        st = self.lib.ugsm_next_done(self._h, C.byref(c), 1 if block else 0)
+        if st in (UGSM_PENDING, UGSM_EMPTY):
+            return None
+        self.check(st)
+        if c.status:
+            raise UgsmError(c.status, f"pair {c.tag}: {status_string(c.status)}: {self.lib.ugsm_last_error(self._h).decode()}")
+        return c
+
+    def drain(self):
+        """Flushes and fetches every outstanding completion, oldest first."""
+        out = []
+        while True:
+            c = self.next_done(True)
+            if c is None:
+                return out
+            out.append(c)
+
+    def queue_depth(self):
+        w, f, u = C.c_int(), C.c_int(), C.c_int()
+        self.check(self.lib.ugsm_queue_depth(self._h, C.byref(w), C.byref(f), C.byref(u)))
+        return w.value, f.value, u.value
+
+    @staticmethod
+    def managed_planes(c: "Completion", shapes):
+        """numpy views (valid until the next next_done on the context) of a managed completion's result planes; shapes: one per plane wanted."""
+        out = []
+        for k, shp in enumerate(shapes):
+            n = int(np.prod(shp))
+            out.append(np.ctypeslib.as_array(c.result[k], shape=(n,)).reshape(shp))
+        return out
+
+    # ---- the fovea shard with RCCL inside the library (ugsm_shard_*) ------------------------------------------------------------------
+    def shard_init(self, id128: bytes, rank: int, world: int):
+        buf = (C.c_char * UGSM_SHARD_ID_BYTES).from_buffer_copy(id128)
+        self.check(self.lib.ugsm_shard_init(self._h, buf, rank, world))
+
+    def shard_count_ranks(self) -> int:
+        n = C.c_int()
+        self.check(self.lib.ugsm_shard_count_ranks(self._h, C.byref(n)))
+        return n.value
+
+    def submit_fovea_shard(self, slot: int, d_rgbL: int, d_rgbR: int, W: int, H: int, stride: int, off, d_stack: int, src_rank: int = 0):
+        self.check(self.lib.ugsm_submit_fovea_shard(self._h, slot, d_rgbL, d_rgbR, W, H, stride, int(off[0]), int(off[1]), d_stack, src_rank))
+
+    def shard_gather(self, slot: int, d_stack: int, stack_floats: int, d_all, dst_rank: int = 0):
+        self.check(self.lib.ugsm_shard_gather(self._h, slot, d_stack, stack_floats, d_all, dst_rank))
+
+    def shard_finalize(self):
+        self.check(self.lib.ugsm_shard_finalize(self._h))
+
     def kernel_stats(self):
         """One dict per (kernel, pyramid level) with harvested launches; level -1 = not tied to a level."""
         cap = 512
@@ -393,6 +513,30 @@ def plan_level(W: int, H: int, frame=None, **cfg_fields):
         raise UgsmError(st, "ugsm_plan_level")
     return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "latency_policy",
                                               "pairs_per_launch")}
+
+
+def shard_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 makes one and hands it to the other ranks out of band)."""
+    buf = (C.c_char * UGSM_SHARD_ID_BYTES)()
+    st = load().ugsm_shard_unique_id(buf)
+    if st != 0:
+        raise UgsmError(st, "ugsm_shard_unique_id: " + status_string(st))
+    return bytes(buf)
+
+
+def queue_plan(n_pairs: int, **cfg_fields):
+    """The calls the queue forms from a burst of n_pairs pairs enqueued from idle and flushed (host only)."""
+    lib = load()
+    cfg = Config()
+    lib.ugsm_default_config(C.byref(cfg))
+    for k, v in cfg_fields.items():
+        setattr(cfg, k, v)
+    cap = max(1, n_pairs)
+    sizes = (C.c_int * cap)()
+    n = lib.ugsm_queue_plan(C.byref(cfg), n_pairs, sizes, cap)
+    if n < 0:
+        raise UgsmError(UGSM_ERR_BAD_ARG, "ugsm_queue_plan")
+    return list(sizes[:n])
 
 
 def fovea_mapping(W: int, H: int, src_level: int, dest_level: int = 0):

@@ -1,0 +1,32 @@
+// ugsm_internal.hpp -- what the layers above the slot API (ugsm_queue.cpp: the queue; ugsm_shard.cpp: RCCL) need from the runtime
+// besides include/ugsm.h itself.  Both are written against the public slot-level entry points (ugsm_submit_*, ugsm_wait, ugsm_poll,
+// ugsm_slot_stream): they are what a host would otherwise have to write, moved behind the C-ABI.
+#pragma once
+
+#include "../../include/ugsm.h"
+
+#include <stddef.h>
+
+namespace ugsm {
+
+// State the layers hang on a context; the runtime owns the storage and calls the `free` hooks from ugsm_destroy (before the slots go).
+struct CtxHooks {
+    void *queue = nullptr;
+    void (*queue_free)(ugsm_ctx *, void *) = nullptr;
+    void *shard = nullptr;
+    void (*shard_free)(ugsm_ctx *, void *) = nullptr;
+    bool queue_busy = false;   // pairs are outstanding in the queue: the slots belong to it (slot-level entry points answer UGSM_ERR_STATE)
+    bool queue_calling = false;  // ... except while the queue itself is calling them
+};
+CtxHooks &ctx_hooks(ugsm_ctx *ctx);
+const ugsm_config &ctx_config(const ugsm_ctx *ctx);
+// sets ugsm_last_error and returns `status`
+int ctx_fail(ugsm_ctx *ctx, int status, const char *what);
+// memcpy by the context's host team (large copies; falls back to the calling thread)
+void ctx_host_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes);
+// hipPointerGetAttributes says page-locked host memory
+bool host_pinned(const void *p);
+// the stagger of the queue's first round after idle and the size of every later call (ugsm.h, "the queue")
+int queue_target(int batch, int slots, long long calls_since_idle);
+
+}  // namespace ugsm

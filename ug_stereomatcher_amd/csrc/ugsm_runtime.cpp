@@ -7,7 +7,11 @@
 // HIP stream ("slot") so the launch-bound coarse levels of one pair overlap the
 // bandwidth/VALU-bound fine levels of another.
 #include "../../include/ugsm.h"
+#ifdef UGSM_DEV_LIB
+#include "../../include/ugsm_dev.h"
+#endif
 #include "ugsm_device.hpp"
+#include "ugsm_internal.hpp"
 #include "ugsm_launch.hpp"
 
 #include <hip/hip_runtime.h>
@@ -196,7 +200,18 @@ struct ugsm_ctx {
     int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
     long long batch_max_px = 0;  // development override of kBatchMaxPixels (batch_level): levels up to this size go through a batched call as one launch; < 0 = none
+    CtxHooks hooks;  // the queue (ugsm_queue.cpp) and the RCCL shard (ugsm_shard.cpp): layers over the slot API
 };
+
+namespace ugsm {
+CtxHooks &ctx_hooks(ugsm_ctx *ctx) { return ctx->hooks; }
+const ugsm_config &ctx_config(const ugsm_ctx *ctx) { return ctx->cfg; }
+int ctx_fail(ugsm_ctx *ctx, int status, const char *what)
+{
+    if (ctx && what) ctx->err = what;
+    return status;
+}
+}  // namespace ugsm
 
 namespace {
 
@@ -1254,6 +1269,10 @@ int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
         ctx->err = "slot out of range";
         return UGSM_ERR_BAD_ARG;
     }
+    if (enqueues && ctx->hooks.queue_busy && !ctx->hooks.queue_calling) {
+        ctx->err = "pairs enqueued with ugsm_enqueue_* are outstanding: the slots belong to the queue until ugsm_next_done has reported them all";
+        return UGSM_ERR_STATE;
+    }
     *out = &ctx->slots[slot];
     if (enqueues) (*out)->done_recorded = false;  // whatever this call enqueues comes after the slot's last completion mark
     return UGSM_OK;
@@ -1402,6 +1421,11 @@ int copy_out_planes(ugsm_ctx *ctx, Slot &s, const float *d_src, size_t plane_flo
 
 }  // namespace
 
+namespace ugsm {
+void ctx_host_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes) { team_copy(ctx, dst, src, bytes); }
+bool host_pinned(const void *p) { return is_pinned(p); }
+}  // namespace ugsm
+
 // =========================================================================================
 // C-ABI
 // =========================================================================================
@@ -1433,6 +1457,8 @@ const char *ugsm_status_string(int st)
     case UGSM_ERR_DEVICE: return "HIP runtime error";
     case UGSM_ERR_NOMEM: return "out of device memory";
     case UGSM_ERR_STATE: return "call sequence error";
+    case UGSM_PENDING: return "not finished yet";
+    case UGSM_EMPTY: return "nothing outstanding";
     default: return "unknown status";
     }
 }
@@ -1514,6 +1540,13 @@ void ugsm_destroy(ugsm_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
+    for (Slot &s : ctx->slots) {  // (the layers' state refers to work on the slots' streams: drain them first)
+        if (s.st) (void)hipStreamSynchronize(s.st);
+        if (s.st2) (void)hipStreamSynchronize(s.st2);
+    }
+    if (ctx->hooks.queue && ctx->hooks.queue_free) ctx->hooks.queue_free(ctx, ctx->hooks.queue);
+    if (ctx->hooks.shard && ctx->hooks.shard_free) ctx->hooks.shard_free(ctx, ctx->hooks.shard);
+    ctx->hooks = CtxHooks{};
     for (Slot &s : ctx->slots) {
         if (s.st) (void)hipStreamSynchronize(s.st);
         if (s.st2) (void)hipStreamSynchronize(s.st2);
@@ -1753,6 +1786,17 @@ int ugsm_wait(ugsm_ctx *ctx, int slot)
     UCHK(get_slot(ctx, slot, &s, false));
     if (s->done_recorded) HIPCHK(ctx, hipEventSynchronize(s->ev_done));  // (shared stream: this slot's pair, not the ones queued behind it)
     else HIPCHK(ctx, hipStreamSynchronize(s->st));
+    harvest(ctx, *s);
+    return UGSM_OK;
+}
+
+int ugsm_poll(ugsm_ctx *ctx, int slot)
+{
+    Slot *s;
+    UCHK(get_slot(ctx, slot, &s, false));
+    const hipError_t e = s->done_recorded ? hipEventQuery(s->ev_done) : hipStreamQuery(s->st);
+    if (e == hipErrorNotReady) return UGSM_PENDING;
+    HIPCHK(ctx, e);
     harvest(ctx, *s);
     return UGSM_OK;
 }
