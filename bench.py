@@ -5,10 +5,13 @@
 
 One "step" = one synthetic 16 MP (4928x3264) stereo pair through the full-resolution 14-level
 pyramid path (BASELINE.json configs[2], the configuration `metric` is quoted on), inputs already
-resident in HBM, `--slots` calls of up to `--batch` pairs each in flight on separate HIP streams.  For N > 1 the driver launches
+resident in HBM.  The timed region is a loop over ugsm_enqueue_full + ugsm_next_done (include/ugsm.h, "the queue"): WHICH pairs share a
+library call, which of the `--slots` slots takes it and when a slot is free again is decided inside libugsm.so -- this file holds no
+call planning (rounds 3-4 kept that logic here: plan_calls / run / submit).  For N > 1 the driver launches
 one rank per GPU (torch.distributed.run); run without a launcher, `--gpus N` starts the ranks itself.
 Pairs are independent, so ranks share nothing on the data path ("weak" scaling, no collective); the
-barrier and the max-over-ranks reduction go over RCCL.
+barrier and the max-over-ranks reduction go over RCCL.  --workload fovea-shard: one fovea window per rank, the coarse state broadcast by
+the library's own RCCL communicator on the slot's stream (ugsm_submit_fovea_shard); `rccl_ranks` = what an all-reduce of ones counts.
 
 How the line is put together (rank 0 prints ONE JSON line):
   value, ms_per_step  -- the timed region: W warm-up steps, then exactly K steps between two
@@ -49,7 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PIXEL_ITER = 48.0  # L 12 + R 12 + (dx,dy,conf) in 12 + out 12
 BYTES_PER_PIXEL = {"k_cost": BYTES_PER_PIXEL_ITER, "k_smooth": 24.0, "k_box": 24.0, "k_warp": 36.0, "k_sqblur": 24.0, "k_seed": 24.0}
 REFERENCE_PAIRS_PER_S = {"full16mp": 0.1, "fovea16mp": 1.0 / 3.0}  # BASELINE.md section 1 (README.md:15-16)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 WORKLOADS = {
     "full16mp": dict(W=4928, H=3264, mode="full", desc="16MP (4928x3264) stereo pair, full-res 14-level pyramid"),
@@ -167,29 +170,9 @@ def cpu_baseline(wl: dict, runs: int = 3):
             "host_cpu_count": os.cpu_count(), "usable_cpus": usable_cpus(), "cpu_model": cpu_model(), "all_cores": allc, "one_thread": one}
 
 
-def plan_calls(n: int, slots: int, B: int, taper: float = 0.0, head=None):
-    """Sizes of the calls that take n pairs through `slots` slots with at most B pairs per call (ugsm_submit_*_batch), in submission order:
-    a host that batches what has piled up -- full-size calls while B pairs are left, the rest in one call.  The first round of calls is
-    staggered in size -- slot c starts with at most ceil(B (c + 2) / (slots + 1)) pairs: 2, 3, 4, 4 for B = 4 on four slots -- so that the
-    slots do not march through the levels in phase from a drained pipe (same box, 20 steps: 172 against 169 pairs/s; 162 for 4, 3, 2, 1).
-    `taper` > 0 shrinks the calls towards the end, min(B, remaining / (taper x slots)): the default of the first half of round 4
-    (taper 1), measured again with the staggered start in place and dropped -- same box, full-size calls to the end against taper 1:
-    178.1 against 172.0 pairs/s over 20 steps, 181.4 / 178.7 over 40, 184.2 / 181.1 over 96, 184.9 / 184.5 over 384
-    (tools/exp/taper.sh).  `head` overrides the stagger (experiments)."""
-    if head is None:
-        head = [-(-B * (c + 2) // (slots + 1)) for c in range(slots)]
-    sizes, k = [], 0
-    while k < n:
-        nb = min(B, n - k) if taper <= 0 else max(1, min(B, n - k, int((n - k) / (taper * slots))))
-        if len(sizes) < len(head):
-            nb = max(1, min(nb, head[len(sizes)], n - k))
-        sizes.append(nb)
-        k += nb
-    return sizes
-
-
 def steady_window(call_sizes, slots: int):
-    """(lo, hi): indices of the LAST PAIR of the first and of the last call that have the pipe full of FULL-size calls behind them (the call
+    """Analysis only -- the calls are formed by the library's queue (ugsm_completion.call_index / call_pairs say which).
+    (lo, hi): indices of the LAST PAIR of the first and of the last call that have the pipe full of FULL-size calls behind them (the call
     itself and the `slots` calls after it are of the region's largest size, and at least `slots` calls precede it), or None when the region has
     no such middle.  The rate between those two completions counts no fill, no drain and no staggered or tapered call: such calls hold
     less work in flight, and an interval that touched them would be credited with work done outside it."""
@@ -286,113 +269,102 @@ def main():
     stride = 3 * W
     if rank == 0:
         log(f"synthetic inputs ready in {time.perf_counter() - t0:.1f} s; workload: {wl['desc']}; slots={slots}")
-    nbuf = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1   # result buffers per slot: one per pair of a call
-    if mode == "full":
-        outs = [[torch.empty((3, H, W), dtype=torch.float32, device=dev) for _ in range(nbuf)] for _ in range(slots)]
-    else:
-        outs = [[torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev) for _ in range(nbuf)] for _ in range(slots)]
-    # fovea-shard: one coarse-state buffer and one "fine phase has read it" event PER SLOT, so that the broadcast of a later
-    # step never overwrites a state an earlier step's fine phase has not copied yet, and the slots overlap
-    states = [torch.empty((3, fh, fw), dtype=torch.float32, device=dev) for _ in range(slots)]
+    B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
+    # result buffers: a ring of (slots + 1) x batch, recycled in enqueue order -- the most the queue lets be outstanding (ugsm.h)
+    cap = (slots + 1) * B
+    shape = (3, H, W) if mode == "full" else (3, F, fh, fw)
+    ring = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(cap)]
     offsets = ud.fovea_window_offsets(n_gpus, W, H, fw, fh)
     my_off = offsets[rank % len(offsets)]
-    shard_drv = ud.UgsmShardDriver(ctx)
+    rccl_ranks = None
+    if mode == "fovea-shard":
+        # the library's own communicator: rank 0 makes the id, torch.distributed's control plane hands it round (out of band, once)
+        rccl_ranks = ud.shard_init(ctx, rank, n_gpus)
     torch.cuda.synchronize()
 
-    done_t = []   # host clock when a pair's completion was noticed (ugsm_wait on its slot returned), in submission order
-    in_slot = [0] * slots   # pairs of the call each slot holds
-    call_sizes = []         # pairs per call of the region being timed, in submission order
-    B = max(1, min(args.batch, _lib.UGSM_MAX_BATCH)) if mode != "fovea-shard" else 1
-    TAPER = float(os.environ.get("UGSM_BENCH_TAPER", "0"))   # > 0: a call takes at most remaining / (TAPER x slots) pairs (experiments)
-    HEAD = [int(v) for v in os.environ["UGSM_BENCH_HEAD"].split(",") if v] if "UGSM_BENCH_HEAD" in os.environ else None   # (experiments; default: plan_calls' stagger)
+    done = []   # completions of the region being timed, in enqueue order (ugsm_completion: tag, call_index, call_pairs, done_ns)
 
-    def wait_slot(s, stamp):
-        ctx.check(ctx.lib.ugsm_wait(ctx.handle, s))  # slot free?  (also: the slot's fine phase has consumed states[s])
-        if stamp and in_slot[s]:
-            done_t.extend([time.perf_counter()] * in_slot[s])   # the pairs of the slot's previous call are complete
-        in_slot[s] = 0
+    def fetch(block):
+        while True:
+            c = ctx.next_done(block)
+            if c is None:
+                return
+            done.append((c.tag, c.call_index, c.call_pairs, c.done_ns))
 
-    def submit(k, slot=None, stamp=False, n=1):
-        """Pairs k .. k+n-1 as ONE call on a slot (n > 1: ugsm_submit_*_batch)."""
-        s = k % slots if slot is None else slot
-        wait_slot(s, stamp)
-        in_slot[s] = n
-        if n > 1:
-            sel = [pairs[(k + b) % 2] for b in range(n)]
-            dL, dR, dO = [p[0].data_ptr() for p in sel], [p[1].data_ptr() for p in sel], [o.data_ptr() for o in outs[s][:n]]
-            if mode == "full":
-                ctx.submit_full_batch(s, dL, dR, W, H, stride, dO)
-            else:
-                ctx.submit_foveated_batch(s, dL, dR, W, H, stride, None, dO)
+    def run(n):
+        """n pairs through the library: enqueue, fetch what has finished, flush at the end, drain.  (fovea-shard: slot-level calls, every
+        rank the same sequence -- collectives match by order -- on the slots in rotation.)"""
+        del done[:]
+        if mode == "fovea-shard":
+            for k in range(n):
+                sl = k % slots
+                ctx.check(ctx.lib.ugsm_wait(ctx.handle, sl))
+                Lt, Rt = pairs[k % 2]
+                ctx.submit_fovea_shard(sl, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, my_off, ring[sl].data_ptr(), 0)
+            ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
             return
-        Lt, Rt = pairs[k % 2]
-        if mode == "full":
-            ctx.check(ctx.lib.ugsm_submit_full(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, outs[s][0].data_ptr()))
-        elif mode == "fovea":
-            ctx.check(ctx.lib.ugsm_submit_foveated(ctx.handle, s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, 0, 0,
-                                                   outs[s][0].data_ptr(), None, None))
-        else:
-            ud.fovea_shard_step(shard_drv, s, Lt, Rt, W, H, stride, states[s], my_off, outs[s][0], rank)
+        for k in range(n):
+            Lt, Rt = pairs[k % 2]
+            if mode == "full":
+                ctx.enqueue_full(Lt.data_ptr(), Rt.data_ptr(), W, H, stride, ring[k % cap].data_ptr(), k)
+            else:
+                ctx.enqueue_foveated(Lt.data_ptr(), Rt.data_ptr(), W, H, stride, (0, 0), ring[k % cap].data_ptr(), k)
+            fetch(False)
+        ctx.flush()
+        fetch(True)
+        assert [d[0] for d in done] == list(range(n))
 
-    def run(n, stamp=False):
-        """n pairs through the slots, call sizes by plan_calls (batches while a backlog exists, staggered at the start)."""
-        call_sizes[:] = plan_calls(n, slots, B, TAPER, HEAD)
-        if os.environ.get("UGSM_BENCH_PLAN") and n == args.steps:   # (experiments: the timed region's calls given outright)
-            call_sizes[:] = [int(v) for v in os.environ["UGSM_BENCH_PLAN"].split(",")]
-            assert sum(call_sizes) == n and max(call_sizes) <= B
-        k = 0
-        for call, nb in enumerate(call_sizes):
-            submit(k, slot=call % slots, stamp=stamp, n=nb)
-            k += nb
-        for c in range(max(0, len(call_sizes) - slots), len(call_sizes)):   # the last calls, in the order they were submitted
-            wait_slot(c % slots, stamp)
-        ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
+    def call_sizes_of(dn):
+        out, last = [], None
+        for (_, ci, cp, _) in dn:
+            if ci != last:
+                out.append(cp)
+                last = ci
+        return out
 
     def steady_state(n):
         """Pairs/s between the completions of the first and the last call of the region just timed that have the pipe full of full-size calls
         behind them (steady_window; SURVEY 8d defines the metric as steady state with the slots full): the region starts from a drained pipe
         and ends by draining it, which costs about one call's in-flight time whatever its length -- 4 % of 96 steps, more of 20 -- and hides
-        changes of a few per cent (VERDICT r03 weak #5).  None when the region is too short to have a middle."""
-        win = steady_window(call_sizes, slots)
-        if len(done_t) != n or win is None or done_t[win[1]] <= done_t[win[0]]:
+        changes of a few per cent.  None when the region is too short to have a middle.  Completion times are the
+        library's (ugsm_completion.done_ns: CLOCK_MONOTONIC when it noticed the call complete)."""
+        win = steady_window(call_sizes_of(done), slots)
+        if len(done) != n or win is None or done[win[1]][3] <= done[win[0]][3]:
             return None
-        return (win[1] - win[0]) / (done_t[win[1]] - done_t[win[0]])
+        return (win[1] - win[0]) / ((done[win[1]][3] - done[win[0]][3]) * 1e-9)
 
     def timed(n):
         torch.cuda.synchronize()
         ud.barrier()
-        del done_t[:]
         t0 = time.perf_counter()
-        run(n, stamp=True)
+        run(n)
         torch.cuda.synchronize()
         ud.barrier()
         return ud.max_over_ranks(time.perf_counter() - t0, dev)
 
     run(args.warmup)
-    if B > 1:   # ... and one full-size call per slot, untimed: whatever a first batched call sets up is not the workload
-        for s_ in range(slots):
-            submit(0, slot=s_, n=B)
-        ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
-        for s_ in range(slots):
-            in_slot[s_] = 0
+    if B > 1:   # ... and enough pairs, untimed, that every slot has run a full-size call: whatever a first batched call sets up is not the workload
+        run(2 * slots * B)
     dt = timed(args.steps)
     work = n_gpus if mode != "fovea-shard" else 1
     value = work * args.steps / dt
+    timed_calls = call_sizes_of(done)
     steady = [steady_state(args.steps)]
     repeats = []
     for _ in range(max(0, args.repeats)):
         repeats.append(work * args.steps / timed(args.steps))
         steady.append(steady_state(args.steps))
-    # A region too short to have a middle (the driver's --steps 20 with calls of four pairs is all fill and drain) gets its steady-state
-    # figure from one more region, long enough to have one, run after the regions `value` and `value_repeats` come from and outside them.
+    # A region too short to have a middle (the driver's --steps 20 is all fill and drain) gets its steady-state figure from one more region,
+    # long enough to have one, run after the regions `value` and `value_repeats` come from and outside them.
     steady_region, steady_steps = "the timed region of `value`", args.steps
-    if args.steady_steps != 0 and steady_window(plan_calls(args.steps, slots, B, TAPER, HEAD), slots) is None:   # (the same answer on every rank: timed() holds barriers)
+    steady_calls = timed_calls
+    if args.steady_steps != 0 and mode != "fovea-shard" and steady_window(timed_calls, slots) is None:   # (the same answer on every rank: the queue's rule is deterministic)
         steady_steps = args.steady_steps if args.steady_steps > 0 else max(args.steps, 48 * B, 12 * slots * B)
         timed(steady_steps)
         steady[0] = steady_state(steady_steps)
+        steady_calls = call_sizes_of(done)
         steady_region = (f"a further region of {steady_steps} steps after the timed ones (the timed region of {args.steps} steps has no call with the pipe "
                          "full of full-size calls on both sides); `value` and `value_repeats` do not include it")
-    steady_calls = list(call_sizes)
     pi = _lib.pixel_iterations(W, H, 14, 0 if mode == "full" else F)
 
     result = {
@@ -410,16 +382,22 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl["desc"], "slots_per_gpu": slots, "pairs_per_call_max": B, "pairs_in_flight_per_gpu": slots * B,
                    "streams_per_gpu": args.streams or slots, "kernel_path": args.kernel_path,
-                   "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}"},
+                   "pixel_iterations_per_pair": pi, "parallelism": f"replicas x{n_gpus}" if mode != "fovea-shard" else f"fovea windows x{n_gpus}",
+                   "host_loop": "ugsm_enqueue_* + ugsm_next_done (the library forms the calls and owns the slots)" if mode != "fovea-shard"
+                                else "ugsm_submit_fovea_shard on the slots in rotation (ncclBroadcast on the slot's stream, inside the library)"},
+        # the calls the LIBRARY formed from the timed region's pairs (ugsm_completion.call_pairs), e.g. [4, 5, 7, 4] for 20 steps
+        "calls_formed_by_the_library": timed_calls if len(timed_calls) <= 16 else {"calls": len(timed_calls), "head": timed_calls[:6], "tail": timed_calls[-6:]},
+        # ranks the library's own RCCL communicator counts (ncclAllReduce of ones; fovea-shard only): = n_gpus when RCCL really spans them
+        "rccl_ranks": rccl_ranks,
         "value_repeats": repeats,
         # this rank's pairs/s between the completions of pair slots + 1 and pair steps - slots, inside the same timed regions as `value`
         # and `value_repeats` (first entry: the region `value` comes from); x n_gpus for independent replicas
         "steady_state": {"value": (work * steady[0]) if steady[0] else None, "repeats": [(work * v) if v else None for v in steady[1:]],
                          "unit": "pairs/s", "region": steady_region, "steps": steady_steps, "calls": len(steady_calls),
                          "call_sizes_head_tail": [steady_calls[:6], steady_calls[-6:]],
-                         "note": "host clock at the return of ugsm_wait(slot) for every call's pairs, in submission order; the rate between the "
-                                 "completions of the first and the last call that have the pipe full of full-size calls behind them: no fill, "
-                                 "no drain, no staggered or tapered calls"},
+                         "note": "ugsm_completion.done_ns (CLOCK_MONOTONIC when the library noticed a call complete) of every pair, in enqueue order; "
+                                 "the rate between the completions of the first and the last call that have the pipe full of full-size calls "
+                                 "behind them: no fill, no drain, no staggered calls"},
         "whole_pair_algorithmic_bytes": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F),
         "whole_pair_algorithmic_GBps": whole_pair_algorithmic_bytes(W, H, 14, 0 if mode == "full" else F) * value / n_gpus / 1e9,
     }
@@ -432,10 +410,14 @@ def main():
         ctx.set_profile_events(2)
         ctx.reset_kernel_stats()
         t0 = time.perf_counter()
-        for k in range(args.profile_pairs):
-            submit(k * B, slot=0, n=B)
+        for k in range(args.profile_pairs):   # (an explicit call of B pairs on slot 0: ugsm_submit_*_batch, the full-size call of the timed region)
+            sel = [pairs[(k * B + b) % 2] for b in range(B)]
+            dL, dR, dO = [p_[0].data_ptr() for p_ in sel], [p_[1].data_ptr() for p_ in sel], [o.data_ptr() for o in ring[:B]]
+            if mode == "full":
+                ctx.submit_full_batch(0, dL, dR, W, H, stride, dO)
+            else:
+                ctx.submit_foveated_batch(0, dL, dR, W, H, stride, None, dO)
             ctx.check(ctx.lib.ugsm_wait(ctx.handle, 0))
-        in_slot[0] = 0
         t_single = (time.perf_counter() - t0) / (args.profile_pairs * B)
         ctx.set_profile_events(0)
         stats = ctx.kernel_stats()
@@ -514,7 +496,7 @@ def main():
     # ---- one pair at a time, un-instrumented, on a ONE-SLOT context: the reference's call pattern (UG_GPU_matcher.cpp:497-694) ------
     if rank == 0 and n_gpus == 1 and mode != "fovea-shard" and args.single_pairs > 0:
         ctx1 = _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=1, kernel_path=args.kernel_path, profile_events=0)
-        out1 = outs[0][0]
+        out1 = ring[0]
 
         def one(k):
             Lt, Rt = pairs[k % 2]
@@ -573,56 +555,46 @@ def main():
             pr[...] = R
             t_pin = call(pl, pr, po)
             ctx_s.close()
-            # several pairs in flight from page-locked host memory ("end-to-end from pinned host memory"): every slot has its own
-            # pinned image pair and result planes; uploads, match and downloads of a pair are enqueued on the slot's stream
-            hb = [(pl, pr, po)] + [(ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W)))
-                                   for _ in range(slots - 1)]
-            for (a_, b_, _) in hb[1:]:
-                a_[...] = L
-                b_[...] = R
-
-            def piped(n):
-                t0 = time.perf_counter()
-                for k in range(n):
-                    sl = k % slots
-                    ctx.check(ctx.lib.ugsm_wait(ctx.handle, sl))
-                    a_, b_, o_ = hb[sl]
-                    ctx.check(ctx.lib.ugsm_submit_full_host(ctx.handle, sl, a_.ctypes.data, b_.ctypes.data, W, H, stride, o_[0].ctypes.data,
-                                                            o_[1].ctypes.data, o_[2].ctypes.data))
-                ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
-                return (time.perf_counter() - t0) / n
-            piped(2 * slots)
-            t_piped = min(piped(12 * slots) for _ in range(2))
-            # ... and in batches (ugsm_submit_full_batch_host): every slot takes Bh pairs per call, each pair with page-locked buffers of its own
-            Bh = 2
-            t_piped_b = None
-            if B > 1:
-                hbb = [hb[sl:sl + 1] + [(ctx.host_array(L.shape, L.dtype), ctx.host_array(R.shape, R.dtype), ctx.host_array((3, H, W))) for _ in range(Bh - 1)]
-                       for sl in range(slots)]
-                for group in hbb:
-                    for (a_, b_, _) in group[1:]:
+            # several pairs in flight from host memory through the queue ("end-to-end from pinned host memory"): the host enqueues
+            # and fetches, the library forms the calls.  Own contexts (batch 1 and batch 2: (slots + 1) x batch page-locked buffer sets of
+            # 290 MB each); `managed` = pageable images in, library-owned page-locked planes out (what the node's topic path uses).
+            def in_flight(Bh, managed):
+                with _lib.Context(device=local_rank, levels=14, fovea_levels=F, slots=slots, kernel_path=args.kernel_path, batch=Bh) as ch:
+                    cap_h = (slots + 1) * Bh
+                    hb = [] if managed else [(ch.host_array(L.shape, L.dtype), ch.host_array(R.shape, R.dtype), ch.host_array((3, H, W))) for _ in range(cap_h)]
+                    for (a_, b_, _) in hb:
                         a_[...] = L
                         b_[...] = R
 
-                def piped_b(n):
-                    t0 = time.perf_counter()
-                    for k in range(n // Bh):
-                        sl = k % slots
-                        ctx.check(ctx.lib.ugsm_wait(ctx.handle, sl))
-                        ctx.submit_full_batch_host(sl, [g[0] for g in hbb[sl]], [g[1] for g in hbb[sl]], W, H, stride, [g[2] for g in hbb[sl]])
-                    ctx.check(ctx.lib.ugsm_wait_all(ctx.handle))
-                    return (time.perf_counter() - t0) / (n // Bh * Bh)
-                piped_b(2 * slots * Bh)
-                t_piped_b = min(piped_b(12 * slots * Bh) for _ in range(2))
+                    def go(n):
+                        t0 = time.perf_counter()
+                        for k in range(n):
+                            if managed:
+                                ch.enqueue_full_managed(L, R, k)
+                            else:
+                                ch.enqueue_full_host(hb[k % cap_h][0], hb[k % cap_h][1], hb[k % cap_h][2], k)
+                            while ch.next_done(False) is not None:
+                                pass
+                        ch.drain()
+                        return (time.perf_counter() - t0) / n
+                    go(2 * slots * Bh)
+                    return min(go(12 * slots * Bh) for _ in range(2))
+            t_piped = in_flight(1, False)
+            Bh = 2
+            t_piped_b = in_flight(Bh, False)
+            t_managed = in_flight(Bh, True)
             result["pcie_inclusive"] = {"pageable_ms_per_pair": 1e3 * t_page, "pageable_pairs_per_s": 1.0 / t_page,
                                         "pinned_ms_per_pair": 1e3 * t_pin, "pinned_pairs_per_s": 1.0 / t_pin,
                                         "pinned_in_flight_pairs_per_s": 1.0 / t_piped, "pinned_in_flight_slots": slots,
-                                        "pinned_in_flight_batched_pairs_per_s": (1.0 / t_piped_b) if t_piped_b else None, "pinned_in_flight_batch": Bh,
-                                        "pinned_in_flight_GBps_over_pcie": (2 * H * stride + 12 * W * H) / t_piped / 1e9,
+                                        "pinned_in_flight_batched_pairs_per_s": 1.0 / t_piped_b, "pinned_in_flight_batch": Bh,
+                                        "managed_in_flight_pairs_per_s": 1.0 / t_managed,
+                                        "pinned_in_flight_GBps_over_pcie": (2 * H * stride + 12 * W * H) / min(t_piped, t_piped_b) / 1e9,
                                         "note": "ugsm_match_full on a one-slot context, one call at a time: rgb8 pair in (2 x 48 MB at 16 MP), three float planes out "
                                                 "(193 MB); median of 3 calls; pageable = fresh result planes for every call, as the reference "
                                                 "node allocates them (UG_GPU_matcher.cpp:414-418); the caller's free() is not in the call; "
-                                                "pinned_in_flight = ugsm_submit_full_host on every slot in turn, page-locked images and planes"}
+                                                "pinned_in_flight = ugsm_enqueue_full_host + ugsm_next_done (the queue; page-locked images and planes of the "
+                                                "host); managed_in_flight = ugsm_enqueue_full_managed (pageable images copied in by the library, results "
+                                                "lent from its page-locked ring), batch 2"}
 
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -245,9 +245,9 @@ int ugsm_poll(ugsm_ctx *ctx, int slot);
  * ugsm_enqueue_* appends one pair to the context's backlog and returns; it never waits for that pair.  Calls are formed from the
  * backlog by one rule ("batch what has piled up"):
  *   - a call goes out as soon as `target` pairs of one kind (mode, memory kind, W x H, stride) wait, where target = ugsm_config.batch,
- *     except for the first `slots` calls after the queue was idle, which are staggered -- call c takes ceil(batch (c + 2) / (slots + 1))
- *     pairs (4, 5, 7, 8 for batch 8 on four slots) so that the slots do not march through the pyramid levels in phase from a drained
- *     pipe ("The queue");
+ *     except for the first `slots` calls of a burst (after ugsm_create, and after every flush), which are staggered -- call c takes
+ *     ceil(batch (c + 2) / (slots + 1)) pairs (4, 5, 7, 8 for batch 8 on four slots) so that the slots do not march through the pyramid
+ *     levels in phase from a drained pipe ("The queue");
  *   - ugsm_flush, or a blocking ugsm_next_done, declares that nothing more is coming for now: whatever waits goes out in calls of at
  *     most `target` pairs as slots come free, without waiting for a call to fill.  A host that wants every frame started at once calls
  *     ugsm_flush after every ugsm_enqueue_*: calls then hold one pair while slots are free and grow by themselves under load;

@@ -1,17 +1,18 @@
-"""Child process of tests/test_gpu_dist.py: the fovea shard's DEVICE-ORDERED exchange on one GPU.
+"""Child process of tests/test_gpu_dist.py: the fovea shard with its exchange INSIDE the library, on one GPU.
 
-Runs in a process of its own because the RCCL process group must exist before anything else touches the GPU
-(ug_stereomatcher_amd.dist.init with UGSM_FORCE_DIST=1: a ONE-RANK group over backend "nccl" == RCCL).  Three checks, each bit for bit:
+ugsm_shard_init joins a ONE-RANK RCCL communicator (the id is made by ugsm_shard_unique_id and handed round by
+ug_stereomatcher_amd.dist.exchange_shard_id over a one-rank torch.distributed "nccl" group -- the control plane bench.py uses); every
+step is ONE call, ugsm_submit_fovea_shard: pyramids -> coarse levels -> ncclBroadcast of the state on the slot's own stream -> fine levels
+of an off-centre window.  Runs in a process of its own so that a hang inside RCCL cannot take the test session with it.  Checks, bit for bit:
 
-  A  the real UgsmShardDriver through fovea_shard_step, `steps` steps dealt over two slots, an off-centre window, no host wait inside
-     a step (orders_on_device is true over nccl) -- against ugsm_submit_foveated at the same offset, and gather_stacks;
-  B  current_after_slot: the torch stream the collective is launched from reads the state only after the slot's coarse phase has
-     written it (the source rank's side of the exchange), shown by copying the state on that stream right after the call;
-  C  slot_after_current: the slot's fine phase starts only after the work enqueued on the torch stream has delivered the state (a
-     receiving rank's side): the state arrives late, behind some milliseconds of other work on that stream, and starts out as NaN.
+  A  `steps` steps dealt over two slots without any host wait inside a step, against ugsm_submit_foveated at the same offset;
+  B  ugsm_shard_count_ranks (ncclAllReduce of ones) = 1, ugsm_shard_rank = (0, 1);
+  C  ugsm_shard_gather: the consumer rank's own stack lands in d_all (one rank: the device copy; no send / receive);
+  D  call-sequence errors: a shard call on a context that has not joined (UGSM_ERR_STATE), a second ugsm_shard_init (UGSM_ERR_STATE), a
+     source rank outside the communicator (UGSM_ERR_BAD_ARG) -- all refused BEFORE any collective is enqueued;
+  E  after ugsm_shard_finalize the context works as before (ugsm_submit_foveated).
 
-B and C use a torch copy in the place of the broadcast: with one rank the collective moves nothing, so the ordering it needs would not
-show in A alone.  Prints one line "RCCL_SHARD_OK ..." on success; any failure raises.
+Prints one line "RCCL_SHARD_OK ..." on success; any failure raises.
 """
 import os
 import sys
@@ -26,7 +27,6 @@ os.environ["UGSM_FORCE_DIST"] = "1"
 
 
 def main():
-    import numpy as np
     import torch
     import torch.distributed as dist
     from ug_stereomatcher_amd import _lib, dist as ud, synth
@@ -52,92 +52,72 @@ def main():
 
     with _lib.Context(device=local_rank, levels=levels, fovea_levels=F, slots=slots) as ctx:
         lib, h = ctx.lib, ctx.handle
-        # what every step must reproduce: the one-shot foveated match at the same offset, and the coarse state on its own
-        expect, expect_state = [], []
+        # what every step must reproduce: the one-shot foveated match at the same offset
+        expect = []
         for (Lt, Rt) in pairs:
             o = torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev)
             ctx.check(lib.ugsm_submit_foveated(h, 0, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, off[0], off[1], o.data_ptr(), None, None))
             ctx.check(lib.ugsm_wait(h, 0))
             expect.append(o)
-            st = torch.empty((3, fh, fw), dtype=torch.float32, device=dev)
-            ctx.check(lib.ugsm_submit_pyramids(h, 0, Lt.data_ptr(), Rt.data_ptr(), W, H, stride))
-            ctx.check(lib.ugsm_submit_fovea_coarse(h, 0, st.data_ptr()))
-            ctx.check(lib.ugsm_wait(h, 0))
-            expect_state.append(st)
         torch.cuda.synchronize()
 
-        # ---- A: the real driver, device-ordered, no host wait inside a step -------------------------------------------------
-        drv = ud.UgsmShardDriver(ctx)
-        waits = []
-        real_wait = drv.wait
-        drv.wait = lambda slot: (waits.append(slot), real_wait(slot))[1]
-        states = [torch.full((3, fh, fw), float("nan"), dtype=torch.float32, device=dev) for _ in range(slots)]
+        # ---- D (first half): not part of a shard yet --------------------------------------------------------------------------
+        o = torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev)
+        st = lib.ugsm_submit_fovea_shard(h, 0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off[0], off[1], o.data_ptr(), 0)
+        assert st == _lib.UGSM_ERR_STATE, st
+
+        # ---- B: join, count -------------------------------------------------------------------------------------------------------
+        counted = ud.shard_init(ctx, rank, world)
+        assert counted == 1, counted
+        import ctypes as C
+        r_, w_ = C.c_int(-1), C.c_int(-1)
+        ctx.check(lib.ugsm_shard_rank(h, C.byref(r_), C.byref(w_)))
+        assert (r_.value, w_.value) == (0, 1)
+        # ---- D (second half) --------------------------------------------------------------------------------------------------------
+        ident = (C.c_char * 128)(*_lib.shard_unique_id())
+        assert lib.ugsm_shard_init(h, ident, 0, 1) == _lib.UGSM_ERR_STATE
+        st = lib.ugsm_submit_fovea_shard(h, 0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off[0], off[1], o.data_ptr(), 1)
+        assert st == _lib.UGSM_ERR_BAD_ARG, st
+        st = lib.ugsm_submit_fovea_shard(h, slots, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off[0], off[1], o.data_ptr(), 0)
+        assert st == _lib.UGSM_ERR_BAD_ARG, st
+
+        # ---- A: `steps` steps over two slots; the host never waits inside a step -----------------------------------------------
         outs = [torch.full((3, F, fh, fw), float("nan"), dtype=torch.float32, device=dev) for _ in range(slots)]
-        assert drv.orders_on_device(states[0])
         results = []
         for k in range(steps):
             s = k % slots
             if k >= slots:
-                real_wait(s)                      # the slot (and its state buffer) is free again: bench.py's submit() does the same
+                ctx.check(lib.ugsm_wait(h, s))      # the slot is free again: bench.py's loop does the same
                 results.append((k - slots, outs[s].clone()))
                 outs[s].fill_(float("nan"))
-                states[s].fill_(float("nan"))
                 torch.cuda.current_stream().synchronize()
             Lt, Rt = pairs[k % 2]
-            n_before = len(waits)
-            ud.fovea_shard_step(drv, s, Lt, Rt, W, H, stride, states[s], off, outs[s], rank)
-            assert len(waits) == n_before, "a device-ordered step must not block the host"
+            ctx.submit_fovea_shard(s, Lt.data_ptr(), Rt.data_ptr(), W, H, stride, off, outs[s].data_ptr(), 0)
         for k in range(max(0, steps - slots), steps):
-            real_wait(k % slots)
+            ctx.check(lib.ugsm_wait(h, k % slots))
             results.append((k, outs[k % slots].clone()))
         torch.cuda.synchronize()
         assert len(results) == steps
-        for k, o in results:
-            same(o, expect[k % 2], f"A: fovea_shard_step {k} (slot {k % slots}) vs ugsm_submit_foveated at offset {off}")
-        got = ud.gather_stacks(results[-1][1], 0)
-        assert got is not None and len(got) == 1
-        same(got[0], expect[(steps - 1) % 2], "A: gather_stacks")
+        for k, o_ in results:
+            same(o_, expect[k % 2], f"A: ugsm_submit_fovea_shard step {k} (slot {k % slots}) vs ugsm_submit_foveated at offset {off}")
 
-        # ---- B: current_after_slot (source side) ---------------------------------------------------------------------------------
-        side = torch.cuda.Stream()               # "the stream the collective is launched from"
-        for rep in range(3):
-            Lt, Rt = pairs[rep % 2]
-            st = states[0]
-            st.fill_(float("nan"))
-            sent = torch.full_like(st, float("nan"))
-            torch.cuda.synchronize()
-            drv.submit_pyramids(0, Lt, Rt, W, H, stride)
-            drv.submit_coarse(0, st)
-            with torch.cuda.stream(side):
-                drv.current_after_slot(0)
-                sent.copy_(st)                   # stands in for the broadcast reading the state
-            side.synchronize()
-            same(sent, expect_state[rep % 2], f"B: state read on the collective's stream after current_after_slot (rep {rep})")
-            real_wait(0)
+        # ---- C: the gather on the consumer rank ------------------------------------------------------------------------------------
+        n = 3 * F * fh * fw
+        d_all = torch.full((1, n), float("nan"), dtype=torch.float32, device=dev)
+        last = (steps - 1) % slots
+        ctx.shard_gather(last, outs[last].data_ptr(), n, d_all.data_ptr(), 0)
+        ctx.check(lib.ugsm_wait(h, last))
+        same(d_all[0].view(3, F, fh, fw), expect[(steps - 1) % 2], "C: ugsm_shard_gather")
 
-        # ---- C: slot_after_current (receiving side) ----------------------------------------------------------------------------
-        big = torch.randn((4096, 4096), device=dev)
-        for rep in range(3):
-            Lt, Rt = pairs[rep % 2]
-            st, o = states[1], outs[1]
-            st.fill_(float("nan"))
-            o.fill_(float("nan"))
-            torch.cuda.synchronize()
-            drv.submit_pyramids(1, Lt, Rt, W, H, stride)
-            with torch.cuda.stream(side):
-                drv.current_after_slot(1)
-                acc = big
-                for _ in range(6):               # some milliseconds of other work in front of the state's arrival
-                    acc = acc @ big
-                    acc = acc / acc.abs().max()
-                st.copy_(expect_state[rep % 2])  # stands in for the broadcast delivering the state
-                drv.slot_after_current(1)
-            drv.submit_fine(1, st, off, o)
-            real_wait(1)
-            side.synchronize()
-            same(o, expect[rep % 2], f"C: fine phase after slot_after_current (rep {rep})")
+        # ---- E: leave the communicator; the context is an ordinary one again ---------------------------------------------------
+        ctx.shard_finalize()
+        assert lib.ugsm_shard_rank(h, None, None) == _lib.UGSM_ERR_STATE
+        o2 = torch.empty((3, F, fh, fw), dtype=torch.float32, device=dev)
+        ctx.check(lib.ugsm_submit_foveated(h, 1, pairs[1][0].data_ptr(), pairs[1][1].data_ptr(), W, H, stride, off[0], off[1], o2.data_ptr(), None, None))
+        ctx.check(lib.ugsm_wait(h, 1))
+        same(o2, expect[1], "E: ugsm_submit_foveated after ugsm_shard_finalize")
     dist.destroy_process_group()
-    print(f"RCCL_SHARD_OK steps={steps} slots={slots} offset={off} fovea={fw}x{fh} backend=nccl world=1", flush=True)
+    print(f"RCCL_SHARD_OK steps={steps} slots={slots} offset={off} fovea={fw}x{fh} rccl_ranks={counted} exchange=inside-the-library", flush=True)
 
 
 if __name__ == "__main__":

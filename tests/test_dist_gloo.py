@@ -1,6 +1,8 @@
-"""N>1 plumbing on CPU: world_size-2 gloo process group exercising what bench.py and the
-fovea-shard mode use (pair sharding, max-over-ranks timing, the one broadcast of the coarse state,
-optional gather of the stacks).  No GPU, no compute: the kernels are covered by -m gpu tests."""
+"""N>1 plumbing on CPU: a world_size-2 gloo process group exercising bench.py's control plane (pair sharding, barrier, max-over-ranks
+timing, the hand-over of the RCCL unique id) and a MODEL of the fovea-shard protocol -- pyramids, coarse levels on the source rank, ONE
+broadcast of the coarse state, fine levels of every rank's own window -- run by the CPU oracle over gloo: it shows that the state of
+level F-1 is all a rank needs from the source, for any window.  The library's implementation of that protocol (ugsm_submit_fovea_shard:
+ncclBroadcast on the slot's stream, csrc/ugsm_shard.cpp) needs a GPU and is covered by tests/test_gpu_dist.py."""
 import os
 import socket
 import sys
@@ -32,25 +34,16 @@ def _worker(rank, world, port, out_q):
     # bench contract: duration = max over ranks; work = sum over ranks
     tmax = ud.max_over_ranks(1.0 + rank)
     total = ud.sum_over_ranks(float(len(mine)))
-    # fovea sharding: rank 0 owns the coarse state (3 x fovH x fovW), everyone receives it
-    fh, fw = 13, 17
-    state = torch.zeros((3, fh, fw), dtype=torch.float32)
-    if rank == 0:
-        state = torch.arange(3 * fh * fw, dtype=torch.float32).reshape(3, fh, fw).contiguous()
     ud.barrier()
-    ud.broadcast_coarse_state(state, 0)
-    ok_state = bool(torch.equal(state, torch.arange(3 * fh * fw, dtype=torch.float32).reshape(3, fh, fw)))
-    # rgb pair broadcast
-    L = torch.full((4, 5, 3), 7 if rank == 0 else 0, dtype=torch.uint8)
-    R = torch.full((4, 5, 3), 9 if rank == 0 else 0, dtype=torch.uint8)
-    ud.broadcast_pair(L, R, 0)
-    # gather of the per-window stacks on rank 0
-    stack = torch.full((3, 2, fh, fw), float(rank), dtype=torch.float32)
-    got = ud.gather_stacks(stack, 0)
-    ok_gather = True
-    if rank == 0:
-        ok_gather = len(got) == world and all(float(g.mean()) == float(i) for i, g in enumerate(got))
-    out_q.put((rank, mine, tmax, total, ok_state, int(L[0, 0, 0]), int(R[0, 0, 0]), ok_gather))
+    # the RCCL unique id of the library's communicator: made on rank 0 only, 128 bytes, the same on every rank afterwards
+    made = []
+
+    def make_id():
+        made.append(rank)
+        return bytes(range(128))
+    ident = ud.exchange_shard_id(make_id, rank, 0)
+    ok_id = ident == bytes(range(128)) and made == ([0] if rank == 0 else [])
+    out_q.put((rank, mine, tmax, total, ok_id))
     dist.destroy_process_group()
 
 
@@ -71,7 +64,7 @@ def test_world_size_2_gloo():
     for r in res:
         assert r[2] == 2.0          # max over ranks of (1+rank)
         assert r[3] == 11.0         # pairs processed by the whole job
-        assert r[4] and r[5] == 7 and r[6] == 9 and r[7]
+        assert r[4]                 # the shard id reached every rank, made once
 
 
 def test_single_process_helpers_are_noops():
@@ -79,8 +72,7 @@ def test_single_process_helpers_are_noops():
     from ug_stereomatcher_amd import dist as ud
     assert ud.shard_pairs(5, 0, 1) == [0, 1, 2, 3, 4]
     assert ud.max_over_ranks(3.5) == 3.5 and ud.sum_over_ranks(2.0) == 2.0
-    s = torch.ones((3, 2, 2))
-    assert ud.broadcast_coarse_state(s) is s
+    assert ud.exchange_shard_id(lambda: b"x" * 128, 0) == b"x" * 128   # (no process group: the id stays where it was made)
 
 
 def test_fovea_window_offsets():
@@ -91,56 +83,38 @@ def test_fovea_window_offsets():
     assert all(abs(x) <= 4928 // 2 and abs(y) <= 3264 // 2 for x, y in offs)
 
 
-# ---- the fovea-shard submit sequence, two ranks, two slots ---------------------------------------------
+# ---- a model of the fovea-shard protocol, two ranks, two slots ---------------------------------------------
 
-class OracleShardDriver:
-    """The four calls UgsmShardDriver makes, answered by the CPU oracle's stage functions (test double: lives in tests/).
-    Work is deferred to wait() / the next use of the slot, like the asynchronous library, so that a state buffer shared
-    between slots -- the hazard the per-slot buffers remove -- would be caught."""
+class OracleShardModel:
+    """ugsm_submit_fovea_shard's stream order -- pyramids; coarse levels on the source rank; one broadcast of the state; fine levels of this
+    rank's window -- with the CPU oracle's stage functions for the phases and a gloo broadcast for the exchange (test double: lives in
+    tests/).  The fine phase is deferred to wait() / the next use of the slot, like the asynchronous library, so that a state buffer shared
+    between slots -- the hazard the per-slot state buffers of csrc/ugsm_shard.cpp remove -- would be caught."""
 
-    def __init__(self, orc, levels, F, on_device=False):
+    def __init__(self, orc, levels, F, slots, fw, fh):
         self.orc, self.levels, self.F = orc, levels, F
         self.slot = {}
-        self.on_device = on_device  # answer of orders_on_device(): stands for "CUDA tensors over RCCL" (round 3: no host wait on the source rank)
-        self.log = []
+        self.state = [torch.zeros((3, fh, fw)) for _ in range(slots)]   # per slot, as in the library
 
-    def orders_on_device(self, state):
-        return self.on_device
-
-    def current_after_slot(self, slot):
-        self.log.append(("current_after_slot", slot))  # (the double's coarse phase has already written the state: nothing to order)
-
-    def slot_after_current(self, slot):
-        self.log.append(("slot_after_current", slot))
-
-    def submit_pyramids(self, slot, L, R, W, H, stride):
-        self.log.append(("pyramids", slot))
-        self._finish(slot)
+    def submit_fovea_shard(self, slot, L, R, W, H, off, out, rank, src=0):
+        self.wait(slot)
         o = self.orc
-        self.slot[slot] = dict(pl=o.pyramid(o.rgb_to_planes(L.numpy()), self.levels), pr=o.pyramid(o.rgb_to_planes(R.numpy()), self.levels),
-                               W=W, H=H, fine=None)
-
-    def submit_coarse(self, slot, state):
-        self.log.append(("coarse", slot))
-        o, s = self.orc, self.slot[slot]
-        top = self.levels - 1
-        cur = np.zeros_like(s["pl"][top])
-        for i in range(top, self.F - 2, -1):
-            mi = o.iterations_for_level(i)
-            cur, _ = o.iterate_level(s["pl"][i], s["pr"][i], cur, mi, o.smooth_passes_for_level(i), i == top)
-            if i > self.F - 1:
-                cur = o.seed(cur, s["pl"][i - 1].shape[2], s["pl"][i - 1].shape[1])
-        state.copy_(torch.from_numpy(cur))
+        s = self.slot[slot] = dict(pl=o.pyramid(o.rgb_to_planes(L.numpy()), self.levels), pr=o.pyramid(o.rgb_to_planes(R.numpy()), self.levels),
+                                   W=W, H=H, fine=None)
+        state = self.state[slot]
+        if rank == src:
+            top = self.levels - 1
+            cur = np.zeros_like(s["pl"][top])
+            for i in range(top, self.F - 2, -1):
+                mi = o.iterations_for_level(i)
+                cur, _ = o.iterate_level(s["pl"][i], s["pr"][i], cur, mi, o.smooth_passes_for_level(i), i == top)
+                if i > self.F - 1:
+                    cur = o.seed(cur, s["pl"][i - 1].shape[2], s["pl"][i - 1].shape[1])
+            state.copy_(torch.from_numpy(cur))
+        dist.broadcast(state, src=src)
+        s["fine"] = (state, off, out)  # reads `state` later, like the stream-ordered fine phase in the library
 
     def wait(self, slot):
-        self.log.append(("wait", slot))
-        self._finish(slot)
-
-    def submit_fine(self, slot, state, off, out):
-        self.log.append(("fine", slot))
-        self.slot[slot]["fine"] = (state, off, out)  # reads `state` later, like the stream-ordered copy in the library
-
-    def _finish(self, slot):
         s = self.slot.get(slot)
         if not s or not s["fine"]:
             return
@@ -170,57 +144,31 @@ def _shard_worker(rank, world, port, out_q):
     fw, fh, *_ = orc.fovea_geometry(W, H, levels, F)
     pairs = [tuple(torch.from_numpy(a) for a in synth.make_pair(W, H, 900 + j)[:2]) for j in range(2)]
     offsets = [(0, 0), (37, -21)]
-    ok, n_got, no_host_wait = True, 0, True
-    for on_device in (False, True):
-        drv = OracleShardDriver(orc, levels, F, on_device)
-        states = [torch.zeros((3, fh, fw)) for _ in range(slots)]
-        outs = [torch.zeros((3, F, fh, fw)) for _ in range(slots)]
-        got = []
-        for k in range(steps):  # bench.py's submit(): slot free? then the step
-            s = k % slots
-            drv.wait(s)
-            if k >= slots:
-                got.append((k - slots, outs[s].clone()))
-            L, R = pairs[k % 2]
-            mark = len(drv.log)
-            ud.fovea_shard_step(drv, s, L, R, W, H, 3 * W, states[s], offsets[rank], outs[s], rank)
-            step_log = drv.log[mark:]
-            if on_device:
-                # the step itself never waits on the host, on any rank; the source rank orders the collective after its coarse phase
-                # and every rank orders its fine phase after the collective, both on the device
-                no_host_wait = no_host_wait and all(c[0] != "wait" for c in step_log)
-                want = [("pyramids", s)] + ([("coarse", s)] if rank == 0 else []) + [("current_after_slot", s), ("slot_after_current", s), ("fine", s)]
-                no_host_wait = no_host_wait and step_log == want
-            elif rank == 0:
-                no_host_wait = no_host_wait and ("wait", s) in step_log  # (the host path: the state is complete before gloo sends it)
-        for k in range(max(steps - slots, 0), steps):
-            drv.wait(k % slots)
-            got.append((k, outs[k % slots].clone()))
-        for k, st in got:
-            L, R = pairs[k % 2]
-            exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[rank][0], offsets[rank][1])
-            ok = ok and bool((st.numpy().view(np.uint32) == exp.view(np.uint32)).all())
-        n_got += len(got)
-        # the optional gather of every rank's stack on one consumer rank
-        last = outs[(steps - 1) % slots]
-        stacks = ud.gather_stacks(last, dst=0)
-        if rank == 0:
-            L, R = pairs[(steps - 1) % 2]
-            ok = ok and stacks is not None and len(stacks) == world
-            for r in range(world):
-                exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[r][0], offsets[r][1])
-                ok = ok and bool((stacks[r].numpy().view(np.uint32) == exp.view(np.uint32)).all())
-        else:
-            ok = ok and stacks is None
-    out_q.put((rank, ok and no_host_wait, n_got))
+    ok = True
+    drv = OracleShardModel(orc, levels, F, slots, fw, fh)
+    outs = [torch.zeros((3, F, fh, fw)) for _ in range(slots)]
+    got = []
+    for k in range(steps):  # bench.py's loop: slot free? then the step
+        s = k % slots
+        drv.wait(s)
+        if k >= slots:
+            got.append((k - slots, outs[s].clone()))
+        L, R = pairs[k % 2]
+        drv.submit_fovea_shard(s, L, R, W, H, offsets[rank], outs[s], rank)
+    for k in range(max(steps - slots, 0), steps):
+        drv.wait(k % slots)
+        got.append((k, outs[k % slots].clone()))
+    for k, st in got:
+        L, R = pairs[k % 2]
+        exp, _, _ = orc.match_foveated(L.numpy(), R.numpy(), levels, F, offsets[rank][0], offsets[rank][1])
+        ok = ok and bool((st.numpy().view(np.uint32) == exp.view(np.uint32)).all())
+    out_q.put((rank, ok, len(got)))
     dist.destroy_process_group()
 
 
-def test_fovea_shard_sequence_world_size_2_two_slots():
+def test_fovea_shard_protocol_world_size_2_two_slots():
     """coarse on rank 0 -> one broadcast -> fine on every rank, three steps over two slots: rank 0's window (the centred fovea)
-    equals the one-shot foveated result bit for bit, and so does rank 1's off-centre window.  Run twice: with the host-side wait a
-    gloo broadcast needs, and with the device-side ordering the RCCL path uses (the step then never calls wait: rank 0 keeps
-    submitting); the stacks gathered on rank 0 equal each rank's own result."""
+    equals the one-shot foveated result bit for bit, and so does rank 1's off-centre window."""
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -232,4 +180,4 @@ def test_fovea_shard_sequence_world_size_2_two_slots():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, True, 6), (1, True, 6)]
+    assert res == [(0, True, 3), (1, True, 3)]

@@ -1,7 +1,8 @@
-"""The RCCL branch of the fovea shard on ONE GPU (VERDICT r03 #2b): a one-rank process group over backend "nccl" (= RCCL),
-the real UgsmShardDriver, device-side ordering between the slots' streams and the stream the collective runs on.  The work is done by
-tests/rccl_shard_child.py in a fresh process, because the process group has to be created before anything else initialises the GPU
-in that process (this pytest process has long done so)."""
+"""The fovea shard with its exchange inside the library, on ONE GPU: ugsm_shard_init over a one-rank RCCL communicator,
+ugsm_submit_fovea_shard (ncclBroadcast on the slot's own stream), ugsm_shard_count_ranks, ugsm_shard_gather, ugsm_shard_finalize.  The work
+is done by tests/rccl_shard_child.py in a fresh process: the torch.distributed group that hands the id round has to be created before
+anything else initialises the GPU in that process (this pytest process has long done so), and a hang inside RCCL must not take the
+session down.  No two-rank run is possible on the one-GPU pool; the protocol itself is rehearsed over gloo in tests/test_dist_gloo.py."""
 import os
 import subprocess
 import sys

@@ -129,7 +129,7 @@ def test_foveated_pairs_with_offsets_and_pyramid_stacks(lib, orc):
         assert [s for _, s in _calls_of(done)] == lib.queue_plan(n, slots=2, batch=4)
         for k in range(n):
             L, R = uniq[k % 2]
-            st, pl, pr = orc.match_foveated(L, R, lv, F, offs[k][0], offs[k][1])
+            st, pl, pr = orc.match_foveated(L, R, lv, F, offs[k][0], offs[k][1], want_pyr=True)
             assert_bit_equal(c.to_host(dS[k], (3, F, fh, fw)), st, f"foveated queue, pair {k} at {offs[k]}")
             if dP[k][0] is not None:
                 assert_bit_equal(c.to_host(dP[k][0], (F, 3, fh, fw)), pl, f"left pyramid stack, pair {k}")
@@ -235,7 +235,7 @@ def test_host_and_managed_memory(lib, orc):
             d = c.next_done(True)
             assert d.tag == 200 + k
             L, R = uniq[k]
-            st, pl, pr = orc.match_foveated(L, R, lv, F, off[0], off[1])
+            st, pl, pr = orc.match_foveated(L, R, lv, F, off[0], off[1], want_pyr=True)
             sh, sv, sc, gl, gr = c.managed_planes(d, [(F, fh, fw)] * 3 + [(F, 3, fh, fw)] * 2)
             assert_bit_equal(np.stack([sh, sv, sc]), st, f"managed foveated, pair {k}")
             assert_bit_equal(gl, pl, "managed left pyramid stack")

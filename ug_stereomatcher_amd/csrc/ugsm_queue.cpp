@@ -64,6 +64,7 @@ struct Queue {
     std::vector<Managed> pool;
     std::vector<int> lent;               // managed buffers the last ugsm_next_done lent to the host
     unsigned long long seq = 0, flush_upto = 0;
+    bool round_restarts = false;  // a flush has closed the burst: the next pair enqueued opens a new staggered round
     long long calls = 0, calls_since_idle = 0;
     int next_slot = 0;
     std::vector<char> slot_busy;
@@ -229,7 +230,12 @@ int pump(ugsm_ctx *ctx, Queue *q, bool may_block)
     int first_err = UGSM_OK;
     while (!q->waiting.empty()) {
         reap(ctx, q);
-        if (q->flight.empty()) q->calls_since_idle = 0;  // no call in flight: the pipe is drained, the next call opens a new staggered round
+        if (q->round_restarts && q->waiting.front().seq > q->flush_upto) {
+            // the pairs before the last flush have all gone out: what arrived after it is a new burst, staggered again (a host's flush is
+            // the one event that says "the pipe is about to drain" without depending on how fast the GPU happens to be)
+            q->round_restarts = false;
+            q->calls_since_idle = 0;
+        }
         const int target = queue_target(batch_of(cfg), cfg.slots, q->calls_since_idle);
         const Item &f = q->waiting.front();
         const int cap = (f.mem != MEM_DEVICE && f.pyr()) ? 1 : target;
@@ -546,6 +552,7 @@ int ugsm_flush(ugsm_ctx *ctx)
     Queue *q = queue_of(ctx);
     if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_flush: out of host memory");
     q->flush_upto = q->seq;
+    q->round_restarts = true;
     return pump(ctx, q, false);
 }
 
@@ -556,7 +563,10 @@ int ugsm_next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
     if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_next_done: out of host memory");
     for (int idx : q->lent) q->pool[(size_t)idx].busy = false;  // what the previous call lent comes back
     q->lent.clear();
-    if (block) q->flush_upto = q->seq;
+    if (block && q->flush_upto != q->seq) {
+        q->flush_upto = q->seq;
+        q->round_restarts = true;
+    }
     for (;;) {
         reap(ctx, q);
         (void)pump(ctx, q, false);  // (a slot may just have come free for pairs that wait)
