@@ -442,6 +442,11 @@ int ugsm_reset_kernel_stats(ugsm_ctx *ctx);
  * from a separate single-pair pass. */
 int ugsm_set_profile_events(ugsm_ctx *ctx, int mode);
 
+/* Device memory the context holds right now in its slots' buffers (pyramids, fields, staging; they grow on demand and are kept):
+ * about 1.35 GB per pair of a call and slot at 16 MP, i.e. slots x batch x 1.35 GB once every slot has run a full-size call
+ * (four slots, batch 8: 43 GB; batch 16: 86 GB of the 288).  -1 for a null context. */
+long long ugsm_context_device_bytes(const ugsm_ctx *ctx);
+
 /* Device-memory helpers so a C/C++ host (the ROS node) needs no HIP headers. */
 int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes);
 int ugsm_dev_free(ugsm_ctx *ctx, void *d_ptr);

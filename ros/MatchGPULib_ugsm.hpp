@@ -8,9 +8,11 @@
 // cv_bridge::CvImagePtr in the node; the header itself needs neither OpenCV nor ROS.
 #pragma once
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 
@@ -22,6 +24,7 @@ public:
     int foveatelevel;
     int fovH;
     int fovW;
+    int frames_in_flight = 1;  // (not in the reference) pairs the pipelined calls keep outstanding; "-inflight=N"
 
     // MatchGPULib.cpp:251-265: "-device=N" anywhere in argv, argv[2] = number of fovea levels (7)
     MatchGPULib(int argc, char **argv) : foveatedmatching(false), foveatelevel(7), fovH(0), fovW(0), ctx_(nullptr)
@@ -33,7 +36,14 @@ public:
             // not in the reference: "-lrcheck=TAU" switches the optional LR-consistency check on (ugsm_config.lr_check_threshold;
             // full mode only; off by default, and the results are the reference's only while it is off)
             if (argv[i] && std::strncmp(argv[i], "-lrcheck=", 9) == 0) cfg.lr_check_threshold = (float)std::atof(argv[i] + 9);
+            // not in the reference: "-inflight=N" sizes the context for the pipelined calls below (N pairs outstanding in the library's
+            // queue: min(N, 4) slots, ceil(N / slots) pairs per call at most); 1 = the reference's one blocking call at a time
+            if (argv[i] && std::strncmp(argv[i], "-inflight=", 10) == 0) frames_in_flight = std::atoi(argv[i] + 10);
         }
+        if (frames_in_flight < 1) frames_in_flight = 1;
+        cfg.slots = frames_in_flight < 4 ? frames_in_flight : 4;
+        cfg.batch = (frames_in_flight + cfg.slots - 1) / cfg.slots;
+        if (cfg.batch > 8) cfg.batch = 8;
         if (argc > 2) foveatelevel = std::atoi(argv[2]);
         cfg.fovea_levels = foveatelevel;
         const int st = ugsm_create(&cfg, &ctx_);
@@ -108,8 +118,62 @@ public:
         return fin;
     }
 
+    // ---- the pipelined twin of match / matchStack / matchStackPyramid (not in the reference): include/ugsm.h, "the queue" ------------
+    // The images are copied into page-locked staging memory of the library before the call returns (the cv_bridge image may be freed);
+    // the result comes out of nextDone, in arrival order.  Every call flushes: a frame starts at once if a slot is free, and under load
+    // the backlog batches itself.
+    template <class ImgPtr>
+    int enqueueMatch(ImgPtr L, ImgPtr R, uint64_t tag)
+    {
+        const int W = L->image.cols, H = L->image.rows;
+        if (R->image.cols != W || R->image.rows != H) return UGSM_ERR_SIZE_MISMATCH;
+        int st = ugsm_enqueue_full_managed(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, tag);
+        if (st == UGSM_OK) { kinds_[tag] = Kind{false, false, W, H}; st = ugsm_flush(ctx_); }
+        return report(st);
+    }
+    template <class ImgPtr>
+    int enqueueStack(ImgPtr L, ImgPtr R, bool want_pyramids, uint64_t tag)
+    {
+        const int W = L->image.cols, H = L->image.rows;
+        if (R->image.cols != W || R->image.rows != H) return UGSM_ERR_SIZE_MISMATCH;
+        if (ugsm_fovea_dims(W, H, 14, foveatelevel, &fovW, &fovH) != UGSM_OK) return UGSM_ERR_BAD_ARG;
+        int st = ugsm_enqueue_foveated_managed(ctx_, L->image.data, R->image.data, W, H, (int)L->image.step, 0, 0, want_pyramids ? 1 : 0, tag);
+        if (st == UGSM_OK) { kinds_[tag] = Kind{true, want_pyramids, W, H}; st = ugsm_flush(ctx_); }
+        return report(st);
+    }
+    int outstanding() const { return (int)kinds_.size(); }
+    // What nextDone hands out.  planes: full mode dispH, dispV, dispC (rows x cols); foveated stackH, stackV, stackC ((levels fovH) x fovW,
+    // finest level first -- the layout the node publishes, UG_GPU_matcher.cpp:293-320) and, if asked for, the L / R pyramid stacks
+    // ((levels 3 fovH) x fovW, :203-226).  The planes belong to the library and stay valid until the next nextDone.
+    struct Done {
+        uint64_t tag;
+        bool foveated, pyramids;
+        int rows, cols;  // of the image
+        float *planes[5];
+    };
+    // true: *out filled.  false: nothing outstanding, or (block == false) the oldest pair has not finished, or its call failed (stderr).
+    bool nextDone(bool block, Done *out)
+    {
+        ugsm_completion c;
+        const int st = ugsm_next_done(ctx_, &c, block ? 1 : 0);
+        if (st != UGSM_OK) { if (st != UGSM_PENDING && st != UGSM_EMPTY) report(st); return false; }
+        const Kind k = kinds_[c.tag];
+        kinds_.erase(c.tag);
+        if (c.status != UGSM_OK) { report(c.status); return false; }
+        out->tag = c.tag; out->foveated = k.foveated; out->pyramids = k.pyramids; out->rows = k.H; out->cols = k.W;
+        for (int i = 0; i < 5; i++) out->planes[i] = c.result[i];
+        return true;
+    }
+
 private:
     ugsm_ctx *ctx_;
+    struct Kind { bool foveated, pyramids; int W, H; };
+    std::map<uint64_t, Kind> kinds_;
+    int report(int st)
+    {
+        if (st != UGSM_OK) std::fprintf(stderr, "ugsm: %s: %s\n", ugsm_status_string(st), ugsm_last_error(ctx_));
+        return st;
+    }
 
     static float **alloc_planes(int n, size_t px)
     {

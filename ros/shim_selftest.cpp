@@ -40,6 +40,33 @@ int main(int argc, char **argv)
         for (int c = 0; c < 3; c++) { free(full[c]); free(one[c]); }
         free(full);
         free(one);
+        // the pipelined calls ("-inflight=3"): five frames enqueued, results in arrival order, equal to the blocking calls
+        {
+            char *av2[] = {(char *)"node", (char *)"x", (char *)"3", (char *)"-inflight=3"};
+            MatchGPULib p(4, av2);
+            float **blocking = p.match(L, R, 0);
+            if (!blocking) return 4;
+            size_t bad = 0, got = 0;
+            uint64_t expect_tag = 0;
+            MatchGPULib::Done d;
+            auto check = [&](const MatchGPULib::Done &dn) {
+                bad += dn.tag != expect_tag++;
+                if (!dn.foveated) for (int c = 0; c < 3; c++) bad += std::memcmp(dn.planes[c], blocking[c], sizeof(float) * W * H) != 0;
+                else for (int k = 0; k < p.getFoveateLevel(); k++)
+                    for (int c = 0; c < 3; c++)
+                        bad += std::memcmp(dn.planes[c] + (size_t)k * p.getFoveaWidth() * p.getFoveaHeight(), st[k][c], sizeof(float) * p.getFoveaWidth() * p.getFoveaHeight()) != 0;
+                got++;
+            };
+            for (uint64_t t = 0; t < 5; t++) {
+                if ((t & 1 ? p.enqueueStack(L, R, false, t) : p.enqueueMatch(L, R, t)) != UGSM_OK) return 5;
+                while (p.outstanding() >= p.frames_in_flight) { if (!p.nextDone(true, &d)) return 6; check(d); }
+            }
+            while (p.outstanding() > 0) { if (!p.nextDone(true, &d)) return 7; check(d); }
+            std::printf("pipelined (3 in flight) vs blocking: %zu frames, %s\n", got, bad ? "DIFFER" : "identical");
+            for (int c = 0; c < 3; c++) free(blocking[c]);
+            free(blocking);
+            if (bad || got != 5) return 8;
+        }
         for (int k = 0; k < m.getFoveateLevel(); k++) { for (int i = 0; i < 3; i++) free(st[k][i]); free(st[k]); }
         free(st);
     } catch (const std::exception &e) {

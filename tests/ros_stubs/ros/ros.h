@@ -8,9 +8,12 @@
 namespace ros {
 struct Publisher { template <class M> void publish(const M &) const; };
 struct ServiceServer {};
-struct WallDuration { double toSec() const; };
+struct WallDuration { WallDuration(); explicit WallDuration(double s); double toSec() const; };
 struct WallTime { static WallTime now(); WallDuration operator-(const WallTime &) const; };
+struct WallTimerEvent {};
+struct WallTimer {};
 struct NodeHandle {
+    template <class T> WallTimer createWallTimer(WallDuration period, void (T::*)(const WallTimerEvent &), T *obj);
     template <class M> Publisher advertise(const std::string &topic, unsigned queue);
     template <class T, class Req, class Res> ServiceServer advertiseService(const std::string &name, bool (T::*)(Req &, Res &), T *obj);
     bool getParam(const std::string &key, int &v) const;

@@ -28,6 +28,15 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
     assert lib.load().ugsm_abi_version() == 5
     assert lib.load().ugsm_is_dev_library() == 0
+    # ... and NOTHING else (-fvisibility=hidden + csrc/ugsm.map): no ugsm::launch_*, no __device_stub__*, no kernel handles
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm:
+        for path, extra in ((lib.LIB_PATH, []), (lib.DEV_LIB_PATH, lib.DEV_EXPORTS)):
+            out = subprocess.run([nm, "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+            names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+            assert names == sorted(declared + extra), sorted(set(names) ^ set(declared + extra))
 
 
 def test_dev_header_symbols_are_exported_by_the_dev_library_only(lib):

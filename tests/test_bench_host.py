@@ -1,5 +1,6 @@
-"""bench.py's host logic without a GPU: how a region's pairs are dealt into calls (plan_calls) and which interval of completions counts as
-steady state (steady_window)."""
+"""Host logic without a GPU: how the LIBRARY's queue deals a burst of pairs into calls (ugsm_queue_plan, include/ugsm.h -- the rule
+bench.py's plan_calls had in rounds 3-4, now behind the C-ABI) and which interval of completions bench.py counts as steady state
+(steady_window: analysis of the calls the library formed, no planning)."""
 import os
 import sys
 
@@ -8,34 +9,52 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-def test_plan_calls_batches_the_backlog_and_staggers_the_start():
-    for n in (1, 5, 20, 96, 384, 385, 1000):
+def _plan(n, slots, B):
+    import __graft_entry__ as ge
+    ge.build_library()
+    from ug_stereomatcher_amd import _lib
+    return _lib.queue_plan(n, slots=slots, batch=B)
+
+
+def test_bench_holds_no_call_planning():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "def plan_calls" not in src
+    timed_loop = src.split("    def run(n):")[1].split("    def call_sizes_of(")[0]      # the body of the timed region
+    assert "ctx.enqueue_full(" in timed_loop and "ctx.flush()" in timed_loop and "fetch(" in timed_loop
+    assert "submit_full" not in timed_loop and "% slots" not in timed_loop.split('if mode == "fovea-shard":')[0] + timed_loop.split("return\n", 1)[1]
+
+
+def test_queue_plan_batches_the_backlog_and_staggers_the_start():
+    for n in (0, 1, 5, 20, 96, 384, 385, 1000):
         for slots in (1, 2, 4):
             for B in (1, 2, 4, 8, 16):
-                for taper in (0.0, 0.5, 1.0):
-                    sizes = bench.plan_calls(n, slots, B, taper)
-                    assert sum(sizes) == n and all(1 <= v <= B for v in sizes), (n, slots, B, taper, sizes)
-    assert bench.plan_calls(20, 4, 1) == [1] * 20                      # single-pair calls: rounds 1-3
-    assert bench.plan_calls(20, 4, 4) == [2, 3, 4, 4, 4, 3]            # the driver's protocol: staggered start, full-size calls, the rest in one
-    s = bench.plan_calls(384, 4, 4)
+                sizes = _plan(n, slots, B)
+                assert sum(sizes) == n and all(1 <= v <= B for v in sizes), (n, slots, B, sizes)
+    assert _plan(20, 4, 1) == [1] * 20                      # single-pair calls: rounds 1-3
+    assert _plan(20, 4, 4) == [2, 3, 4, 4, 4, 3]            # staggered start, full-size calls, the rest in one
+    assert _plan(20, 4, 8) == [4, 5, 7, 4]                  # the driver's protocol with bench.py's default batch
+    s = _plan(384, 4, 4)
     assert s[:6] == [2, 3, 4, 4, 4, 4] and set(s[4:-1]) == {4} and s[-1] == 3   # batches while a backlog exists
-    assert bench.plan_calls(20, 4, 4, taper=1.0) == [2, 3, 3, 3, 2, 1, 1, 1, 1, 1, 1, 1]   # (the tapered end of the round's first half, kept for A/Bs)
-    t = bench.plan_calls(384, 4, 4, taper=1.0)[-20:]
-    assert t == sorted(t, reverse=True) and t[-1] == 1
-    assert bench.plan_calls(10, 4, 8, head=[8, 8, 8, 8]) == [8, 2] and bench.plan_calls(10, 4, 8) == [4, 5, 1]
+    assert _plan(10, 4, 8) == [4, 5, 1] and _plan(5, 1, 8) == [5]
+    # bad arguments are an answer, not a crash
+    import ctypes as C
+    from ug_stereomatcher_amd import _lib
+    assert _lib.load().ugsm_queue_plan(None, -1, None, 0) == -1
+    assert _lib.load().ugsm_queue_plan(None, 3, None, 0) == 3        # (count only; default config: one slot, batch 1)
+    buf = (C.c_int * 2)()
+    assert _lib.load().ugsm_queue_plan(None, 3, buf, 2) == 3 and list(buf) == [1, 1]
 
 
 def test_steady_window():
-    assert bench.steady_window(bench.plan_calls(20, 4, 4), 4) is None           # 20 steps have no middle
-    assert bench.steady_window(bench.plan_calls(20, 4, 1), 4) == (4, 15)        # single pairs: completions slots+1 .. steps-slots
-    for taper in (0.0, 1.0):
-        s = bench.plan_calls(384, 4, 4, taper)
-        lo, hi = bench.steady_window(s, 4)
-        first = next(j for j in range(4, len(s)) if all(v == 4 for v in s[j:j + 5]))
-        assert lo == sum(s[:first + 1]) - 1 and lo < hi < 384
-        # every call between the two ends, and the `slots` calls behind the last one, is full-size
-        j_hi = next(j for j in range(len(s)) if sum(s[:j + 1]) - 1 == hi)
-        assert all(v == 4 for v in s[first:j_hi + 5]) and s[j_hi + 5] < 4
+    assert bench.steady_window(_plan(20, 4, 4), 4) is None           # 20 steps have no middle
+    assert bench.steady_window(_plan(20, 4, 1), 4) == (4, 15)        # single pairs: completions slots+1 .. steps-slots
+    s = _plan(384, 4, 4)
+    lo, hi = bench.steady_window(s, 4)
+    first = next(j for j in range(4, len(s)) if all(v == 4 for v in s[j:j + 5]))
+    assert lo == sum(s[:first + 1]) - 1 and lo < hi < 384
+    # every call between the two ends, and the `slots` calls behind the last one, is full-size
+    j_hi = next(j for j in range(len(s)) if sum(s[:j + 1]) - 1 == hi)
+    assert all(v == 4 for v in s[first:j_hi + 5]) and s[j_hi + 5] < 4
     assert bench.steady_window([], 4) is None and bench.steady_window([4] * 7, 4) is None
 
 
@@ -45,5 +64,5 @@ def test_the_further_region_of_a_short_run_always_has_a_middle():
         for B in (1, 2, 4, 8, 16):
             for steps in (1, 5, 20):
                 n = max(steps, 48 * B, 12 * slots * B)
-                win = bench.steady_window(bench.plan_calls(n, slots, B), slots)
+                win = bench.steady_window(_plan(n, slots, B), slots)
                 assert win is not None and win[1] - win[0] >= 8 * B, (slots, B, steps, win)

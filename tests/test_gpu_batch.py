@@ -226,9 +226,10 @@ def test_batch_bad_arguments(lib):
 
 
 def test_16mp_batches_vs_single_calls(lib):
-    """BASELINE configs[2] / configs[4] at full size: a batch of two 16 MP pairs in full mode (levels 0-2 pair by pair, 3-13 as one
-    launch for both) and a batch of eight foveated 16 MP pairs with eight different windows, against the single calls on the same context
-    (which tests/test_gpu_parity.py pins to the oracle at this size)."""
+    """BASELINE configs[2] / configs[4] at full size: a batch of two 16 MP pairs in full mode (level 0 pair by pair, levels 1-13 -- every
+    level of at most 9 Mpx -- as one launch for both) and a batch of eight foveated 16 MP pairs with eight different windows, against the
+    single calls on the same context (which tests/test_gpu_parity.py pins to the oracle at this size; full-mode calls of 4 / 5 / 7 / 8 / 16
+    pairs meet the oracle directly in tests/test_gpu_queue.py and test_the_largest_documented_context_at_16mp)."""
     from ug_stereomatcher_amd import synth
     W, H, F = 4928, 3264, 7
     fw, fh = lib.fovea_dims(W, H, 14, F)
@@ -368,3 +369,75 @@ def test_batches_from_page_locked_host_memory(lib, orc):
         bad = (C.c_void_p * B)(*[pageable[0].ctypes.data] * B)
         good = lambda arrs: (C.c_void_p * B)(*[a.ctypes.data for a in arrs])
         assert c.lib.ugsm_submit_full_batch_host(c.handle, 0, B, good(hL[:B]), good(hR[:B]), W, H, 3 * W, bad, bad, bad) == lib.UGSM_ERR_BAD_ARG
+
+
+def test_out_of_device_memory_is_a_status_code_and_the_context_lives_on(lib, orc, monkeypatch):
+    """UGSM_ERR_NOMEM, cleanly: the development limit UGSM_MEM_LIMIT_MB makes the slots' allocator refuse to grow past it --
+    the same branch a failed hipMalloc takes, without exhausting a GPU.  A call whose buffers do not fit answers UGSM_ERR_NOMEM with a
+    message, holds no half-grown buffer afterwards, and the context goes on serving calls that fit, bit for bit."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv = 640, 480, 12
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 8100)
+    exp = orc.match_full(L, R, lv)
+    monkeypatch.setenv("UGSM_MEM_LIMIT_MB", "60")        # one 640 x 480 pair needs ~26 MB of slot buffers, a batch of four ~100 MB
+    with lib.Context(levels=lv, slots=1, batch=1) as c:
+        dL, dR = c.to_device(L), c.to_device(R)
+        outs = [c.alloc(3 * W * H * 4) for _ in range(4)]
+        assert c.device_bytes() == 0
+        c.check(c.lib.ugsm_submit_full(c.handle, 0, dL, dR, W, H, 3 * W, outs[0]))
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        assert_bit_equal(c.to_host(outs[0], (3, H, W)), exp, "a call that fits")
+        held = c.device_bytes()
+        assert 20e6 < held < 60e6, held
+        import ctypes as C
+        ptrs = lambda ps: (C.c_void_p * len(ps))(*ps)   # noqa: E731
+        st = c.lib.ugsm_submit_full_batch(c.handle, 0, 4, ptrs([dL] * 4), ptrs([dR] * 4), W, H, 3 * W, ptrs(outs))
+        assert st == lib.UGSM_ERR_NOMEM, st
+        assert b"hipMalloc" in c.lib.ugsm_last_error(c.handle)
+        assert c.device_bytes() <= held          # nothing half-grown is kept
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        c.check(c.lib.ugsm_submit_full(c.handle, 0, dL, dR, W, H, 3 * W, outs[1]))   # ... and the context still works
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        assert_bit_equal(c.to_host(outs[1], (3, H, W)), exp, "a call that fits, after the refused one")
+        # the queue reports the failure of a call through its pairs' completions
+        comp = lib.Completion()
+        for k in range(4):
+            c.lib.ugsm_enqueue_full(c.handle, dL, dR, W, H, 3 * W, outs[k], k)
+        c.lib.ugsm_flush(c.handle)
+        sts = []
+        while c.lib.ugsm_next_done(c.handle, C.byref(comp), 1) == lib.UGSM_OK:
+            sts.append(comp.status)
+        assert sts == [0, 0, 0, 0]                # (batch 1: four single calls, which fit)
+        for p in [dL, dR] + outs:
+            c.free(p)
+
+
+def test_the_largest_documented_context_at_16mp(lib, oracle_16mp, oracle_16mp_b):
+    """INTEGRATION.md section 5's upper end: four slots, batch 16, 16 MP -- 64 pairs in flight, ~86 GB of slot buffers.  One
+    call of sixteen on every slot, all four in flight; a sample of the results against the live oracle, all of them against each other."""
+    W, H = oracle_16mp["W"], oracle_16mp["H"]
+    imgs = [oracle_16mp, oracle_16mp_b]
+    slots, B = 4, 16
+    with lib.Context(levels=14, slots=slots, batch=B) as c:
+        dL = [c.to_device(g["L"]) for g in imgs]
+        dR = [c.to_device(g["R"]) for g in imgs]
+        outs = [[c.alloc(3 * W * H * 4) for _ in range(B)] for _ in range(slots)]
+        sel = [(b + s) % 2 for s in range(slots) for b in range(B)]
+        for s in range(slots):
+            idx = sel[s * B:(s + 1) * B]
+            c.submit_full_batch(s, [dL[j] for j in idx], [dR[j] for j in idx], W, H, 3 * W, outs[s])
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        held = c.device_bytes()
+        assert 70e9 < held < 110e9, held          # slots x batch x ~1.35 GB
+        ref = [None, None]
+        for s in range(slots):
+            for b in range(B):
+                j = sel[s * B + b]
+                a = c.to_host(outs[s][b], (3, H, W))
+                if ref[j] is None:
+                    assert_bit_equal(a, imgs[j]["full"], f"16 MP, slot {s}, pair {b} of a call of sixteen vs oracle")
+                    ref[j] = a
+                else:
+                    assert (a.view(np.uint32) == ref[j].view(np.uint32)).all(), f"16 MP, slot {s}, pair {b} of a call of sixteen differs from its image's result"
+        for p in dL + dR + [q for o in outs for q in o]:
+            c.free(p)

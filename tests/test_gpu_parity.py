@@ -500,6 +500,7 @@ def test_cpp_shim_of_matchgpulib_compiles_and_runs(lib, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fovea 159x119 levels 3" in out.stdout and "stack[0][0][centre]" in out.stdout
     assert "hierarchicalDisparity vs match(fov=1): identical" in out.stdout, out.stdout
+    assert "pipelined (3 in flight) vs blocking: 5 frames, identical" in out.stdout, out.stdout   # enqueueMatch / enqueueStack / nextDone
 
 
 def test_exact_shortcuts_of_the_fused_kernels(lib, orc):

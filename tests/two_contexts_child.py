@@ -1,8 +1,14 @@
 """Child process of tests/test_gpu_batch.py::test_two_contexts_in_one_process_with_stream_priority_pools: two contexts of four slots in one
-(fresh) process, in different stream-priority pools, each at the rate a context alone reaches; a context at the process default priority
-for comparison.  Prints the rates and "TWO_CONTEXTS_OK"; any failure raises."""
+(fresh) process, in different stream-priority pools.
+
+ASSERTED: results do not depend on any of it -- every context's result equals the first one's bit for bit, including while the two
+contexts submit SIDE BY SIDE from two host threads (each context is driven by one thread, the serialisation the header asks for).
+REPORTED, not asserted (which hardware queue a stream lands on is undocumented HIP behaviour, and a
+rate depends on the box): pairs/s of a context alone, of each of two contexts run one after the other, of the two run together
+(their sum), and of a context at the process default priority.  Prints the rates and "TWO_CONTEXTS_OK"; any failure raises."""
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -15,18 +21,20 @@ W, H, lv, slots, n = 4928, 3264, 14, 4, 32   # (16 MP: bound by the GPU, not by 
 L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 77)
 
 
+def run(c, o, dL, dR, k):
+    for i in range(k):
+        s = i % slots
+        c.check(c.lib.ugsm_wait(c.handle, s))
+        c.check(c.lib.ugsm_submit_full(c.handle, s, dL, dR, W, H, 3 * W, o[s]))
+    c.check(c.lib.ugsm_wait_all(c.handle))
+
+
 def rate(c, o, dL, dR):
-    def run(k):
-        for i in range(k):
-            s = i % slots
-            c.check(c.lib.ugsm_wait(c.handle, s))
-            c.check(c.lib.ugsm_submit_full(c.handle, s, dL, dR, W, H, 3 * W, o[s]))
-        c.check(c.lib.ugsm_wait_all(c.handle))
-    run(2 * slots)
+    run(c, o, dL, dR, 2 * slots)
     best = 0.0
     for _ in range(3):
         t0 = time.perf_counter()
-        run(n)
+        run(c, o, dL, dR, n)
         best = max(best, n / (time.perf_counter() - t0))
     return best
 
@@ -44,12 +52,30 @@ with lib.Context(levels=lv, slots=slots) as a:
         rb = rate(b, outs[slots:], dL, dR)
         ra = rate(a, outs[:slots], dL, dR)
         assert same(b.to_host(outs[slots], (3, H, W)), ref), "results do not depend on the stream priorities"
+        # side by side: one host thread per context (ctypes releases the GIL inside the library calls)
+        errs = []
+
+        def drive(c, o):
+            try:
+                run(c, o, dL, dR, n)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        ta, tb = threading.Thread(target=drive, args=(a, outs[:slots])), threading.Thread(target=drive, args=(b, outs[slots:]))
+        t0 = time.perf_counter()
+        ta.start()
+        tb.start()
+        ta.join()
+        tb.join()
+        both = 2 * n / (time.perf_counter() - t0)
+        assert not errs, errs
+        for k in range(2 * slots):
+            assert same(a.to_host(outs[k], (3, H, W)), ref), f"two contexts submitting side by side: buffer {k} differs"
     with lib.Context(levels=lv, slots=slots, stream_priority=1) as d:       # the opt-out: the process default priority
         rd = rate(d, outs[slots:], dL, dR)
         assert same(d.to_host(outs[slots], (3, H, W)), ref), "results do not depend on the stream priorities"
     for p in [dL, dR] + outs:
         a.free(p)
-print(f"pairs/s at 16 MP, four slots: context alone {alone:.0f}; second context in the least-priority pool {rb:.0f}, the first again {ra:.0f}; "
-      f"a context at the process default priority (beside the null stream) {rd:.0f}")
-assert rb >= 0.85 * alone and ra >= 0.85 * alone, (alone, rb, ra)
+print(f"pairs/s at 16 MP, four slots (reported, not asserted): context alone {alone:.0f}; second context in the least-priority pool {rb:.0f}, "
+      f"the first again {ra:.0f}; the two submitting side by side from two threads {both:.0f} in sum; a context at the process default "
+      f"priority (beside the null stream) {rd:.0f}")
 print("TWO_CONTEXTS_OK")

@@ -48,7 +48,7 @@ EXPORTS = [
     "ugsm_enqueue_foveated_managed", "ugsm_flush", "ugsm_next_done", "ugsm_queue_depth", "ugsm_queue_plan",
     # ... and RCCL inside the library
     "ugsm_shard_unique_id", "ugsm_shard_init", "ugsm_shard_init_all", "ugsm_shard_rank", "ugsm_shard_count_ranks", "ugsm_submit_fovea_shard",
-    "ugsm_shard_gather", "ugsm_shard_finalize",
+    "ugsm_shard_gather", "ugsm_shard_finalize", "ugsm_context_device_bytes",
 ]
 # ... and what include/ugsm_dev.h adds (libugsm_dev.so only)
 DEV_EXPORTS = ["ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div_probe"]
@@ -183,6 +183,8 @@ def load(dev: bool = False):
     lib.ugsm_copy_to_host.argtypes = [vp, vp, vp, C.c_longlong]
     u64 = C.c_uint64
     lib.ugsm_poll.argtypes = [vp, i]
+    lib.ugsm_context_device_bytes.argtypes = [vp]
+    lib.ugsm_context_device_bytes.restype = C.c_longlong
     lib.ugsm_enqueue_full.argtypes = [vp, vp, vp, i, i, i, vp, u64]
     lib.ugsm_enqueue_foveated.argtypes = [vp, vp, vp, i, i, i, i, i, vp, vp, vp, u64]
     lib.ugsm_enqueue_full_host.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, u64]
@@ -482,6 +484,9 @@ class Context:
 
     def shard_finalize(self):
         self.check(self.lib.ugsm_shard_finalize(self._h))
+
+    def device_bytes(self) -> int:
+        return int(self.lib.ugsm_context_device_bytes(self._h))
 
     def kernel_stats(self):
         """One dict per (kernel, pyramid level) with harvested launches; level -1 = not tied to a level."""

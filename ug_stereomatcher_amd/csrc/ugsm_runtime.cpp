@@ -28,6 +28,7 @@
 #include <string>
 #include <system_error>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace ugsm;
@@ -201,6 +202,10 @@ struct ugsm_ctx {
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
     long long batch_max_px = 0;  // development override of kBatchMaxPixels (batch_level): levels up to this size go through a batched call as one launch; < 0 = none
     CtxHooks hooks;  // the queue (ugsm_queue.cpp) and the RCCL shard (ugsm_shard.cpp): layers over the slot API
+    long long dev_bytes = 0;    // device memory held by the slots' growable buffers (grow); ugsm_context_device_bytes
+    std::unordered_map<const void *, size_t> dev_allocs;  // ... buffer by buffer, so that every release is accounted whatever path it takes
+    bool counted_live = false;  // this context counts in g_live_contexts (ugsm_create got as far as handing it out)
+    long long mem_limit = 0;    // development (UGSM_MEM_LIMIT_MB under UGSM_DEV=1): grow refuses to go past it -- the UGSM_ERR_NOMEM path without exhausting a GPU
 };
 
 namespace ugsm {
@@ -304,20 +309,37 @@ void fovea_geometry(const int *w, const int *h, int F, int off_x, int off_y, Fov
 
 // ---- buffers ---------------------------------------------------------------------------
 
+void untrack(ugsm_ctx *ctx, const void *p)
+{
+    auto it = ctx->dev_allocs.find(p);
+    if (it == ctx->dev_allocs.end()) return;
+    ctx->dev_bytes -= (long long)it->second;
+    ctx->dev_allocs.erase(it);
+}
+
 template <class T>
 int grow(ugsm_ctx *ctx, T *&p, size_t &cap, size_t need)
 {
     if (need <= cap) return UGSM_OK;
-    if (p) HIPCHK(ctx, hipFree(p));
+    if (p) {
+        untrack(ctx, p);
+        HIPCHK(ctx, hipFree(p));
+    }
     p = nullptr;
     cap = 0;
-    hipError_t e = hipMalloc((void **)&p, need * sizeof(T));
+    hipError_t e = (ctx->mem_limit > 0 && ctx->dev_bytes + (long long)(need * sizeof(T)) > ctx->mem_limit) ? hipErrorOutOfMemory
+                                                                                                          : hipMalloc((void **)&p, need * sizeof(T));
     if (e != hipSuccess) {
-        ctx->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        (void)hipGetLastError();  // (the failed allocation must not poison the next launch check)
+        char b[256];
+        snprintf(b, sizeof b, "hipMalloc of %zu bytes failed: %s (the context holds %lld bytes)", need * sizeof(T), hipGetErrorString(e), ctx->dev_bytes);
+        ctx->err = b;
         p = nullptr;
         return UGSM_ERR_NOMEM;
     }
     cap = need;
+    ctx->dev_bytes += (long long)(need * sizeof(T));
+    ctx->dev_allocs[p] = need * sizeof(T);
     return UGSM_OK;
 }
 
@@ -339,7 +361,10 @@ int ensure_level_bufs(ugsm_ctx *ctx, Slot &s, size_t lvl)
     }
     if (st != UGSM_OK) {
         for (int k = 0; k < nb; k++) {
-            if (*bufs[k]) (void)hipFree(*bufs[k]);
+            if (*bufs[k]) {
+                untrack(ctx, *bufs[k]);
+                (void)hipFree(*bufs[k]);
+            }
             *bufs[k] = nullptr;
         }
         return st;
@@ -379,9 +404,22 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
     const int cap_pairs = std::max(nb, std::min(std::max(ctx->cfg.batch, 1), kMaxBatch));
     const size_t pyr_need = cap_pairs > 1 ? s.pyr_stride * cap_pairs : tot;
     if (pyr_need > s.pyr_cap) {
-        size_t cap = s.pyr_cap;
-        UCHK(grow(ctx, s.pyrL, cap, pyr_need));
-        UCHK(grow(ctx, s.pyrR, s.pyr_cap, pyr_need));
+        // both or neither: a failure leaves the slot without pyramids and the capacity at zero (never a capacity one of them lacks)
+        size_t capL = s.pyr_cap, capR = s.pyr_cap;
+        s.pyr_cap = 0;
+        int st = grow(ctx, s.pyrL, capL, pyr_need);
+        if (st == UGSM_OK) st = grow(ctx, s.pyrR, capR, pyr_need);
+        if (st != UGSM_OK) {
+            for (float **b : {&s.pyrL, &s.pyrR}) {
+                if (*b) {
+                    untrack(ctx, *b);
+                    (void)hipFree(*b);
+                }
+                *b = nullptr;
+            }
+            return st;
+        }
+        s.pyr_cap = pyr_need;
     }
     UCHK(ensure_level_bufs(ctx, s, cap_pairs > 1 ? s.lvl_stride * cap_pairs : lvl));
     return UGSM_OK;
@@ -470,8 +508,12 @@ bool dev_env_on()
     const char *e = getenv("UGSM_DEV");
     return e && e[0] == '1';
 }
-// set_globals: also apply the two process-wide tuning variables (UGSM_SMOOTH_MID_MIN, UGSM_MARCH_AGE).  ugsm_create does; the host-only
-// ugsm_plan_level does not, so that asking for a plan never changes the kernels of live contexts.
+// set_globals: also apply the process-wide tuning variables (UGSM_SMOOTH_MID_MIN, UGSM_PYR_STREAM*, UGSM_MARCH_AGE).  They are CREATE-TIME,
+// PROCESS-WIDE settings: ugsm_create applies them only while no other context of the process is alive (g_live_contexts, under
+// g_globals_mutex), so that creating a second context never changes the kernels of a live one, from whatever thread; the
+// host-only ugsm_plan_level never does.
+std::mutex g_globals_mutex;
+int g_live_contexts = 0;
 void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
 {
     if (!dev_env_on()) return;
@@ -1471,7 +1513,10 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     if (cfg_in) cfg = *cfg_in;
     else ugsm_default_config(&cfg);
     DevKnobs knobs;
-    apply_dev_env(cfg, knobs, true);  // (nothing unless UGSM_DEV=1)
+    {
+        std::lock_guard<std::mutex> lk(g_globals_mutex);
+        apply_dev_env(cfg, knobs, g_live_contexts == 0);  // (nothing unless UGSM_DEV=1)
+    }
     {   // the kernels carry the Gaussian taps as literals (ugsm_device.hpp); they must be the numbers the reference computes at
         // start-up: five float literals divided by their float sum (MatchGPULib.cpp:761-774)
         const float lit[5] = {0.0816475f, 0.218507f, 0.303281f, 0.218507f, 0.0816475f};
@@ -1494,6 +1539,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ugsm_ctx *ctx = new ugsm_ctx();
     ctx->cfg = cfg;
     set_policy(ctx, knobs);
+    if (dev_env_on() && getenv("UGSM_MEM_LIMIT_MB")) ctx->mem_limit = atoll(getenv("UGSM_MEM_LIMIT_MB")) << 20;
     // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
     // beside the left pyramid and the coarse levels).  With four pairs in flight it LOSES 13 % (136 against 157 pairs/s): eight
     // streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So: one-slot contexts only.
@@ -1532,6 +1578,11 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
             return UGSM_ERR_DEVICE;
         }
     }
+    {
+        std::lock_guard<std::mutex> lk(g_globals_mutex);
+        g_live_contexts++;
+        ctx->counted_live = true;
+    }
     *out = ctx;
     return UGSM_OK;
 }
@@ -1539,6 +1590,10 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
 void ugsm_destroy(ugsm_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->counted_live) {
+        std::lock_guard<std::mutex> lk(g_globals_mutex);
+        g_live_contexts--;
+    }
     (void)hipSetDevice(ctx->cfg.device);
     for (Slot &s : ctx->slots) {  // (the layers' state refers to work on the slots' streams: drain them first)
         if (s.st) (void)hipStreamSynchronize(s.st);
@@ -2335,6 +2390,8 @@ int ugsm_set_profile_events(ugsm_ctx *ctx, int mode)
     ctx->cfg.profile_events = mode;
     return UGSM_OK;
 }
+
+long long ugsm_context_device_bytes(const ugsm_ctx *ctx) { return ctx ? ctx->dev_bytes : -1; }
 
 int ugsm_dev_alloc(ugsm_ctx *ctx, void **d_ptr, long long bytes)
 {

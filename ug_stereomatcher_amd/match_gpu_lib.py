@@ -48,14 +48,20 @@ def _as_rgb8(img) -> np.ndarray:
 class MatchGPULib:
     MAX_LEVEL = 14  # MatchLib_common.h:13
 
-    def __init__(self, argc: int = 0, argv=None, *, levels: int = MAX_LEVEL, kernel_path: int = 0):
+    def __init__(self, argc: int = 0, argv=None, *, levels: int = MAX_LEVEL, kernel_path: int = 0, frames_in_flight: int = 1):
+        """frames_in_flight > 1 (not in the reference): the context gets min(frames_in_flight, 4) slots and the pipelined calls below
+        (enqueueMatch / enqueueStack / nextDone) keep that many pairs outstanding in the library's queue; the blocking calls are unchanged."""
         device, fl = _parse_argv(argv if argc else None)
         self.foveatedmatching = 0
         self.foveatelevel = fl
         self.fovH = 0
         self.fovW = 0
         self._levels = levels
-        self._ctx = Context(device=device, levels=levels, fovea_levels=fl, slots=1, kernel_path=kernel_path)
+        self.frames_in_flight = max(1, int(frames_in_flight))
+        slots = min(self.frames_in_flight, 4)
+        batch = min(8, -(-self.frames_in_flight // slots))
+        self._ctx = Context(device=device, levels=levels, fovea_levels=fl, slots=slots, kernel_path=kernel_path, batch=batch)
+        self._tags = {}     # tag -> (kind, rows, cols, want_pyr) of the pairs outstanding in the queue
 
     # -- getters / setters, MatchGPULib.cpp:268-301 --
     def getFoveaWidth(self) -> int:
@@ -146,6 +152,49 @@ class MatchGPULib:
     def matchStackPyramid(self, cv_ptrL, cv_ptrR, off_x: int = 0, off_y: int = 0):
         """Returns (disparity stack, leftFov, rightFov); the latter two are (foveatelevel, 3, fovH, fovW)."""
         return self._stack(cv_ptrL, cv_ptrR, True, off_x, off_y)
+
+    # -- the pipelined twin of match / matchStack / matchStackPyramid (not in the reference; include/ugsm.h "the queue") --
+    def enqueueMatch(self, cv_ptrL, cv_ptrR, tag: int):
+        """match(L, R, 0) without the wait: the images are copied before the call returns; the result comes out of nextDone."""
+        L, R = _as_rgb8(cv_ptrL), _as_rgb8(cv_ptrR)
+        if L.shape != R.shape or L.strides[0] != R.strides[0]:
+            raise UgsmError(_lib.UGSM_ERR_SIZE_MISMATCH, "left/right images differ in size")
+        self._ctx.enqueue_full_managed(L, R, tag)
+        self._tags[tag] = ("full", L.shape[0], L.shape[1], False)
+        self._ctx.flush()   # a frame that arrives starts at once if a slot is free; under load the backlog batches itself
+
+    def enqueueStack(self, cv_ptrL, cv_ptrR, tag: int, want_pyr: bool = False, off_x: int = 0, off_y: int = 0):
+        """matchStack / matchStackPyramid without the wait."""
+        L, R = _as_rgb8(cv_ptrL), _as_rgb8(cv_ptrR)
+        if L.shape != R.shape or L.strides[0] != R.strides[0]:
+            raise UgsmError(_lib.UGSM_ERR_SIZE_MISMATCH, "left/right images differ in size")
+        rows, cols = L.shape[:2]
+        self.fovW, self.fovH = _lib.fovea_dims(cols, rows, self._levels, self.foveatelevel)
+        self._ctx.enqueue_foveated_managed(L, R, (off_x, off_y), want_pyr, tag)
+        self._tags[tag] = ("stack", rows, cols, bool(want_pyr))
+        self._ctx.flush()
+
+    def outstanding(self) -> int:
+        return len(self._tags)
+
+    def nextDone(self, block: bool = True):
+        """The oldest outstanding pair: (tag, result) with result as match / matchStack / matchStackPyramid return it (copies owned by the
+        caller), or None if there is none (block=False: or it has not finished)."""
+        c = self._ctx.next_done(block)
+        if c is None:
+            return None
+        kind, rows, cols, want_pyr = self._tags.pop(c.tag)
+        if kind == "full":
+            h, v, cf = self._ctx.managed_planes(c, [(rows, cols)] * 3)
+            return c.tag, np.stack([h, v, cf])
+        F = self.foveatelevel
+        fw, fh = _lib.fovea_dims(cols, rows, self._levels, F)
+        shapes = [(F, fh, fw)] * 3 + ([(F, 3, fh, fw)] * 2 if want_pyr else [])
+        pl = self._ctx.managed_planes(c, shapes)
+        stack = np.ascontiguousarray(np.stack(pl[:3]).transpose(1, 0, 2, 3))   # [level][plane][row][col], as matchStack
+        if want_pyr:
+            return c.tag, (stack, pl[3].copy(), pl[4].copy())
+        return c.tag, stack
 
     def close(self):
         self._ctx.close()

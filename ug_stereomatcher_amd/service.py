@@ -122,9 +122,16 @@ def to_cv_copy_rgb8(msg: Image) -> np.ndarray:
 class GPUMatcher:
     """class GPU_matcher, UG_GPU_matcher.cpp:66-738, minus the ROS transport."""
 
-    def __init__(self, argc: int = 0, argv=None, params: dict | None = None, publish=None, matcher=None, **lib_kwargs):
+    def __init__(self, argc: int = 0, argv=None, params: dict | None = None, publish=None, matcher=None, frames_in_flight: int = 1, **lib_kwargs):
         """`matcher`: an object with MatchGPULib's interface to use instead of constructing one
-        (the plumbing tests inject a CPU-oracle-backed double; the product never does)."""
+        (the plumbing tests inject a CPU-oracle-backed double; the product never does).
+        `frames_in_flight` (opt-in, default 1 = the reference's behaviour: one blocking match() per callback, UG_GPU_matcher.cpp:423):
+        with n > 1 the topic path enqueues the synchronised pair into the library's queue and publishes results AS THEY COMPLETE, in
+        arrival order, a frame or n - 1 later; a callback blocks only while n pairs are outstanding.  spinOnce() publishes what has
+        finished meanwhile, drain() everything (node shutdown).  The service call stays blocking: a response belongs to its request."""
+        self.frames_in_flight = max(1, int(frames_in_flight))
+        self._pending = {}   # tag -> (imL header, imR header, image rows, image cols) of the frames in flight
+        self._next_tag = 0
         self.cmd_argc, self.cmd_argv = argc, argv
         self.params = params if params is not None else {}
         self.published = {}
@@ -139,7 +146,10 @@ class GPUMatcher:
     def _matcher(self) -> MatchGPULib:
         # the reference constructs a MatchGPULib per callback (:160,530); the context here persists
         if self._mgpu is None:
-            self._mgpu = MatchGPULib(self.cmd_argc, self.cmd_argv, **self._lib_kwargs)
+            kw = dict(self._lib_kwargs)
+            if self.frames_in_flight > 1:
+                kw["frames_in_flight"] = self.frames_in_flight
+            self._mgpu = MatchGPULib(self.cmd_argc, self.cmd_argv, **kw)
         return self._mgpu
 
     @staticmethod
@@ -161,6 +171,7 @@ class GPUMatcher:
         self.foveated = self._read_foveated()
         mgpu = self._matcher()
         mgpu.setFoveated(self.foveated)
+        self.drain()  # (pipelined topic path: the slots belong to the queue while frames are in flight; publish them first)
         try:
             if self.foveated == 1:
                 stack = mgpu.matchStack(L, R)  # :535
@@ -189,6 +200,20 @@ class GPUMatcher:
         self.foveated = self._read_foveated()
         mgpu = self._matcher()
         mgpu.setFoveated(self.foveated)
+        if self.frames_in_flight > 1:
+            # pipelined topic path: enqueue, publish what has finished, block only while frames_in_flight pairs are outstanding
+            tag = self._next_tag
+            self._next_tag += 1
+            self._pending[tag] = (imL.header, imR.header, L.shape[0], L.shape[1], self.foveated)
+            if self.foveated == 1:
+                mgpu.initStack(L, R)
+                mgpu.enqueueStack(L, R, tag, want_pyr=True)
+            else:
+                mgpu.enqueueMatch(L, R, tag)
+            self.spinOnce()
+            while mgpu.outstanding() >= self.frames_in_flight:
+                self._publish_next(True)
+            return
         if self.foveated == 1:
             mgpu.initStack(L, R)  # :166
             stack, lf, rf = mgpu.matchStackPyramid(L, R)  # :181
@@ -207,3 +232,43 @@ class GPUMatcher:
             self._publish(CAM_PUB_HOR, DisparityImage(imL.header, Image.from_array(fin[0], "32FC1", imL.header)))
             self._publish(CAM_PUB_VER, DisparityImage(imR.header, Image.from_array(fin[1], "32FC1", imR.header)))
             self._publish(CAM_PUB_CONF, DisparityImage(imL.header, Image.from_array(fin[2], "32FC1", imL.header)))
+
+    # ---- the pipelined topic path (frames_in_flight > 1) ----------------------------------------------------------------------
+    def _publish_next(self, block: bool) -> bool:
+        mgpu = self._matcher()
+        got = mgpu.nextDone(block)
+        if got is None:
+            return False
+        tag, res = got
+        hl, hr, rows, cols, fov = self._pending.pop(tag)
+        if fov == 1:
+            stack, lf, rf = res
+            F, fw, fh = mgpu.getFoveateLevel(), stack.shape[3], stack.shape[2]
+            Lshape = np.empty((rows, cols, 0), np.uint8)   # (only the image size is read)
+            for topic, pyr, hdr in ((CAM_PUB_STACK_LEFTP, lf, hl), (CAM_PUB_STACK_LEFTR, rf, hr)):
+                st = FoveatedStack(header=hdr, image_stack=Image.from_array(pyr.reshape(F * 3 * fh, fw), "32FC1", hdr))
+                st.im_width, st.im_height = cols, rows
+                st.roi_width, st.roi_height, st.num_levels = fw, fh, F
+                self._publish(topic, st)
+            self._publish(CAM_PUB_STACK_HOR, self._stack_msg(stack[:, 0], hl, Lshape, fw, fh, F, True))
+            self._publish(CAM_PUB_STACK_VER, self._stack_msg(stack[:, 1], hr, Lshape, fw, fh, F, True))
+            self._publish(CAM_PUB_STACK_CONF, self._stack_msg(stack[:, 2], hl, Lshape, fw, fh, F, True))
+        else:
+            self._publish(CAM_PUB_HOR, DisparityImage(hl, Image.from_array(res[0], "32FC1", hl)))
+            self._publish(CAM_PUB_VER, DisparityImage(hr, Image.from_array(res[1], "32FC1", hr)))
+            self._publish(CAM_PUB_CONF, DisparityImage(hl, Image.from_array(res[2], "32FC1", hl)))
+        return True
+
+    def spinOnce(self) -> int:
+        """Publishes every frame that has finished (never blocks); returns how many."""
+        n = 0
+        while self._mgpu is not None and self._pending and self._publish_next(False):
+            n += 1
+        return n
+
+    def drain(self) -> int:
+        """Publishes every frame still in flight (blocks); returns how many."""
+        n = 0
+        while self._mgpu is not None and self._pending and self._publish_next(True):
+            n += 1
+        return n
