@@ -419,6 +419,27 @@ int main(int argc, char **argv)
                 }
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 19) {  // K-cost issue-slot study: the production launch (np = 1, strips by age class) of THIS build
+        // (-DMARCH_ILV=0|1|2 ...) -- bits against k_cost_split, then `reps` back-to-back launches, three rounds: kbench W H reps 19
+        float *o2; CK(hipMalloc(&o2, 12 * n));
+        std::vector<float> ha(3 * n), hb(3 * n);
+        launch_cost_fused(st, iL, iR, A, d, o, W, H, 0.55f, 1);
+        CK(hipMemset(o2, 0xff, 12 * n));
+        launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, 1, 0, rb);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb.data(), o2, 12 * n, hipMemcpyDeviceToHost));
+        size_t bad = 0;
+        for (size_t i = 0; i < 3 * n; i++)
+            if (memcmp(&ha[i], &hb[i], 4) != 0 && !(ha[i] != ha[i] && hb[i] != hb[i])) bad++;
+#ifndef MARCH_VARIANT
+#define MARCH_VARIANT "base"
+#endif
+        printf("variant %s: march np=1 vs k_cost_split: %zu of %zu values differ%s\n", MARCH_VARIANT, bad, 3 * n, bad ? "" : " (bit-exact)");
+        for (int round = 0; round < 3; round++) timeit("k_cost_march np=1 rows=0 [" MARCH_VARIANT "]", [&]() { launch_cost_march(st, iL, iR, A, d, o2, W, H, 0.55f, 1, 0, 1, 0, rb); });
+        CK(hipGetLastError());
+        return bad ? 1 : 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 2) {  // marching K-cost against the LDS-tiled one: bit comparison + timing
         float *o2; CK(hipMalloc(&o2, 12 * n));
         std::vector<float> ha(3 * n), hb(3 * n);

@@ -95,6 +95,37 @@ __device__ __forceinline__ void rowconv5(const float (&p)[NP], float (&out)[NP])
     }
 }
 
+// MARCH_ILV (development switch, tools/kbench only): the N systolic row passes of one colour channel -- R'^2 and the
+// five products -- advance in LOCKSTEP, stage by stage, instead of chain after chain: between a chain's VALU result and the DPP read of it
+// one stage later lie N - 1 independent instructions, so the two wait states of the VALU-write -> DPP-read hazard need no s_nop.
+// 1: lockstep in source order; 2: lockstep pinned by scheduling barriers between the stages.  Same operations, same results bit for bit.
+#ifndef MARCH_ILV
+#define MARCH_ILV 1
+#endif
+template <int N>
+__device__ __forceinline__ void rowconv5_lockstep(const float (&v)[N], float (&out)[N])
+{
+    float a0[N], a1[N], a2[N], t[N];
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        a0[c] = v[c] * UGSM_G0;
+        a1[c] = v[c] * UGSM_G1;
+        a2[c] = v[c] * UGSM_G2;
+    }
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(a0[c]) + a1[c];
+    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a2[c];
+    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a1[c];
+    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < N; c++) out[c] = shr1(t[c]) + a0[c];
+    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
+}
+
 // One step of the transposed-form 5-tap column pass: `h` is the row-pass value of the row that has just arrived;
 // s[0..3] hold the partial sums of the four output rows still open.  Returns the sum of the row that closes (two rows up).
 template <bool FMAD>
@@ -211,7 +242,12 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     };
     const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    auto rowc = [&](int r) { return min(max(r, 0), H - 1); };  // rows are clamped with scalar ops in every strip
+    // rows are clamped with scalar ops in every strip (MARCH_NOCLAMP, development switch, VERDICT r04 #3 (ii): not in the interior strips,
+    // which then must keep six rows clear of the frame -- see `interior` in k_cost_march)
+#ifndef MARCH_NOCLAMP
+#define MARCH_NOCLAMP 1
+#endif
+    auto rowc = [&](int r) { return (MARCH_NOCLAMP && !EDGE) ? r : min(max(r, 0), H - 1); };
     auto row_off = [&](const int r, const unsigned pitch, unsigned (&off)[NP], const bool skewed = false) {
         const unsigned ro = (unsigned)rowc(r) * pitch;
 #pragma unroll
@@ -304,9 +340,12 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 rc[j] = cur.R[k][j];
                 sq[j] = rc[j] * rc[j];  // Square, MatchLib.cu:569-570
             }
-            rowconv5<NP, FMAD>(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
+            constexpr bool ILV = MARCH_ILV != 0 && NP == 1 && !FMAD;
+            if (!(ILV && do_prod)) {
+                rowconv5<NP, FMAD>(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
 #pragma unroll
-            for (int j = 0; j < NP; j++) bnew[j] = colstep5<FMAD>(aB[k][j], hb[j]);  // = B(r-2)
+                for (int j = 0; j < NP; j++) bnew[j] = colstep5<FMAD>(aB[k][j], hb[j]);  // = B(r-2)
+            }
             if (do_prod) {
                 float l[NP], p[5][NP], Nv[5][NP];
 #pragma unroll
@@ -319,12 +358,21 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                     p[3][j] = l[j] * rc[j];                   // shift (0, +1)
                     p[4][j] = l[j] * Rm1[k][j];               // shift (0, 0)
                 }
+                if constexpr (ILV) {  // the six row passes of the channel in lockstep (MARCH_ILV)
+                    const float v6[6] = {sq[0], p[0][0], p[1][0], p[2][0], p[3][0], p[4][0]};
+                    float h6[6];
+                    rowconv5_lockstep<6>(v6, h6);
+                    bnew[0] = colstep5<false>(aB[k][0], h6[0]);
 #pragma unroll
-                for (int s = 0; s < 5; s++) {  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
-                    float h[NP];
-                    rowconv5<NP, FMAD>(p[s], h);
+                    for (int s = 0; s < 5; s++) Nv[s][0] = colstep5<false>(aN[k][s][0], h6[s + 1]);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NP; j++) Nv[s][j] = colstep5<FMAD>(aN[k][s][j], h[j]);
+                    for (int s = 0; s < 5; s++) {  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
+                        float h[NP];
+                        rowconv5<NP, FMAD>(p[s], h);
+#pragma unroll
+                        for (int j = 0; j < NP; j++) Nv[s][j] = colstep5<FMAD>(aN[k][s][j], h[j]);
+                    }
                 }
                 if (do_out) {
 #pragma unroll
@@ -494,7 +542,7 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
     const int X0 = xs - 3;
     // interior: every pixel a lane holds lies inside the image, and so do the product rows ys-2 .. ye+1 (L is zero outside)
     // and the rows ys-1 .. ye of the B fetches
-    const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && ys >= 2 && ye <= H - 2;
+    const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && (MARCH_NOCLAMP ? (ys >= 6 && ye <= H - 6) : (ys >= 2 && ye <= H - 2));
     // range-guarded division (ugsm_exact.hpp) when the pyramid builder found every value of the pair in range
     const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
     if constexpr (NP == 1 && !FMAD) {

@@ -47,6 +47,30 @@ __device__ __forceinline__ float rowconv5(const float p)
     const float p4 = shr1(p3) + a1;
     return shr1(p4) + a0;
 }
+// MARCH4_ILV: the six row passes of a channel wave in lockstep (as MARCH_ILV in ugsm_kernels_march.hip): a channel wave is alone on its
+// SIMD in the latency mode this kernel serves, so every s_nop of the VALU-write -> DPP-read hazard is an idle issue slot
+#ifndef MARCH4_ILV
+#define MARCH4_ILV 1
+#endif
+template <int N>
+__device__ __forceinline__ void rowconv5_lockstep(const float (&v)[N], float (&out)[N])
+{
+    float a0[N], a1[N], a2[N], t[N];
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        a0[c] = v[c] * UGSM_G0;
+        a1[c] = v[c] * UGSM_G1;
+        a2[c] = v[c] * UGSM_G2;
+    }
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(a0[c]) + a1[c];
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a2[c];
+#pragma unroll
+    for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a1[c];
+#pragma unroll
+    for (int c = 0; c < N; c++) out[c] = shr1(t[c]) + a0[c];
+}
 // one step of the transposed-form 5-tap column pass: returns the sum of the row that closes (two rows up)
 __device__ __forceinline__ float colstep5(float (&s)[4], const float h)
 {
@@ -167,8 +191,8 @@ __device__ __forceinline__ void channel_wave(const int k, const Img3 &L, const I
         const bool yin = !EDGE || (y >= 0 && y < H);
         const float rc = cur.R;
         const float sq = rc * rc;                  // Square, MatchLib.cu:569-570
-        const float hb = rowconv5(sq);             // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
-        const float bnew = colstep5(aB, hb);       // = B(r-2)
+        float bnew;                                // = B(r-2): convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp)
+        if (!(MARCH4_ILV && do_prod)) bnew = colstep5(aB, rowconv5(sq));
         if (do_prod) {
             const float l = (c.cin && yin) ? cur.L : 0.0f;
             float p[5];                            // CompareMove, MatchLib.cu:622-624
@@ -178,8 +202,17 @@ __device__ __forceinline__ void channel_wave(const int k, const Img3 &L, const I
             p[3] = l * rc;                         // shift (0, +1)
             p[4] = l * Rm1;                        // shift (0, 0)
             float Nv[5];
+            if (MARCH4_ILV) {                      // the six row passes in lockstep: no s_nop between a stage and the DPP read of it
+                const float v6[6] = {sq, p[0], p[1], p[2], p[3], p[4]};
+                float h6[6];
+                rowconv5_lockstep<6>(v6, h6);
+                bnew = colstep5(aB, h6[0]);
 #pragma unroll
-            for (int s = 0; s < 5; s++) Nv[s] = colstep5(aN[s], rowconv5(p[s]));  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
+                for (int s = 0; s < 5; s++) Nv[s] = colstep5(aN[s], h6[s + 1]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 5; s++) Nv[s] = colstep5(aN[s], rowconv5(p[s]));  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
+            }
             if (do_out) {
                 const float a = cur.A, bc = Bm1;
                 float bl = shr1(Bm1), br = shl1(Bm1), bu = Bm2, bd = bnew;
@@ -306,6 +339,9 @@ __global__ __launch_bounds__(256, WAVES) void k_cost_march4(Img3 L, Img3 R, cons
     const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
     const bool seeded = sm.Ws > 0;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if defined(MARCH4_PRIO) && MARCH4_PRIO  // development switch (tools/kbench): the epilogue wave ahead of the channel waves it shares a SIMD with
+    if (role == 3) __builtin_amdgcn_s_setprio(3);
+#endif
     // (every branch below is workgroup-uniform except the role, and both roles run the same number of row steps = barriers)
 #define UGSM_M4_DISPATCH(EDGE, SEED)                                                                                                  \
     do {                                                                                                                              \
