@@ -166,3 +166,28 @@ def test_ros_node_source_compiles_against_declaration_stubs():
     r = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-Itests/ros_stubs", "-Iros", "-Iinclude", "ros/UG_GPU_matcher_ugsm.cpp"],
                        cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_torch_hip_runtime_is_shared_only_when_the_abi_matches(lib, tmp_path, monkeypatch):
+    """the package preloads PyTorch's bundled libamdhip64 (so that `import torch` after it still sees the GPU) only if that
+    file's SONAME is the one libugsm.so was linked against; a mismatch -- mocked here by offering another library, and a file that is no
+    ELF at all -- is skipped with a warning instead of binding libugsm.so's HIP calls to another runtime ABI.  The opt-out stays."""
+    import warnings
+    soname, needed = lib._elf_dynamic(lib.LIB_PATH)
+    hip = [n for n in needed if n.startswith("libamdhip64.so")]
+    assert len(hip) == 1 and soname is None
+    other = "/lib/x86_64-linux-gnu/libm.so.6"
+    assert lib._elf_dynamic(other)[0] == "libm.so.6"
+    junk = tmp_path / "libamdhip64.so"
+    junk.write_bytes(b"not an ELF file")
+    monkeypatch.delenv("UGSM_NO_TORCH_RUNTIME", raising=False)
+    for offered in (other, str(junk)):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert lib._share_torch_hip_runtime(lib.LIB_PATH, torch_hip=offered) == "mismatch"
+        assert len(w) == 1 and "not sharing it" in str(w[0].message) and hip[0] in str(w[0].message)
+    real = lib._torch_hip_runtime_path()
+    if real is not None and lib._elf_dynamic(real)[0] == hip[0]:
+        assert lib._share_torch_hip_runtime(lib.LIB_PATH) == "preloaded"
+    monkeypatch.setenv("UGSM_NO_TORCH_RUNTIME", "1")
+    assert lib._share_torch_hip_runtime(lib.LIB_PATH, torch_hip=other) == "off"

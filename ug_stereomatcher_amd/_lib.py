@@ -85,24 +85,79 @@ class Completion(C.Structure):
 _libs = {}
 
 
-def _share_torch_hip_runtime():
+def _elf_dynamic(path: str):
+    """(SONAME, [DT_NEEDED ...]) of a 64-bit little-endian ELF shared object, read from its dynamic section; (None, []) if the file is not
+    one.  Enough of a reader to compare which HIP runtime ABI two libraries name -- no external tool."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:6] != b"\x7fELF\x02\x01":
+            return None, []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        dyn = next((sec for sec in secs if sec[1] == 6), None)   # SHT_DYNAMIC
+        if dyn is None:
+            return None, []
+        strtab = secs[dyn[6]]                                     # sh_link: its string table
+        def name(off):
+            a = strtab[4] + off
+            return data[a:data.index(b"\0", a)].decode()
+        soname, needed = None, []
+        for i in range(dyn[5] // 16):
+            tag, val = struct.unpack_from("<qQ", data, dyn[4] + 16 * i)
+            if tag == 0:
+                break
+            if tag == 14:
+                soname = name(val)
+            elif tag == 1:
+                needed.append(name(val))
+        return soname, needed
+    except (OSError, ValueError, struct.error, IndexError, StopIteration):
+        return None, []
+
+
+def _torch_hip_runtime_path():
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    return path if os.path.exists(path) else None
+
+
+def _share_torch_hip_runtime(lib_path: str = LIB_PATH, torch_hip: str | None = None):
     """PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  A process that loads libugsm.so FIRST (which brings in
     /opt/rocm's runtime) and imports torch afterwards ends up with two HIP runtimes, and the second one finds no GPU ("No HIP GPUs are
     available").  When torch is installed, its runtime is therefore loaded first, globally, and libugsm.so binds to it -- the order
     bench.py and the tools have always used (they import torch first).  A host without torch (the ROS node) is not affected.
-    UGSM_NO_TORCH_RUNTIME=1 switches this off."""
+    Only when the two name the SAME runtime ABI: libugsm.so was compiled against /opt/rocm's headers and asks for one SONAME
+    (DT_NEEDED libamdhip64.so.N); a torch wheel built for another ROCm major carries another, and binding libugsm.so's HIP calls to it
+    would be an ABI gamble -- then nothing is preloaded and a warning says so.  UGSM_NO_TORCH_RUNTIME=1 switches the preload off.
+    Returns what happened: "preloaded", "off", "no torch", "mismatch" or "failed"."""
+    import warnings
     if os.environ.get("UGSM_NO_TORCH_RUNTIME") == "1":
-        return
+        return "off"
     try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except Exception:
-        pass  # (best effort: without it the library still works, only a later `import torch` would not see the GPU)
+        path = torch_hip if torch_hip is not None else _torch_hip_runtime_path()
+    except Exception as e:  # noqa: BLE001  (a broken torch installation must not keep the library from loading)
+        warnings.warn(f"ug_stereomatcher_amd: could not look for PyTorch's HIP runtime ({e}); libugsm.so uses the system's", RuntimeWarning)
+        return "failed"
+    if path is None:
+        return "no torch"
+    wanted = next((n for n in _elf_dynamic(lib_path)[1] if n.startswith("libamdhip64.so")), None)
+    offered = _elf_dynamic(path)[0]
+    if wanted is None or offered != wanted:
+        warnings.warn(f"ug_stereomatcher_amd: PyTorch bundles HIP runtime {offered!r} but libugsm.so was built against {wanted!r}: not sharing it -- "
+                      "import torch BEFORE this package if both are to see the GPU, or rebuild libugsm.so against torch's ROCm", RuntimeWarning)
+        return "mismatch"
+    try:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        return "preloaded"
+    except OSError as e:
+        warnings.warn(f"ug_stereomatcher_amd: could not preload {path} ({e}); a later `import torch` may not see the GPU", RuntimeWarning)
+        return "failed"
 
 
 def load(dev: bool = False):
@@ -113,7 +168,7 @@ def load(dev: bool = False):
     if not os.path.exists(path):
         raise UgsmError(UGSM_ERR_NO_DEVICE, f"{path} not built: run `make -C ug_stereomatcher_amd/csrc`")
     if not _libs:
-        _share_torch_hip_runtime()
+        _share_torch_hip_runtime(path)
     lib = C.CDLL(path)
     vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
     i = C.c_int
