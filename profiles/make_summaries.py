@@ -19,7 +19,7 @@ for f in ("bench_default.json", "bench_under_rocprof.json"):
     shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 for f in ("kbench_age_16mp.txt", "kbench_graph.txt", "census_16mp.txt", "kbench_16mp.txt", "kbench_smooth_16mp.txt", "kbench_small.txt", "kbench_aux_16mp.txt", "kbench_strips.txt", "level_breakdown.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json",
           "bench_fovea16mp.json", "ab_policies.txt", "ab_batch.txt", "bench_steps20.json", "bench_batch1.json", "kbench_smooth_pipe.txt", "rehearsal_2ranks.txt", "rccl_and_contexts.txt",
-          "kbench_march4.txt", "queue_probe.txt"):
+          "kbench_march4.txt", "queue_probe.txt", "ab_queue.txt", "kbench_march_issue_raw.txt"):
     if os.path.exists(f"{base}/{f}"):
         shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collects everything profiles/make_summaries.py needs, in ONE gpurun call:
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r04'
-#   python profiles/make_summaries.py gpurun_out/prof_r04 r04
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r05 A'   (then B)
+#   python profiles/make_summaries.py gpurun_out/prof_r05 r05
 # Counter passes are separate rocprofv3 runs with at most 8 counters each (--kernel-trace only beside --pmc), each
 # behind its own timeout; a line is printed after every step so that the call never looks hung.
 export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-AB}   # A: the bench lines, the kernel trace, the counter passes; B: kbench, same-box A/Bs, breakdowns, rehearsals (two gpurun calls: each stays well inside the 20-minute limit)
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
@@ -52,8 +52,10 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 timeout -k 10 100 ./tools/kbench_stamp 4928 3264 10 6 > $O/census_16mp.txt 2>&1; step "wave census of the marching K-cost"
 { timeout -k 10 100 python tools/level_breakdown.py; timeout -k 10 100 python tools/level_breakdown.py --batch 4 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --fovea 7; timeout -k 10 100 python tools/level_breakdown.py --fovea 7 --batch 8 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --size 1920 1080 --batch 8 --slots 4; } 2>&1 | grep -v amdgpu.ids > $O/level_breakdown.txt; step "per-level breakdown: one pair, a batch of 4, the foveated stack alone and as a batch of 8, 1080p as a batch of 8"
 timeout -k 10 200 ./tools/kbench 4928 3264 10 17 > $O/kbench_smooth_pipe.txt 2>&1; step "kbench (k_smooth_pipe against k_smooth_fused)"
-{ echo "# two gloo ranks on one MI355X (rehearsal of the N > 1 code path: both ranks share the card, each with its own four-slot context)"; for wl in full16mp fovea-shard; do echo "\$ UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 24 --warmup 4 --workload $wl --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0"; UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo MASTER_PORT=29611 timeout -k 10 200 python bench.py --gpus 2 --steps 24 --warmup 4 --workload $wl --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0 2>/dev/null | cut -c1-400; done; } > $O/rehearsal_2ranks.txt 2>&1; step "two-rank rehearsal over gloo"
-timeout -k 10 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_batch.py::test_two_contexts_in_one_process_with_stream_priority_pools -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -12 > $O/rccl_and_contexts.txt; step "one-rank RCCL shard test + two contexts"
+{ echo "# two gloo ranks on one MI355X (rehearsal of the N > 1 code path of the replicas: both ranks share the card, each with its own four-slot context and its own queue)"; echo "\$ UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0"; UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo MASTER_PORT=29611 timeout -k 10 200 python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0 2>/dev/null | cut -c1-600; echo "# the fovea shard on ONE rank: torch.distributed (nccl) for the barrier, the library's own RCCL communicator for the exchange (two ranks cannot share a GPU under RCCL: no two-rank rehearsal of this workload on a one-GPU box)"; echo "\$ UGSM_FORCE_DIST=1 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline"; UGSM_FORCE_DIST=1 MASTER_PORT=29612 timeout -k 10 200 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline 2>/dev/null | cut -c1-900; } > $O/rehearsal_2ranks.txt 2>&1; step "two-rank rehearsal over gloo + one-rank fovea shard over RCCL"
+timeout -k 10 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_batch.py::test_two_contexts_in_one_process_with_stream_priority_pools -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -12 > $O/rccl_and_contexts.txt; step "one-rank RCCL shard test (ugsm_shard_*) + two contexts"
+bash tools/exp/ab_queue.sh $O/ab_queue.txt > /dev/null 2>&1; step "same-box A/B: round 4's harness (call planning in Python) against the library's queue"
+bash tools/exp/march_issue.sh $O/kbench_march_issue_raw.txt "r04-kernels:tools/kbench_r04k" "product:tools/kbench" > /dev/null 2>&1; step "kbench mode 19: K-cost with and without the lockstep row passes"
 # (7 minutes; the instruction costs do not change with the kernels: only with VALUBENCH=1)
 if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"; fi
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
