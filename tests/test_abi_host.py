@@ -191,3 +191,19 @@ def test_torch_hip_runtime_is_shared_only_when_the_abi_matches(lib, tmp_path, mo
         assert lib._share_torch_hip_runtime(lib.LIB_PATH) == "preloaded"
     monkeypatch.setenv("UGSM_NO_TORCH_RUNTIME", "1")
     assert lib._share_torch_hip_runtime(lib.LIB_PATH, torch_hip=other) == "off"
+
+
+def test_header_is_plain_c99(lib):
+    """include/ugsm.h is the boundary a C / C++ / cgo / JNI host binds: it must compile as C99 by itself, and ros/queue_example.c (the
+    queue from plain C) must compile against it."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "ugsm.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "ros", "queue_example.c")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -354,3 +354,21 @@ def test_node_mirror_pipelined_topic_path_equals_the_blocking_one(lib):
             assert ia.data == ib.data, f"fov={fov}, topic {t}, frame {ma.header.seq}: pipelined and blocking topic paths differ"
             if hasattr(ma, "num_levels"):
                 assert (ma.im_width, ma.im_height, ma.roi_width, ma.roi_height, ma.num_levels) == (mb.im_width, mb.im_height, mb.roi_width, mb.roi_height, mb.num_levels)
+
+
+def test_queue_from_plain_c(lib, tmp_path):
+    """ros/queue_example.c: the frame loop of a C host -- ugsm_enqueue_full_managed with three frames in flight, every result equal to the
+    blocking ugsm_match_full of the same frame -- compiled with gcc against include/ugsm.h and the built library, run here."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "queue_example")
+    libdir = os.path.join(ROOT, "ug_stereomatcher_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "ros", "queue_example.c"), "-L" + libdir, "-lugsm",
+                           "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "QUEUE_EXAMPLE_OK" in out.stdout and "identical to the blocking calls" in out.stdout, out.stdout
