@@ -410,6 +410,22 @@ def test_out_of_device_memory_is_a_status_code_and_the_context_lives_on(lib, orc
         assert sts == [0, 0]                      # single calls, which fit
         for p in [dL, dR] + outs:
             c.free(p)
+    # ... and a queue-formed call that does NOT fit: its pairs come back with UGSM_ERR_NOMEM, in order, and the queue goes on
+    with lib.Context(levels=lv, slots=1, batch=4) as c:
+        dL, dR = c.to_device(L), c.to_device(R)
+        outs = [c.alloc(3 * W * H * 4) for _ in range(5)]
+        rets = [c.lib.ugsm_enqueue_full(c.handle, dL, dR, W, H, 3 * W, outs[k], 10 + k) for k in range(4)]   # one slot: the first call takes four
+        assert rets[:3] == [0, 0, 0] and rets[3] == lib.UGSM_ERR_NOMEM, rets      # the enqueue that completed the call reports its failure
+        got = []
+        while c.lib.ugsm_next_done(c.handle, C.byref(comp), 1) == lib.UGSM_OK:
+            got.append((comp.tag, comp.status, comp.call_pairs))
+        assert got == [(10 + k, lib.UGSM_ERR_NOMEM, 4) for k in range(4)], got
+        assert c.lib.ugsm_enqueue_full(c.handle, dL, dR, W, H, 3 * W, outs[4], 99) == lib.UGSM_OK
+        d = c.next_done(True)
+        assert d.tag == 99 and d.status == 0 and d.call_pairs == 1
+        assert_bit_equal(c.to_host(outs[4], (3, H, W)), exp, "a one-pair call after the refused call of four")
+        for p in [dL, dR] + outs:
+            c.free(p)
 
 
 def test_the_largest_documented_context_at_16mp(lib, oracle_16mp, oracle_16mp_b):

@@ -373,6 +373,31 @@ int ensure_level_bufs(ugsm_ctx *ctx, Slot &s, size_t lvl)
     return UGSM_OK;
 }
 
+// the slot's pyramids and level buffers for `cap_pairs` pairs (both pyramids or neither; level buffers all or nothing)
+int alloc_slot_buffers(ugsm_ctx *ctx, Slot &s, int cap_pairs, size_t tot, size_t lvl)
+{
+    const size_t pyr_need = cap_pairs > 1 ? s.pyr_stride * cap_pairs : tot;
+    if (pyr_need > s.pyr_cap) {
+        // both or neither: a failure leaves the slot without pyramids and the capacity at zero (never a capacity one of them lacks)
+        size_t capL = s.pyr_cap, capR = s.pyr_cap;
+        s.pyr_cap = 0;
+        int st = grow(ctx, s.pyrL, capL, pyr_need);
+        if (st == UGSM_OK) st = grow(ctx, s.pyrR, capR, pyr_need);
+        if (st != UGSM_OK) {
+            for (float **b : {&s.pyrL, &s.pyrR}) {
+                if (*b) {
+                    untrack(ctx, *b);
+                    (void)hipFree(*b);
+                }
+                *b = nullptr;
+            }
+            return st;
+        }
+        s.pyr_cap = pyr_need;
+    }
+    return ensure_level_bufs(ctx, s, cap_pairs > 1 ? s.lvl_stride * cap_pairs : lvl);
+}
+
 int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
 {
     const int levels = ctx->cfg.levels;
@@ -401,28 +426,30 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
     // sized for the batch the context was created for (ugsm_config.batch) even when this call brings fewer pairs: a host that batches
     // what has piled up alternates between call sizes, and a reallocation (hipFree + hipMalloc of gigabytes: a device-wide
     // synchronisation) must not land in the middle of its stream of calls
-    const int cap_pairs = std::max(nb, std::min(std::max(ctx->cfg.batch, 1), kMaxBatch));
-    const size_t pyr_need = cap_pairs > 1 ? s.pyr_stride * cap_pairs : tot;
-    if (pyr_need > s.pyr_cap) {
-        // both or neither: a failure leaves the slot without pyramids and the capacity at zero (never a capacity one of them lacks)
-        size_t capL = s.pyr_cap, capR = s.pyr_cap;
-        s.pyr_cap = 0;
-        int st = grow(ctx, s.pyrL, capL, pyr_need);
-        if (st == UGSM_OK) st = grow(ctx, s.pyrR, capR, pyr_need);
-        if (st != UGSM_OK) {
-            for (float **b : {&s.pyrL, &s.pyrR}) {
-                if (*b) {
-                    untrack(ctx, *b);
-                    (void)hipFree(*b);
-                }
-                *b = nullptr;
+    const int want_pairs = std::max(nb, std::min(std::max(ctx->cfg.batch, 1), kMaxBatch));
+    // ... but a context created for batches of eight on a card that has room for four still serves the calls that fit: if the buffers for
+    // the configured batch cannot be had, size them for this call alone (they grow again when a larger call comes and memory allows)
+    int st = UGSM_OK;
+    for (int cap_pairs : {want_pairs, nb}) {
+        st = alloc_slot_buffers(ctx, s, cap_pairs, tot, lvl);
+        if (st != UGSM_ERR_NOMEM) break;
+        // out of memory: what the attempt (or an earlier, larger call) left in the slot goes back before anything else is tried, so that a
+        // refused call never keeps memory it cannot use (the slot's stream has drained its earlier work by then: hipFree waits for it)
+        const std::string why = ctx->err;
+        float **bufs[7] = {&s.pyrL, &s.pyrR, &s.A, &s.d0, &s.d1, &s.Rw, &s.B};
+        for (float **b : bufs) {
+            if (*b) {
+                untrack(ctx, *b);
+                (void)hipFree(*b);
             }
-            return st;
+            *b = nullptr;
         }
-        s.pyr_cap = pyr_need;
+        s.pyr_cap = 0;
+        s.lvl_cap = 0;
+        ctx->err = why;
+        if (cap_pairs == nb) break;
     }
-    UCHK(ensure_level_bufs(ctx, s, cap_pairs > 1 ? s.lvl_stride * cap_pairs : lvl));
-    return UGSM_OK;
+    return st;
 }
 
 // ---- event bookkeeping -----------------------------------------------------------------
