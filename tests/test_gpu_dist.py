@@ -34,3 +34,36 @@ def test_fovea_shard_over_a_one_rank_rccl_group(W, H, levels, F, off, steps):
     tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
     assert r.returncode == 0, tail
     assert "RCCL_SHARD_OK" in r.stdout, tail
+
+
+def test_fovea_shard_two_ranks_over_a_fake_transport(tmp_path):
+    """The multi-rank code of csrc/ugsm_shard.cpp with TWO ranks on the one GPU of this pool ("the receiving side has never
+    run"): two processes, each with its own context; tests/fake_rccl.c -- a shared-memory stand-in with RCCL's signatures, test infrastructure
+    -- is what UGSM_RCCL_PATH points the library's dlopen at, because RCCL refuses two ranks on one device.  Rank 0 at the centre window, rank
+    1 off centre; rank 0 and then rank 1 as the source of the coarse state; every stack equals ugsm_submit_foveated at the rank's own window
+    bit for bit; ugsm_shard_count_ranks = 2; ugsm_shard_gather delivers both stacks to rank 0.  (RCCL itself -- transport, asynchrony, xGMI --
+    is NOT exercised by this test; the one-rank test above runs the real library.)"""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    import __graft_entry__ as ge
+    ge.build_library()
+    fake = str(tmp_path / "libfake_rccl.so")
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt",
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", fake])
+    env = dict(os.environ, UGSM_RCCL_PATH=fake, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    idfile = str(tmp_path / "shard.id")
+    args = ["1280", "960", "12", "5", "5"]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "shard_two_ranks_child.py"), str(r), "2", idfile] + args, env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o[-2000:], e[-2000:]))
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and f"SHARD2_OK rank={r} world=2" in o, (r, rc, o, e)
