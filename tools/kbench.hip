@@ -419,6 +419,37 @@ int main(int argc, char **argv)
                 }
         return 0;
     }
+    if (argc > 4 && atoi(argv[4]) == 20) {  // K-smooth phase shift (round 5): the second workgroup of every CU starts late, once per launch: kbench W H reps 20
+        auto run = [&](auto kern, int stx, int sty, int nt, const char *nm, int P = 5, int box = 1) {
+            const size_t bytes = 3 * (size_t)(sty + 14) * (stx + 16 + UGSM_SMOOTH_PAD(stx)) * sizeof(float);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            const int stxn = (W + stx - 1) / stx, stn = stxn * ((H + sty - 1) / sty);
+            timeit(nm, [&]() { hipLaunchKernelGGL(kern, dim3(stn), dim3(nt), bytes, st, d, o, W, H, P, box, stxn, stn, sty, Batch{1}); });
+        };
+        for (int round = 0; round < 3; round++) {
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5+box");
+            for (int sl : {0, 1, 2, 3, 4, 6, 8}) {
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(smooth_phase_sleep), &sl, sizeof sl));
+                char nm[96]; snprintf(nm, sizeof nm, "  phase shift %d x 3.5 us p5+box", sl);
+                run((k_smooth_fused<112, 36, 512, 16, true>), 112, 36, 512, nm);
+            }
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p5", 5, 0);
+            for (int sl : {0, 2, 4}) {
+                CK(hipMemcpyToSymbol(HIP_SYMBOL(smooth_phase_sleep), &sl, sizeof sl));
+                char nm[96]; snprintf(nm, sizeof nm, "  phase shift %d x 3.5 us p5", sl);
+                run((k_smooth_fused<112, 36, 512, 16, true>), 112, 36, 512, nm, 5, 0);
+            }
+            // occupancy: three workgroups per CU (LDS 53.8 KB each) -- eight waves each at <= 80 VGPRs, or four waves each
+            run((k_smooth_fused<112, 21, 512, 0, true, 6>), 112, 21, 512, "smooth<112,21,512> occ 6 (3 WG/CU) p5+box");
+            run((k_smooth_fused<112, 21, 512, 0, true, 4>), 112, 21, 512, "smooth<112,21,512> occ 4 (2 WG/CU) p5+box");
+            run((k_smooth_fused<112, 21, 256, 0, true, 3>), 112, 21, 256, "smooth<112,21,256> occ 3 (3 WG/CU) p5+box");
+            run((k_smooth_fused<112, 21, 384, 0, true, 5>), 112, 21, 384, "smooth<112,21,384> occ 5 (3 WG/CU x 6 waves) p5+box");
+            run((k_smooth_fused<112, 28, 512, 0, true, 5>), 112, 28, 512, "smooth<112,28,512> occ 5 p5+box");
+            run((k_smooth_fused<112, 36, 512, 0, true, 5>), 112, 36, 512, "smooth<112,36,512> occ 5 p5+box");
+        }
+        CK(hipGetLastError());
+        return 0;
+    }
     if (argc > 4 && atoi(argv[4]) == 19) {  // K-cost issue-slot study: the production launch (np = 1, strips by age class) of THIS build
         // (-DMARCH_ILV=0|1|2 ...) -- bits against k_cost_split, then `reps` back-to-back launches, three rounds: kbench W H reps 19
         float *o2; CK(hipMalloc(&o2, 12 * n));

@@ -992,13 +992,23 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
     }
 }
 
-template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false>
-__global__ __launch_bounds__(NT, (NT <= 512 ? NT / 128 : 1)) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
+__device__ int smooth_phase_sleep = 0;  // (development, VAR & 16: tools/kbench mode 20)
+// OCC (development, tools/kbench mode 20): waves per SIMD the register allocation is held to (0 = the product's NT / 128)
+template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false, int OCC = 0>
+__global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
                                                   int tiles_x, int n_tiles, int sty_arg, Batch bt)
 {
     if (bt.n > 1) {  // this workgroup's pair of the batch (blockIdx.y)
         s3 = shifted(s3, bt.in[blockIdx.y]);
         o3 = shifted(o3, bt.out[blockIdx.y]);
+    }
+    if constexpr ((VAR & 16) != 0) {
+        // development (tools/kbench mode 20, round 5): PHASE SHIFT.  The two workgroups a CU holds start together and take the same time, so
+        // they load together and compute together, launch after launch; the second workgroup of every CU (dispatch order 256 .. 511) waits
+        // smooth_phase_sleep x 64 x 127 cycles before it starts, once per launch, so that its successors run half a period out of phase
+        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        if (lin >= 256 && lin < 512)
+            for (int i = 0; i < smooth_phase_sleep; i++) __builtin_amdgcn_s_sleep(127);
     }
     const int sty = FIXH ? STY : sty_arg;
     constexpr int HX = 8, HY = 7;
