@@ -439,6 +439,20 @@ int main(int argc, char **argv)
                 char nm[96]; snprintf(nm, sizeof nm, "  phase shift %d x 3.5 us p5", sl);
                 run((k_smooth_fused<112, 36, 512, 16, true>), 112, 36, 512, nm, 5, 0);
             }
+            run((k_smooth_fused<112, 36, 512, 8, true>), 112, 36, 512, "smooth<112,36,512> p5, the box's halo, no box", 5, 0);
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p0+box", 0, 1);
+            run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, "smooth<112,36,512> p0", 0, 0);
+            for (int P = 1; P <= 7; P++) {   // the cost of a launch over its halo: P passes without the box (halo P), with the box (halo P + 2), and with the box's halo alone
+                char nm[96];
+                snprintf(nm, sizeof nm, "  P=%d no box (halo %d)", P, P);
+                run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, nm, P, 0);
+                if (P <= 5) {
+                    snprintf(nm, sizeof nm, "  P=%d + box (halo %d)", P, P + 2);
+                    run((k_smooth_fused<112, 36, 512, 0, true>), 112, 36, 512, nm, P, 1);
+                    snprintf(nm, sizeof nm, "  P=%d, halo %d, no box", P, P + 2);
+                    run((k_smooth_fused<112, 36, 512, 8, true>), 112, 36, 512, nm, P, 0);
+                }
+            }
             // occupancy: three workgroups per CU (LDS 53.8 KB each) -- eight waves each at <= 80 VGPRs, or four waves each
             run((k_smooth_fused<112, 21, 512, 0, true, 6>), 112, 21, 512, "smooth<112,21,512> occ 6 (3 WG/CU) p5+box");
             run((k_smooth_fused<112, 21, 512, 0, true, 4>), 112, 21, 512, "smooth<112,21,512> occ 4 (2 WG/CU) p5+box");

@@ -993,6 +993,9 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
 }
 
 __device__ int smooth_phase_sleep = 0;  // (development, VAR & 16: tools/kbench mode 20)
+#ifndef SMOOTH_FILL_ALL
+#define SMOOTH_FILL_ALL 1  // 0: round 4's load phase (cells outside the needed halo stay unwritten); tools/kbench A/B only
+#endif
 // OCC (development, tools/kbench mode 20): waves per SIMD the register allocation is held to (0 = the product's NT / 128)
 template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false, int OCC = 0>
 __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
@@ -1052,13 +1055,19 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void 
             const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
             v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
             v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
-            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 0.0f;
+            v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 1.0f;
         }
+        // EVERY cell of the region is written, the ones outside the needed halo with (0, 0, confidence 1) (round 5).  A pass works on whole
+        // quads: with a halo of 6 or 7 (five passes + the box: every iteration's last launch) the outermost quads of a row straddle the
+        // needed region, and their outer pixels -- whose results nobody reads -- used to be computed on never-written LDS: a sum of
+        // confidences of 0 there failed div3_shared_ok, so EVERY wave redid its rows with the literal division in the first one or two
+        // passes of such a launch: 78 of 274 us at level 0 (tools/kbench mode 20, profiles/r05_kbench_smooth_halo.txt).  A defined,
+        // in-range confidence in those cells keeps their (unused) denominators in range; no value any valid pixel reads changes.
 #pragma unroll
         for (int u = 0; u < NLD; u++) {
             const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
-            if (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h)) {
+            if (SMOOTH_FILL_ALL ? r < LHr : (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h))) {
                 f0[r * LW + c] = v[u][0];
                 f1[r * LW + c] = v[u][1];
                 f2[r * LW + c] = v[u][2];
