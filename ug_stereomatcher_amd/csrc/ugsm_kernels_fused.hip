@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 // global stores are issued -- by then they have long arrived, and the stores themselves are never waited for.
 template <int STX, int STY, int NT, int VAR, bool FIXH, bool PIPE = false>
 __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f1, float *const f2, float *__restrict__ o3, const int W, const int H, const int P,
-                                                 const int do_box, const int tile_x, const int tile_y, const int sty)
+                                                 const int do_box, const int tile_x, const int tile_y, const int sty, const bool pf_tile = false)
 {
     constexpr int HX = 8, HY = 7;
     constexpr int RWID = STX + 2 * HX;       // region width (multiple of 4)
@@ -736,6 +736,16 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
     // (VAR & 2, development: the earlier per-pixel selects.)
     const bool edge_e = x0 + RWID > W, edge_s = y0 + LHr > H, edge_nw = x0 <= 0 || y0 <= 0;
 
+    // PRODUCT FORM (round 5; pf_tile, interior tiles of the product kernel): between the passes LDS holds (dx*kappa, dy*kappa, kappa) instead of
+    // (dx, dy, kappa).  smoothKernel weights every neighbour's dx and dy with that neighbour's own confidence (MatchLib.cu:1108-1139): the
+    // product v*kappa of a pixel enters the stencils of its five neighbours, i.e. it used to be formed five times per pass -- 15
+    // multiplications per pixel and pass for the three fields.  Formed ONCE, when the pixel's new value is written back (2 multiplications;
+    // kappa*kappa is still formed where it is used), they are the same binary32 numbers -- RN(dx*kappa) of the same two operands -- added in the
+    // same order centre, W, E, N, S onto the same leading 0: 7 multiplications instead of 15, bit for bit.  The last pass writes plain values
+    // back (the box and the copy-out read those).  Tiles that touch the frame keep the plain form: their pass-through cells (row 0 /
+    // column 0) must come out as they went in, and a product cannot be divided back.
+    auto run_passes = [&](auto pf_tag) {
+    constexpr bool PF = decltype(pf_tag)::value;
     for (int p = 1; p <= P; p++) {
         // pass p is needed (and valid) on the region shrunk to halo h-p -- and inside the image: cells above / left of / below /
         // right of it are never read by an in-image pixel (the replica row H and column W are re-established after every
@@ -777,11 +787,19 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
 #pragma unroll
                 for (int f = 0; f < 3; f++) {
                     float a = 0.0f;
-                    a = c4[f][i] * wc + a;
-                    a = vw[f] * ww + a;
-                    a = ve[f] * we + a;
-                    a = n4[f][i] * wn + a;
-                    a = vs[f] * ws + a;
+                    if (PF && f < 2) {  // the neighbours' products, formed when they were written
+                        a = c4[f][i] + a;
+                        a = vw[f] + a;
+                        a = ve[f] + a;
+                        a = n4[f][i] + a;
+                        a = vs[f] + a;
+                    } else {
+                        a = c4[f][i] * wc + a;
+                        a = vw[f] * ww + a;
+                        a = ve[f] * we + a;
+                        a = n4[f][i] * wn + a;
+                        a = vs[f] * ws + a;
+                    }
                     acc[f] = a;
                 }
                 if constexpr (LIT) {
@@ -793,7 +811,11 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
                 }
 #pragma unroll
                 for (int f = 0; f < 3; f++) nv[u][f][i] = (!EDGE || act) ? qf[f] : c4[f][i];
-                __builtin_amdgcn_sched_barrier(0);  // keep the binary64 temporaries of one pixel at a time
+#ifndef SMOOTH_PIX_ILP
+#define SMOOTH_PIX_ILP 1
+#endif
+                // keep the binary64 temporaries of one pixel at a time (SMOOTH_PIX_ILP = 2, 4: of two / four pixels -- tools/kbench A/B)
+                if ((i + 1) % SMOOTH_PIX_ILP == 0) __builtin_amdgcn_sched_barrier(0);
             }
             return ok;
         };
@@ -838,7 +860,7 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
                     err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
                     quad_row(u, gy, c4r, n4r, s4r, wlr, err, std::true_type{});
                 }
-                if (!(VAR & 2) && edge_nw && col_on) {  // row 0 / column 0 (and anything left / above the image) keeps its value
+                if (!PF && !(VAR & 2) && edge_nw && col_on) {  // row 0 / column 0 (and anything left / above the image) keeps its value
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         if (gy <= 0 || gx0 + i <= 0) {
@@ -855,6 +877,13 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
             const int r = r_lo + rg + u * RG;
             if (col_on && r < r_hi) {
                 const int at = r * LW + c0;
+                if (PF && p < P) {  // what the next pass reads: the pixels' weighted terms (formed here, off the division chains)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        nv[u][0][i] = nv[u][0][i] * nv[u][2][i];
+                        nv[u][1][i] = nv[u][1][i] * nv[u][2][i];
+                    }
+                }
                 st4(f0 + at, nv[u][0]); st4(f1 + at, nv[u][1]); st4(f2 + at, nv[u][2]);
             }
         }
@@ -875,6 +904,13 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
             __syncthreads();
         }
     }
+    };  // run_passes
+#if defined(SMOOTH_PF_ONLY) && SMOOTH_PF_ONLY  // (timing experiment only: every tile in product form, frame tiles wrong at row 0 / column 0)
+    run_passes(std::true_type{});
+#else
+    if (pf_tile) run_passes(std::true_type{});
+    else run_passes(std::false_type{});
+#endif
 
     if (do_box) {
         // refresh the clamped replicas of out-of-image cells within tile+-2 (only edge tiles have any)
@@ -996,6 +1032,9 @@ __device__ int smooth_phase_sleep = 0;  // (development, VAR & 16: tools/kbench 
 #ifndef SMOOTH_FILL_ALL
 #define SMOOTH_FILL_ALL 1  // 0: round 4's load phase (cells outside the needed halo stay unwritten); tools/kbench A/B only
 #endif
+#ifndef SMOOTH_PRODUCT_FORM
+#define SMOOTH_PRODUCT_FORM 0  // 1: product form (measured slower, profiles/r05_kbench_smooth_product_form.txt); 0: plain (dx, dy, kappa) in LDS in every tile (rounds 1-4); tools/kbench A/B only
+#endif
 // OCC (development, tools/kbench mode 20): waves per SIMD the register allocation is held to (0 = the product's NT / 128)
 template <int STX, int STY, int NT, int VAR = 0, bool FIXH = false, int OCC = 0>
 __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void k_smooth_fused(const float *__restrict__ s3, float *__restrict__ o3, int W, int H, int P, int do_box,
@@ -1037,6 +1076,12 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void 
     const int x0 = tx0 - HX, y0 = ty0 - HY;  // global coords of LDS (0,0)
     const size_t n = (size_t)W * H;
     const int h = P + ((do_box || (VAR & 8)) ? 2 : 0);  // halo actually needed (VAR & 8: development, the box's halo without the box)
+    // product form between the passes (smooth_tile_body): interior tiles of the product kernel
+#if defined(SMOOTH_PF_ONLY) && SMOOTH_PF_ONLY
+    const bool pf = true;
+#else
+    const bool pf = SMOOTH_PRODUCT_FORM && VAR == 0 && P >= 1 && x0 > 0 && y0 > 0 && x0 + RWID <= W && y0 + LHr <= H;
+#endif
 
     // ---- load tile + needed halo (clamped onto the image): every global load of the thread is issued
     // before the first LDS store (a rolled loop waits out one HBM round trip per 512 pixels) ------------
@@ -1068,15 +1113,15 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void 
             const int it = tid + u * NT;
             const int r = it / RWID, c = it - r * RWID;
             if (SMOOTH_FILL_ALL ? r < LHr : (r >= r_lo && r < r_hi && c >= HX - h && c < RWID - (HX - h))) {
-                f0[r * LW + c] = v[u][0];
-                f1[r * LW + c] = v[u][1];
+                f0[r * LW + c] = pf ? v[u][0] * v[u][2] : v[u][0];
+                f1[r * LW + c] = pf ? v[u][1] * v[u][2] : v[u][1];
                 f2[r * LW + c] = v[u][2];
             }
         }
     }
     __syncthreads();
 
-    smooth_tile_body<STX, STY, NT, VAR, FIXH>(f0, f1, f2, o3, W, H, P, do_box, tile_x, tile_y, sty);
+    smooth_tile_body<STX, STY, NT, VAR, FIXH>(f0, f1, f2, o3, W, H, P, do_box, tile_x, tile_y, sty, pf);
 }
 
 #ifdef UGSM_DEV_LIB  // k_smooth_pipe: built, bit-exact, measured 17-20 % SLOWER than k_smooth_fused (profiles/r04_kbench_smooth_pipe.txt) -- libugsm_dev.so / tools only
