@@ -10,6 +10,7 @@
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_march4.hip"
 #include "../ug_stereomatcher_amd/csrc/ugsm_kernels_small.hip"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <chrono>
@@ -244,7 +245,11 @@ int main(int argc, char **argv)
         launch_cost_march(st, iL, iR, A, d, o, W, H, 0.55f, 1, 0, 1, 0, rb);
         CK(hipStreamSynchronize(st));
         CK(hipMemcpy(ha.data(), o, 12 * n, hipMemcpyDeviceToHost));
-        const int shares[][2] = {{0, 0}, {420, 350}, {450, 340}, {440, 360}, {460, 350}, {470, 340}, {480, 340}, {450, 360}, {470, 360}, {500, 320}, {480, 330}, {460, 330}, {430, 370}};
+        std::vector<std::array<int, 2>> shares = {{0, 0}, {420, 350}, {450, 340}, {440, 360}, {460, 350}, {470, 340}, {480, 340}, {450, 360}, {470, 360}, {500, 320}, {480, 330}, {460, 330}, {430, 370}};
+        if (argc > 6) {  // kbench W H reps 12 a0 b0 a1 b1 ...: the shares to sweep
+            shares.clear();
+            for (int i = 5; i + 1 < argc; i += 2) shares.push_back({atoi(argv[i]), atoi(argv[i + 1])});
+        }
         for (auto &sh : shares) {
             march_age_permille[0] = sh[0]; march_age_permille[1] = sh[1];
             CK(hipMemset(o2, 0xff, 12 * n));
