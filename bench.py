@@ -276,10 +276,14 @@ def main():
     ring = [torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(cap)]
     offsets = ud.fovea_window_offsets(n_gpus, W, H, fw, fh)
     my_off = offsets[rank % len(offsets)]
+    # ranks RCCL itself counts (an all-reduce of ones), so that a multi-GPU run shows how many ranks the collective library really saw:
+    # fovea-shard -- the LIBRARY's communicator (ugsm_shard_count_ranks; rank 0 makes the id, torch.distributed's control plane hands it
+    # round, out of band, once); the other workloads -- torch.distributed's, when its backend is nccl (= RCCL; None over gloo / one process)
     rccl_ranks = None
     if mode == "fovea-shard":
-        # the library's own communicator: rank 0 makes the id, torch.distributed's control plane hands it round (out of band, once)
         rccl_ranks = ud.shard_init(ctx, rank, n_gpus)
+    elif ud.backend() == "nccl":
+        rccl_ranks = int(round(ud.sum_over_ranks(1.0, dev)))
     torch.cuda.synchronize()
 
     done = []   # completions of the region being timed, in enqueue order (ugsm_completion: tag, call_index, call_pairs, done_ns)
@@ -387,7 +391,8 @@ def main():
                                 else "ugsm_submit_fovea_shard on the slots in rotation (ncclBroadcast on the slot's stream, inside the library)"},
         # the calls the LIBRARY formed from the timed region's pairs (ugsm_completion.call_pairs), e.g. [4, 5, 7, 4] for 20 steps
         "calls_formed_by_the_library": timed_calls if len(timed_calls) <= 16 else {"calls": len(timed_calls), "head": timed_calls[:6], "tail": timed_calls[-6:]},
-        # ranks the library's own RCCL communicator counts (ncclAllReduce of ones; fovea-shard only): = n_gpus when RCCL really spans them
+        # ranks RCCL counts by an all-reduce of ones (fovea-shard: the library's own communicator; else torch.distributed's nccl group; None
+        # without one): = n_gpus when RCCL really spans them
         "rccl_ranks": rccl_ranks,
         "value_repeats": repeats,
         # this rank's pairs/s between the completions of pair slots + 1 and pair steps - slots, inside the same timed regions as `value`

@@ -56,6 +56,11 @@ def _coll_device(device=None):
     return device or "cuda"
 
 
+def backend():
+    """The process group's backend ("nccl" = RCCL on ROCm, "gloo"), or None without one."""
+    return dist.get_backend() if dist.is_initialized() else None
+
+
 def shard_pairs(n_pairs: int, rank: int, world: int):
     """Pairs handled by `rank`: r, r+world, ... (independent pairs, no collective)."""
     return list(range(rank, n_pairs, world))
