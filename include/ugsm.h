@@ -95,8 +95,12 @@ typedef struct ugsm_config {
                              queues well and no more, so a throughput host uses streams = 4 and slots = 8: a
                              stream's next pair is already enqueued when the one before it ends.  ugsm_wait(slot) still waits for
                              that slot's pair only. */
-    int batch;            /* pairs per ugsm_submit_*_batch call the context expects (1 .. UGSM_MAX_BATCH; 0 = 1).  A hint: buffers grow on
-                             demand to whatever a call brings; ugsm_plan_level reports the kernels of a call of this many pairs. */
+    int batch;            /* pairs per ugsm_submit_*_batch call the context expects (1 .. UGSM_MAX_BATCH; 0 = 1), and the size of the calls the
+                             queue forms (ugsm_enqueue_*).  A slot's buffers are sized for it on first use (slots x batch x 1.35 GB at 16 MP,
+                             ugsm_context_device_bytes) so that no reallocation lands between calls of different sizes; if that much memory
+                             cannot be had the slot is sized for the call at hand instead, and a call that fits by itself still runs
+                             (UGSM_ERR_NOMEM only if even that fails; a refused call leaves no buffer behind).  ugsm_plan_level reports the
+                             kernels of a call of this many pairs. */
     int stream_priority;  /* HIP priority of the slots' streams.  0 (default): a pool of their own -- slots 0-3 at the GREATEST priority,
                              4-7 at the least, the rest at the process default: HIP deals streams onto 4 hardware queues PER PRIORITY
                              LEVEL, and two streams on one queue run strictly one after the other, so slots that share the default
