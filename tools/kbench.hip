@@ -28,11 +28,12 @@ int main(int argc, char **argv)
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
     for (size_t i = 0; i < 3 * n; i++) { hL[i] = 1 + 254 * rnd(); hR[i] = 1 + 254 * rnd(); }
     for (size_t i = 0; i < n; i++) { int x = i % W, y = i / W; hd[i] = 30.0f * sinf(x * 0.002f) * cosf(y * 0.003f) + 0.3f * (rnd() - 0.5f); hd[n + i] = 0.75f * sinf(y * 0.002f) + 0.3f * (rnd() - 0.5f); hd[2 * n + i] = 0.3f + 0.7f * rnd(); }
-    if (argc > 5 && atoi(argv[4]) < 2) {  // real data: 9 planes of W*H floats (L0 L1 L2 R0 R1 R2 dx dy conf), e.g. from tools/kbench_real.py
-        FILE *f = fopen(argv[5], "rb");
-        if (!f || fread(hL.data(), 4, 3 * n, f) != 3 * n || fread(hR.data(), 4, 3 * n, f) != 3 * n || fread(hd.data(), 4, 3 * n, f) != 3 * n) { printf("cannot read %s\n", argv[5]); return 1; }
+    const char *data_file = getenv("KBENCH_DATA") ? getenv("KBENCH_DATA") : ((argc > 5 && atoi(argv[4]) < 2) ? argv[5] : nullptr);
+    if (data_file) {  // real data: 9 planes of W*H floats (L0 L1 L2 R0 R1 R2 dx dy conf), e.g. from tools/kbench_real.py (any mode: KBENCH_DATA=file)
+        FILE *f = fopen(data_file, "rb");
+        if (!f || fread(hL.data(), 4, 3 * n, f) != 3 * n || fread(hR.data(), 4, 3 * n, f) != 3 * n || fread(hd.data(), 4, 3 * n, f) != 3 * n) { printf("cannot read %s\n", data_file); return 1; }
         fclose(f);
-        printf("inputs from %s\n", argv[5]);
+        printf("inputs from %s\n", data_file);
     }
     float *L, *R, *A, *d, *o;
     CK(hipMalloc(&L, 12 * n)); CK(hipMalloc(&R, 12 * n)); CK(hipMalloc(&A, 12 * n)); CK(hipMalloc(&d, 12 * n)); CK(hipMalloc(&o, 12 * n));
