@@ -694,6 +694,9 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #ifndef UGSM_SMOOTH_PAD
 #define UGSM_SMOOTH_PAD(STX) ((STX) == 112 ? 0 : 4)
 #endif
+#ifndef SMOOTH_FUSE_BOX_ROWS
+#define SMOOTH_FUSE_BOX_ROWS 0  // 1: measured, no gain at P = 5 (profiles/r05_kbench_smooth_product_form.txt); 0: the box's row pass as a phase of its own after the last pass (rounds 1-4); tools/kbench A/B
+#endif
 // FIXH: the tile is STY rows high whatever `sty_arg` says -- the height folds into the loop bounds, 2 % faster at level 0 than the
 // same kernel with the height in a register (208 against 212.5 us); the launcher picks it whenever the height is STY.
 // The passes, the box and the copy-out of ONE tile whose region (tile + halo, clamped onto the image) is in LDS at f0 / f1 / f2 -- shared by
@@ -744,6 +747,13 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
     // same order centre, W, E, N, S onto the same leading 0: 7 multiplications instead of 15, bit for bit.  The last pass writes plain values
     // back (the box and the copy-out read those).  Tiles that touch the frame keep the plain form: their pass-through cells (row 0 /
     // column 0) must come out as they went in, and a product cannot be divided back.
+    // ROW PASS OF THE BOX FUSED INTO THE LAST JACOBI PASS (round 5; SMOOTH_FUSE_BOX_ROWS): the last pass produces exactly the rows and columns
+    // the box's row pass reads (tile +- 2), a quad per lane with the neighbouring quads of the row in the neighbouring lanes -- so the row
+    // pass is formed from registers (four DPP moves per plane) when the pass writes back, instead of after another LDS round trip and two
+    // more barriers.  Same box5f on the same values.  Interior tiles only: on the frame the box reads clamped replicas that are rebuilt
+    // in LDS first.
+    const bool fuse_box_rows = SMOOTH_FUSE_BOX_ROWS && VAR == 0 && !PIPE && do_box && P >= 1 && !edge_e && !edge_s && !edge_nw && tx0 - 2 >= 0 && ty0 - 2 >= 0 &&
+                               tx0 + STX + 2 <= W && ty0 + sty + 2 <= H;
     auto run_passes = [&](auto pf_tag) {
     constexpr bool PF = decltype(pf_tag)::value;
     for (int p = 1; p <= P; p++) {
@@ -872,6 +882,26 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
             __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
         }
         __syncthreads();
+        if (fuse_box_rows && p == P) {
+#pragma unroll
+            for (int u = 0; u < MAXR; u++) {
+                const int r = r_lo + rg + u * RG;
+                if (lane_on && r < r_hi) {  // (every lane of the row: the neighbouring quads' values come through DPP)
+                    float rb[3][4];
+#pragma unroll
+                    for (int f = 0; f < 3; f++) {
+                        const float x[8] = {lane_below(nv[u][f][2]), lane_below(nv[u][f][3]), nv[u][f][0], nv[u][f][1], nv[u][f][2], nv[u][f][3],
+                                            lane_above(nv[u][f][0]), lane_above(nv[u][f][1])};
+#pragma unroll
+                        for (int i = 0; i < 4; i++) rb[f][i] = box5f(x[i], x[i + 1], x[i + 2], x[i + 3], x[i + 4]);
+                    }
+                    if (c0 >= HX && c0 < HX + STX) {  // tile columns: what the column pass reads
+                        const int at = r * LW + c0;
+                        st4(f0 + at, rb[0]); st4(f1 + at, rb[1]); st4(f2 + at, rb[2]);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int u = 0; u < MAXR; u++) {
             const int r = r_lo + rg + u * RG;
@@ -929,6 +959,7 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
         constexpr int BQ = STX / 4, BRG = NT / BQ, BMAXR = (STY + 4 + BRG - 1) / BRG;
         const int bq = tid % BQ, brg = tid / BQ;
         const int bc0 = HX + bq * 4;
+        if (!fuse_box_rows) {  // (else: done by the last pass, from registers)
         float bv[BMAXR][3][4];
 #pragma unroll
         for (int u = 0; u < BMAXR; u++) {
@@ -955,6 +986,7 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
             }
         }
         __syncthreads();
+        }
         // columns (Ta) into registers, then back to LDS and out with lanes along the rows: a quad-per-lane
         // store touches one 16-B piece per lane (4 instructions per 1-KiB row segment); the copy-out below
         // writes whole contiguous segments
