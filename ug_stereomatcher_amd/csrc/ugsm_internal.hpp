@@ -7,6 +7,8 @@
 
 #include <stddef.h>
 
+#include <new>
+
 namespace ugsm {
 
 // State the layers hang on a context; the runtime owns the storage and calls the `free` hooks from ugsm_destroy (before the slots go).
@@ -28,5 +30,18 @@ void ctx_host_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes);
 bool host_pinned(const void *p);
 // the stagger of the queue's first round after idle and the size of every later call (ugsm.h, "the queue")
 int queue_target(int batch, int slots, long long calls_since_idle);
+
+// The body of a C entry point that uses growing containers: nothing is thrown across the C-ABI.
+template <class F>
+int no_throw(ugsm_ctx *ctx, const char *entry, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return ctx ? ctx_fail(ctx, UGSM_ERR_NOMEM, entry) : UGSM_ERR_NOMEM;
+    } catch (...) {
+        return ctx ? ctx_fail(ctx, UGSM_ERR_STATE, entry) : UGSM_ERR_STATE;
+    }
+}
 
 }  // namespace ugsm

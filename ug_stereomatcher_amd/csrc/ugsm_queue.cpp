@@ -297,14 +297,16 @@ int room(ugsm_ctx *ctx, const Queue *q)
 
 int enqueue(ugsm_ctx *ctx, Item it)
 {
-    Queue *q = queue_of(ctx);
-    if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_enqueue_*: out of host memory");
-    const int r = room(ctx, q);
-    if (r != UGSM_OK) return r;
-    it.seq = ++q->seq;
-    q->waiting.push_back(it);
-    ctx_hooks(ctx).queue_busy = true;
-    return pump(ctx, q, true);
+    return no_throw(ctx, "ugsm_enqueue_*: out of host memory", [&]() -> int {
+        Queue *q = queue_of(ctx);
+        if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_enqueue_*: out of host memory");
+        const int r = room(ctx, q);
+        if (r != UGSM_OK) return r;
+        it.seq = ++q->seq;
+        q->waiting.push_back(it);
+        ctx_hooks(ctx).queue_busy = true;
+        return pump(ctx, q, true);
+    });
 }
 
 // a managed buffer with room for `in_bytes` of images and `out_floats` of results
@@ -365,8 +367,12 @@ int enqueue_managed(ugsm_ctx *ctx, int mode, const uint8_t *rgbL, const uint8_t 
         plane = (size_t)cfg.fovea_levels * fw * fh;
         out_floats = 3 * plane + (want_pyr ? 6 * plane : 0);
     }
-    const int idx = managed_get(ctx, q, 2 * img, out_floats);
-    if (idx < 0) return UGSM_ERR_NOMEM;  // (ugsm_host_alloc has set the message)
+    int idx = -1;
+    const int grown = no_throw(ctx, "ugsm_enqueue_*_managed: out of host memory", [&]() -> int {
+        idx = managed_get(ctx, q, 2 * img, out_floats);
+        return UGSM_OK;
+    });
+    if (grown != UGSM_OK || idx < 0) return UGSM_ERR_NOMEM;  // (ugsm_host_alloc has set the message)
     Managed &m = q->pool[(size_t)idx];
     // the images, compacted to rows of 3 W bytes, into the staging buffer: after this the caller's memory is not touched again
     for (int side = 0; side < 2; side++) {
@@ -396,6 +402,45 @@ int enqueue_managed(ugsm_ctx *ctx, int mode, const uint8_t *rgbL, const uint8_t 
     it.tag = tag;
     it.managed = idx;
     return enqueue(ctx, it);
+}
+
+int next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
+{
+    Queue *q = queue_of(ctx);
+    if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_next_done: out of host memory");
+    for (int idx : q->lent) q->pool[(size_t)idx].busy = false;  // what the previous call lent comes back
+    q->lent.clear();
+    if (block && q->flush_upto != q->seq) {
+        q->flush_upto = q->seq;
+        q->round_restarts = true;
+    }
+    for (;;) {
+        reap(ctx, q);
+        (void)pump(ctx, q, false);  // (a slot may just have come free for pairs that wait)
+        if (!q->done.empty()) break;
+        if (q->flight.empty() && q->waiting.empty()) {
+            update_busy(ctx, q);
+            return UGSM_EMPTY;
+        }
+        if (!block) {
+            update_busy(ctx, q);
+            return UGSM_PENDING;
+        }
+        if (q->flight.empty()) {
+            // pairs wait and no call is in flight, yet pump sent nothing: cannot happen (every slot is free); do not spin
+            update_busy(ctx, q);
+            return ctx_fail(ctx, UGSM_ERR_STATE, "ugsm_next_done: the queue cannot make progress");
+        }
+        wait_front(ctx, q);
+    }
+    *out = q->done.front();
+    q->done.pop_front();
+    const int m = q->done_managed.front();
+    q->done_managed.erase(q->done_managed.begin());
+    if (m >= 0) q->lent.push_back(m);
+    // (pairs that waited for room may go out now; the slot-level entry points open up again once nothing is outstanding)
+    (void)pump(ctx, q, false);
+    return UGSM_OK;
 }
 
 }  // namespace
@@ -549,51 +594,19 @@ int ugsm_enqueue_foveated_managed(ugsm_ctx *ctx, const uint8_t *rgbL, const uint
 int ugsm_flush(ugsm_ctx *ctx)
 {
     if (!ctx) return UGSM_ERR_BAD_ARG;
-    Queue *q = queue_of(ctx);
-    if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_flush: out of host memory");
-    q->flush_upto = q->seq;
-    q->round_restarts = true;
-    return pump(ctx, q, false);
+    return no_throw(ctx, "ugsm_flush: out of host memory", [&]() -> int {
+        Queue *q = queue_of(ctx);
+        if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_flush: out of host memory");
+        q->flush_upto = q->seq;
+        q->round_restarts = true;
+        return pump(ctx, q, false);
+    });
 }
 
 int ugsm_next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
 {
     if (!ctx || !out) return UGSM_ERR_BAD_ARG;
-    Queue *q = queue_of(ctx);
-    if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_next_done: out of host memory");
-    for (int idx : q->lent) q->pool[(size_t)idx].busy = false;  // what the previous call lent comes back
-    q->lent.clear();
-    if (block && q->flush_upto != q->seq) {
-        q->flush_upto = q->seq;
-        q->round_restarts = true;
-    }
-    for (;;) {
-        reap(ctx, q);
-        (void)pump(ctx, q, false);  // (a slot may just have come free for pairs that wait)
-        if (!q->done.empty()) break;
-        if (q->flight.empty() && q->waiting.empty()) {
-            update_busy(ctx, q);
-            return UGSM_EMPTY;
-        }
-        if (!block) {
-            update_busy(ctx, q);
-            return UGSM_PENDING;
-        }
-        if (q->flight.empty()) {
-            // pairs wait and no call is in flight, yet pump sent nothing: cannot happen (every slot is free); do not spin
-            update_busy(ctx, q);
-            return ctx_fail(ctx, UGSM_ERR_STATE, "ugsm_next_done: the queue cannot make progress");
-        }
-        wait_front(ctx, q);
-    }
-    *out = q->done.front();
-    q->done.pop_front();
-    const int m = q->done_managed.front();
-    q->done_managed.erase(q->done_managed.begin());
-    if (m >= 0) q->lent.push_back(m);
-    // (pairs that waited for room may go out now; the slot-level entry points open up again once nothing is outstanding)
-    (void)pump(ctx, q, false);
-    return UGSM_OK;
+    return no_throw(ctx, "ugsm_next_done: out of host memory", [&]() -> int { return next_done(ctx, out, block); });
 }
 
 int ugsm_queue_depth(ugsm_ctx *ctx, int *waiting, int *in_flight, int *unreported)

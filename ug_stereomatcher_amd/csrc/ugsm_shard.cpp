@@ -311,9 +311,12 @@ int ugsm_shard_gather(ugsm_ctx *ctx, int slot, const float *d_stack, long long s
         return ctx_fail(ctx, UGSM_ERR_DEVICE, "ugsm_shard_gather: device copy failed");
     if (s->world > 1) {
         NCHK(ctx, r->GroupStart());
-        for (int p = 0; p < s->world; p++)
-            if (p != dst_rank) NCHK(ctx, r->Recv(d_all + (size_t)p * n, n, ncclFloat, p, s->comm, stream));
-        NCHK(ctx, r->GroupEnd());
+        ncclResult_t bad = ncclSuccess;  // (the group is closed whatever a receive answers)
+        for (int p = 0; p < s->world && bad == ncclSuccess; p++)
+            if (p != dst_rank) bad = r->Recv(d_all + (size_t)p * n, n, ncclFloat, p, s->comm, stream);
+        const ncclResult_t end = r->GroupEnd();
+        if (bad != ncclSuccess) return nccl_fail(ctx, "ncclRecv", bad);
+        NCHK(ctx, end);
     }
     return UGSM_OK;
 }
