@@ -99,12 +99,46 @@ constexpr int BODY = 512;
 #define B_MIX_RCP1_FMA3(i) B_RCP(i) M_FMA(i, 4) M_FMA(i, 8) M_FMA(i, 12)
 #define B_MIX_MAX1_ADD3(i) B_MAX(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
 #define B_MIX_SNOP1_ADD3(i) B_SNOP(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
-#define B_MIX_SALU1_ADD3(i) asm volatile("s_add_u32 s20, s20, 1" ::: "s20"); M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define B_MIX_SALU1_ADD3(i) asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc");  /* (s_add writes SCC: without the clobber the loop latch read it and the kernel never ended) */ M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
 #define B_MIX_F64_FMA3(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(ACC(i, 0))); M_FMA(i, 4) M_FMA(i, 8) M_FMA(i, 12)
 // dependent chains (latency, not throughput): four instructions in a row on ONE accumulator
 #define B_DEP_ADD4(i) B_ADD(i) B_MUL(i) B_ADD(i) B_MUL(i)
 #define B_DEP_DPP4(i) B_ADDDPP(i) B_ADDDPP(i) B_ADDDPP(i) B_ADDDPP(i)
 
+// grouped mixes (round 5): the same 1 : 3 proportion as the rows above, but the slow instructions in runs of 4 or 16 followed by their 12 or 48
+// plain ones -- does the ORDER of a mix matter, i.e. is the cost of a slow instruction among plain ones a switching cost?
+#define RUN16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)  // (REP16 cannot expand inside itself)
+#define P3(i, k) M_ADD(i, k) M_MUL(i, (k) + 1) M_ADD(i, (k) + 2)
+#define B_G4_DPP(i) if constexpr ((i) % 4 == 0) { B_ADDDPP(i) B_ADDDPP((i) + 1) B_ADDDPP((i) + 2) B_ADDDPP((i) + 3) P3(i, 4) P3(i, 7) P3(i, 10) P3(i, 13) }
+#define B_G16_DPP(i) if constexpr ((i) == 0) { RUN16(B_ADDDPP) RUN16(B_ADD) RUN16(B_MUL) RUN16(B_ADD) }
+#define F3(i, k) M_FMA(i, k) M_FMA(i, (k) + 1) M_FMA(i, (k) + 2)
+#define B_G4_RCP(i) if constexpr ((i) % 4 == 0) { B_RCP(i) B_RCP((i) + 1) B_RCP((i) + 2) B_RCP((i) + 3) F3(i, 4) F3(i, 7) F3(i, 10) F3(i, 13) }
+#define B_G16_RCP(i) if constexpr ((i) == 0) { RUN16(B_RCP) RUN16(B_FMA) RUN16(B_FMA) RUN16(B_FMA) }
+#define B_CVT(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
+#define B_G4_CVT(i) if constexpr ((i) % 4 == 0) { B_CVT(i) B_CVT((i) + 1) B_CVT((i) + 2) B_CVT((i) + 3) F3(i, 4) F3(i, 7) F3(i, 10) F3(i, 13) }
+#define B_G16_CVT(i) if constexpr ((i) == 0) { RUN16(B_CVT) RUN16(B_FMA) RUN16(B_FMA) RUN16(B_FMA) }
+#define B_MIX_CMP1_ADD3(i) B_CMP(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define B_G16_CMP(i) if constexpr ((i) == 0) { RUN16(B_CMP) RUN16(B_ADD) RUN16(B_MUL) RUN16(B_ADD) }
+// alternating 1 : 1
+#define B_ALT_DPP_ADD(i) if constexpr ((i) % 2 == 0) { B_ADDDPP(i) } else { B_ADD(i) }
+#define B_ALT_FMA_ADD(i) if constexpr ((i) % 2 == 0) { B_FMA(i) } else { B_ADD(i) }
+// the neighbouring lane's value through the LDS crossbar instead of DPP (round 5): ds_bpermute_b32 + the plain consumer.  a[i] comes back
+// asynchronously (lgkmcnt, in order); its next use is 12 slots later, so at most 11 newer ones may be outstanding there.
+#define B_BPERM(i) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(a[i]) : "v"(baddr));
+#define B_MIX_BPERM1_ADD3(i) B_BPERM(i) asm volatile("s_waitcnt lgkmcnt(11)"); M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define B_MIX_BPERM1_ADD4(i) B_BPERM(i) asm volatile("s_waitcnt lgkmcnt(11)"); M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12) M_ADD(i, 5)
+#define B_MIX_DPP1_ADD4(i) B_MOVDPP(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12) M_ADD(i, 5)
+#define DECLFB DECLF; const int baddr = ((threadIdx.x + 63) & 63) * 4
+// which DPP form is the expensive one among plain instructions? (round 5)
+#define B_ADDDPPSELF(i) asm volatile("v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+#define B_MOVDPPT(i) asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(t) : "v"(a[i]));
+#define B_ADDT(i) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(t), "v"(b));
+#define B_MIX_ADDDPP1_ADD4(i) B_ADDDPP(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12) M_ADD(i, 5)
+#define B_MIX_ADDDPPSELF1_ADD4(i) B_ADDDPPSELF(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12) M_ADD(i, 5)
+#define B_MIX_ADDDPPSELF1_ADD3(i) B_ADDDPPSELF(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define B_MIX_MOVDPP1_ADD3(i) B_MOVDPP(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define B_MIX_MOVADD_ADD3(i) B_MOVDPPT(i) B_ADDT(i) M_ADD(i, 4) M_MUL(i, 8) M_ADD(i, 12)
+#define DECLFT DECLF; float t = 0.0f
 KERNEL(k_fma, DECLF, B_FMA, SINKF)
 KERNEL(k_fmac, DECLF, B_FMAC, SINKF)
 KERNEL(k_mul, DECLF, B_MUL, SINKF)
@@ -144,6 +178,25 @@ KERNEL(k_mix_salu1_add3, DECLF, B_MIX_SALU1_ADD3, SINKF)
 KERNEL(k_mix_cvt1_fma3, DECLF, B_MIX_F64_FMA3, SINKF)
 KERNEL(k_dep_add4, DECLF, B_DEP_ADD4, SINKF)
 KERNEL(k_dep_dpp4, DECLF, B_DEP_DPP4, SINKF)
+KERNEL(k_g4_dpp4_add12, DECLF, B_G4_DPP, SINKF)
+KERNEL(k_g16_dpp16_add48, DECLF, B_G16_DPP, SINKF)
+KERNEL(k_g4_rcp4_fma12, DECLF, B_G4_RCP, SINKF)
+KERNEL(k_g16_rcp16_fma48, DECLF, B_G16_RCP, SINKF)
+KERNEL(k_g4_cvt4_fma12, DECLF, B_G4_CVT, SINKF)
+KERNEL(k_g16_cvt16_fma48, DECLF, B_G16_CVT, SINKF)
+KERNEL(k_mix_cmp1_add3, DECLF, B_MIX_CMP1_ADD3, SINKF)
+KERNEL(k_g16_cmp16_add48, DECLF, B_G16_CMP, SINKF)
+KERNEL(k_alt_dpp_add, DECLF, B_ALT_DPP_ADD, SINKF)
+KERNEL(k_alt_fma_add, DECLF, B_ALT_FMA_ADD, SINKF)
+KERNEL(k_mix_bperm1_add3, DECLFB, B_MIX_BPERM1_ADD3, SINKF)
+KERNEL(k_mix_bperm1_add4, DECLFB, B_MIX_BPERM1_ADD4, SINKF)
+KERNEL(k_mix_movdpp1_add4, DECLF, B_MIX_DPP1_ADD4, SINKF)
+KERNEL(k_bperm, DECLFB, B_BPERM, SINKF)
+KERNEL(k_mix_adddpp1_add4, DECLF, B_MIX_ADDDPP1_ADD4, SINKF)
+KERNEL(k_mix_adddppself1_add4, DECLF, B_MIX_ADDDPPSELF1_ADD4, SINKF)
+KERNEL(k_mix_adddppself1_add3, DECLF, B_MIX_ADDDPPSELF1_ADD3, SINKF)
+KERNEL(k_mix_movdpp1_add3, DECLF, B_MIX_MOVDPP1_ADD3, SINKF)
+KERNEL(k_mix_movadd_add3, DECLFT, B_MIX_MOVADD_ADD3, SINKF + t)
 __global__ __launch_bounds__(256) void k_cndmask(float *out, int iters)
 {
     DECLF;
@@ -238,8 +291,21 @@ int main(int argc, char **argv)
     RUN(k_add_dpp_wave_shr) RUN(k_add_dpp_row_shr) RUN(k_mov_dpp) RUN(k_rcp) RUN(k_div_scale) RUN(k_div_fmas) RUN(k_div_fixup)
     RUN(k_fma64) RUN(k_mul64) RUN(k_add64) RUN(k_cvt_f64_f32) RUN(k_cvt_f32_f64) RUN(k_pk_fma) RUN(k_pk_mul) RUN(k_pk_add)
     }
+    const bool only_lds = argc > 2 && argv[2][0] == 'l';
+    if (!only_lds) {
     printf("# mixes: cycles per INSTRUCTION of the group of four (if costs add: (c1 + 3 x c_plain) / 4)\n");
     RUN4(k_mix_dpp1_add3) RUN4(k_mix_rcp1_fma3) RUN4(k_mix_max1_add3) RUN4(k_mix_snop1_add3) RUN4(k_mix_salu1_add3) RUN4(k_mix_cvt1_fma3)
+    printf("# grouped mixes: the slow instructions of a 1 : 3 mix in runs of 4 / 16 (cycles per instruction, as above); 1 : 1 alternations\n");
+    RUN4(k_g4_dpp4_add12) RUN4(k_g16_dpp16_add48) RUN4(k_g4_rcp4_fma12) RUN4(k_g16_rcp16_fma48) RUN4(k_g4_cvt4_fma12) RUN4(k_g16_cvt16_fma48)
+    RUN4(k_mix_cmp1_add3) RUN4(k_g16_cmp16_add48) RUN(k_alt_dpp_add) RUN(k_alt_fma_add)
+    }
+    printf("# lane shift through the LDS crossbar: ds_bpermute_b32 among plain instructions (cycles per instruction of the group; the 1 + 4 rows count 5 per slot)\n");
+    RUN(k_bperm) RUN4(k_mix_bperm1_add3)
+    run("k_mix_bperm1_add4", k_mix_bperm1_add4, 1, 5, warm_s); run("k_mix_bperm1_add4", k_mix_bperm1_add4, 2, 5, warm_s); run("k_mix_bperm1_add4", k_mix_bperm1_add4, 3, 5, 0.3); run("k_mix_bperm1_add4", k_mix_bperm1_add4, 4, 5, 0.3);
+    run("k_mix_movdpp1_add4", k_mix_movdpp1_add4, 1, 5, warm_s); run("k_mix_movdpp1_add4", k_mix_movdpp1_add4, 2, 5, warm_s); run("k_mix_movdpp1_add4", k_mix_movdpp1_add4, 3, 5, 0.3); run("k_mix_movdpp1_add4", k_mix_movdpp1_add4, 4, 5, 0.3);
+    printf("# DPP forms among plain instructions (per instruction; rows _add4 and movadd count 5 per slot)\n");
+#define RUN5(k) run(#k, k, 1, 5, warm_s); run(#k, k, 2, 5, warm_s); run(#k, k, 3, 5, 0.3); run(#k, k, 4, 5, 0.3);
+    RUN5(k_mix_adddpp1_add4) RUN5(k_mix_adddppself1_add4) RUN4(k_mix_adddppself1_add3) RUN4(k_mix_movdpp1_add3) RUN5(k_mix_movadd_add3) RUN4(k_mix_dpp1_add3)
     printf("# dependent chains of four on one accumulator (issue-to-issue latency of dependent instructions)\n");
     RUN4(k_dep_add4) RUN4(k_dep_dpp4)
     return 0;

@@ -694,6 +694,9 @@ __global__ __launch_bounds__(512, WAVES) void k_cost_split(Img3 L, Img3 R, const
 #ifndef UGSM_SMOOTH_PAD
 #define UGSM_SMOOTH_PAD(STX) ((STX) == 112 ? 0 : 4)
 #endif
+#ifndef SMOOTH_NEWTON
+#define SMOOTH_NEWTON 0  // 1: the three quotients of a pixel in binary32 (div3_newton); tools/kbench A/B only
+#endif
 #ifndef SMOOTH_FUSE_BOX_ROWS
 #define SMOOTH_FUSE_BOX_ROWS 0  // 1: measured, no gain at P = 5 (profiles/r05_kbench_smooth_product_form.txt); 0: the box's row pass as a phase of its own after the last pass (rounds 1-4); tools/kbench A/B
 #endif
@@ -773,6 +776,9 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
             const bool row_ok = gy > 0 && gy < H;
             const bool south_in = gy + 1 <= H - 1;
             bool ok = true;
+#if SMOOTH_NEWTON
+            float gmin = 1.0f;
+#endif
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int gx = gx0 + i;
@@ -816,8 +822,13 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
 #pragma unroll
                     for (int f = 0; f < 3; f++) qf[f] = acc[f] / sumCorr;
                 } else {
+#if SMOOTH_NEWTON  // (probe: timing only -- the guard is per quad-row here and covers the outputs, not the inputs)
+                    div3_newton(acc[0], acc[1], acc[2], sumCorr, qf[0], qf[1], qf[2]);
+                    gmin = __builtin_elementwise_minimum(gmin, __builtin_elementwise_minimum(__builtin_fabsf(qf[0]), __builtin_fabsf(qf[1])));
+#else
                     div3_shared(acc[0], acc[1], acc[2], sumCorr, qf[0], qf[1], qf[2]);
                     ok = ok && div3_shared_ok(sumCorr);
+#endif
                 }
 #pragma unroll
                 for (int f = 0; f < 3; f++) nv[u][f][i] = (!EDGE || act) ? qf[f] : c4[f][i];
@@ -827,6 +838,9 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
                 // keep the binary64 temporaries of one pixel at a time (SMOOTH_PIX_ILP = 2, 4: of two / four pixels -- tools/kbench A/B)
                 if ((i + 1) % SMOOTH_PIX_ILP == 0) __builtin_amdgcn_sched_barrier(0);
             }
+#if SMOOTH_NEWTON
+            if constexpr (!LIT) ok = gmin >= 0x1p-40f;
+#endif
             return ok;
         };
 #pragma unroll
@@ -1130,8 +1144,9 @@ __global__ __launch_bounds__(NT, (OCC ? OCC : (NT <= 512 ? NT / 128 : 1))) void 
             // one 32-bit byte offset per pixel against three uniform plane bases (a 64-bit address per load would
             // hold 6 VGPRs per pixel across the whole batch); a plane is < 4 GiB
             const unsigned off = ((unsigned)gy * (unsigned)W + (unsigned)gx) * 4u;
-            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : 0.0f;
-            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : 0.0f;
+            constexpr float fill = SMOOTH_NEWTON ? 1.0f : 0.0f;
+            v[u][0] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3) + off) : fill;
+            v[u][1] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + n) + off) : fill;
             v[u][2] = need ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(s3 + 2 * n) + off) : 1.0f;
         }
         // EVERY cell of the region is written, the ones outside the needed halo with (0, 0, confidence 1) (round 5).  A pass works on whole
