@@ -843,55 +843,61 @@ __device__ __forceinline__ void smooth_tile_body(float *const f0, float *const f
 #endif
             return ok;
         };
+        // one row of the thread: west / east taps, the quad-row, the rare literal redo, the pass-through cells of the frame
+        auto do_row = [&](const int u, const int r, const float (&n4)[3][4], const float (&c4)[3][4], const float (&s4)[3][4]) {
+            const int at = r * LW + c0;
+            float wl[3], er[3];
+            if constexpr (VAR & 4) {
+                float t[4];
+                ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
+                ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
+            } else {
+                // west / east neighbours from the neighbouring lanes' registers instead of LDS (a narrowed,
+                // lane-strided ds_read_b32 there is a 4-way bank conflict).  At q = 0 / QW-1 the value comes
+                // from another row: those are region-edge columns, never valid in any pass.
+#pragma unroll
+                for (int f = 0; f < 3; f++) {
+                    wl[f] = lane_below(c4[f][3]);
+                    er[f] = lane_above(c4[f][0]);
+                }
+            }
+            bool redo = false;
+            const int gy = y0 + r;
+            if (col_on) {
+                if constexpr (VAR & 1) quad_row(u, gy, c4, n4, s4, wl, er, std::true_type{});
+                else redo = !quad_row(u, gy, c4, n4, s4, wl, er, std::false_type{});
+            }
+            if (__builtin_expect(redo, 0)) {
+                // rare: a denominator out of range.  Reload the row (so that nothing has to stay in registers
+                // for this path; LDS still holds the previous pass) and divide literally.
+                float c4r[3][4], n4r[3][4], s4r[3][4], wlr[3], err[3];
+                ld4(f0 + at, c4r[0]); ld4(f1 + at, c4r[1]); ld4(f2 + at, c4r[2]);
+                ld4(f0 + at - LW, n4r[0]); ld4(f1 + at - LW, n4r[1]); ld4(f2 + at - LW, n4r[2]);
+                ld4(f0 + at + LW, s4r[0]); ld4(f1 + at + LW, s4r[1]); ld4(f2 + at + LW, s4r[2]);
+                wlr[0] = f0[at - 1]; wlr[1] = f1[at - 1]; wlr[2] = f2[at - 1];
+                err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
+                quad_row(u, gy, c4r, n4r, s4r, wlr, err, std::true_type{});
+            }
+            if (!PF && !(VAR & 2) && edge_nw && col_on) {  // row 0 / column 0 (and anything left / above the image) keeps its value
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (gy <= 0 || gx0 + i <= 0) {
+#pragma unroll
+                        for (int f = 0; f < 3; f++) nv[u][f][i] = c4[f][i];
+                    }
+            }
+        };
 #pragma unroll
         for (int u = 0; u < MAXR; u++) {
             const int r = r_lo + rg + u * RG;
             if (lane_on && r < r_hi) {
                 // every quad of the row loads (the neighbouring lanes' quads feed the west / east taps)
                 const int at = r * LW + c0;
-                float c4[3][4], n4[3][4], s4[3][4], wl[3], er[3];
+                float c4[3][4], n4[3][4], s4[3][4];
                 ld4(f0 + at, c4[0]); ld4(f1 + at, c4[1]); ld4(f2 + at, c4[2]);
                 ld4(f0 + at - LW, n4[0]); ld4(f1 + at - LW, n4[1]); ld4(f2 + at - LW, n4[2]);
                 ld4(f0 + at + LW, s4[0]); ld4(f1 + at + LW, s4[1]); ld4(f2 + at + LW, s4[2]);
-                if constexpr (VAR & 4) {
-                    float t[4];
-                    ld4(f0 + at - 4, t); wl[0] = t[3]; ld4(f1 + at - 4, t); wl[1] = t[3]; ld4(f2 + at - 4, t); wl[2] = t[3];
-                    ld4(f0 + at + 4, t); er[0] = t[0]; ld4(f1 + at + 4, t); er[1] = t[0]; ld4(f2 + at + 4, t); er[2] = t[0];
-                } else {
-                    // west / east neighbours from the neighbouring lanes' registers instead of LDS (a narrowed,
-                    // lane-strided ds_read_b32 there is a 4-way bank conflict).  At q = 0 / QW-1 the value comes
-                    // from another row: those are region-edge columns, never valid in any pass.
-#pragma unroll
-                    for (int f = 0; f < 3; f++) {
-                        wl[f] = lane_below(c4[f][3]);
-                        er[f] = lane_above(c4[f][0]);
-                    }
-                }
-                bool redo = false;
-                const int gy = y0 + r;
-                if (col_on) {
-                    if constexpr (VAR & 1) quad_row(u, gy, c4, n4, s4, wl, er, std::true_type{});
-                    else redo = !quad_row(u, gy, c4, n4, s4, wl, er, std::false_type{});
-                }
-                if (__builtin_expect(redo, 0)) {
-                    // rare: a denominator out of range.  Reload the row (so that nothing has to stay in registers
-                    // for this path; LDS still holds the previous pass) and divide literally.
-                    float c4r[3][4], n4r[3][4], s4r[3][4], wlr[3], err[3];
-                    ld4(f0 + at, c4r[0]); ld4(f1 + at, c4r[1]); ld4(f2 + at, c4r[2]);
-                    ld4(f0 + at - LW, n4r[0]); ld4(f1 + at - LW, n4r[1]); ld4(f2 + at - LW, n4r[2]);
-                    ld4(f0 + at + LW, s4r[0]); ld4(f1 + at + LW, s4r[1]); ld4(f2 + at + LW, s4r[2]);
-                    wlr[0] = f0[at - 1]; wlr[1] = f1[at - 1]; wlr[2] = f2[at - 1];
-                    err[0] = f0[at + 4]; err[1] = f1[at + 4]; err[2] = f2[at + 4];
-                    quad_row(u, gy, c4r, n4r, s4r, wlr, err, std::true_type{});
-                }
-                if (!PF && !(VAR & 2) && edge_nw && col_on) {  // row 0 / column 0 (and anything left / above the image) keeps its value
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (gy <= 0 || gx0 + i <= 0) {
-#pragma unroll
-                            for (int f = 0; f < 3; f++) nv[u][f][i] = c4[f][i];
-                        }
-                }
+                do_row(u, r, n4, c4, s4);
             }
             __builtin_amdgcn_sched_barrier(0);  // one quad-row at a time: interleaving the rows costs 60 more VGPRs
         }
