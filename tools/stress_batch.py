@@ -3,7 +3,7 @@
 levels in lockstep, one launch per level for all of them) against the same pairs through the single-pair calls of the same context --
 random image sizes, pyramid depths, batch sizes, slot counts, batch thresholds, kernel-choice overrides, distinct images and distinct
 fovea offsets inside a batch, pyramid stacks on and off.  (The single-pair calls are pinned to the oracle by tests/.)  Development tool:
-python tools/stress_batch.py [cases]"""
+python tools/stress_batch.py [cases [seed]]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ os.environ["UGSM_DEV"] = "1"
 from ug_stereomatcher_amd import _lib, synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.Generator(np.random.PCG64(20261004))
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004))  # (second argument: another seed)
 KNOBS = [{}, {}, {}, {"UGSM_POLICY": "throughput"}, {"UGSM_POLICY": "latency"}, {"UGSM_MARCH_MIN_PIXELS": "1"}, {"UGSM_MARCH4": "1,2000000000"},
          {"UGSM_FUSE_SEED": "0"}, {"UGSM_BATCH_MAX_PIXELS": "60000"}, {"UGSM_BATCH_MAX_PIXELS": "100000000"}, {"UGSM_PYR_STREAM": "0"},
          {"UGSM_SMALL_MAX_PIXELS": "-1"}]

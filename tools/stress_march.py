@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised A/B of the marching kernels against the LDS-tiled ones on the GPU (both through ugsm_stage_iterate /
 ugsm_stage_smooth; the tiled path is itself pinned to the oracle by tests/): random sizes, strip heights, pixels per lane,
-disparity fields with outliers, zero patches, out-of-range plane values.  Development tool:  python tools/stress_march.py [cases]"""
+disparity fields with outliers, zero patches, out-of-range plane values.  Development tool:  python tools/stress_march.py [cases [seed]]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ug_stereomatcher_amd import _lib  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.Generator(np.random.PCG64(20260410))
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20260410))  # (second argument: another seed)
 
 
 def bits_equal(a, b):

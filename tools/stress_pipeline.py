@@ -2,7 +2,7 @@
 """Randomised whole-matcher A/B on the GPU: kernel_path 0 (production: marching / tiled / latency kernels chosen per level and per
 slot count, fused seeding, strip-height model) against kernel_path 1 (one kernel per reference stage, itself pinned to the oracle by
 tests/), full and foveated mode, random image sizes, pyramid depths, slot counts and fovea offsets.  Development tool:
-python tools/stress_pipeline.py [cases]"""
+python tools/stress_pipeline.py [cases [seed]]"""
 import ctypes as C
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ug_stereomatcher_amd import _lib, synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.Generator(np.random.PCG64(20260412))
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20260412))  # (second argument: another seed)
 
 
 def bits_equal(a, b):

@@ -3,7 +3,7 @@
 batch counts, image sizes, modes (full / foveated with random window offsets, with and without pyramid stacks), memory kinds (device,
 page-locked host, managed), and random points at which the host flushes, fetches without blocking, or drains.  Whatever calls the library
 forms, every pair must come back in enqueue order, with its tag, bit-identical to the single call, and the bookkeeping must balance
-(at most (slots + 1) x batch outstanding; depth 0 after a drain).  Development tool:  python tools/stress_queue.py [cases]"""
+(at most (slots + 1) x batch outstanding; depth 0 after a drain).  Development tool:  python tools/stress_queue.py [cases [seed]]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ug_stereomatcher_amd import _lib, synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.Generator(np.random.PCG64(20261005))
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005))  # (second argument: another seed)
 
 
 def same(a, b):

@@ -2,7 +2,7 @@
 """Randomised A/B on the GPU of (1) the coarse levels' latency kernels (k_cost_small, k_smooth_small at every tile height) against the
 LDS-tiled kernels, through ugsm_stage_iterate / ugsm_stage_smooth, and (2) the seeding fused into the first marching K-cost launch
 against the separate k_seed launch, through whole full-mode and foveated matches with every level marching.  The tiled path is pinned
-to the oracle by tests/.  Development tool:  python tools/stress_small.py [cases]"""
+to the oracle by tests/.  Development tool:  python tools/stress_small.py [cases [seed]]"""
 import ctypes as C
 import os
 os.environ["UGSM_DEV"] = "1"  # the kernel-choice overrides used below are development switches
@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ug_stereomatcher_amd import _lib, synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.Generator(np.random.PCG64(20260411))
+rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20260411))  # (second argument: another seed)
 
 
 def bits_equal(a, b):
