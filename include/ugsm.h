@@ -30,7 +30,11 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define UGSM_ABI_VERSION 5  /* 5: the queue (ugsm_enqueue_*, ugsm_flush, ugsm_next_done, ugsm_queue_depth, ugsm_queue_plan, ugsm_poll; UGSM_PENDING / UGSM_EMPTY),
+#define UGSM_ABI_VERSION 6  /* 6: the kernel choices follow what is in flight, not ugsm_config.slots: ugsm_plan_level takes `alone`, ugsm_plan_level_in_frame
+                               is gone, ugsm_level_plan.latency_policy is .alone; ugsm_enqueue_* returns UGSM_OK once the pair is accepted (a failed
+                               CALL is reported through ugsm_completion.status only); the fovea shard carries a status word (a rank that fails still
+                               reaches the exchange); march_min_pixels < 0 and march_smooth are libugsm_dev.so's
+                               5: the queue (ugsm_enqueue_*, ugsm_flush, ugsm_next_done, ugsm_queue_depth, ugsm_queue_plan, ugsm_poll; UGSM_PENDING / UGSM_EMPTY),
                                RCCL inside the library (ugsm_shard_*), hidden visibility for everything else
                                4: ugsm_config grew (batch, stream_priority), ugsm_submit_full_batch, ugsm_submit_foveated_batch; kernel_path 1,
                                march_smooth and the probe entry points moved to libugsm_dev.so (include/ugsm_dev.h)
@@ -71,19 +75,21 @@ typedef struct ugsm_config {
     int kernel_path;
     int profile_events; /* slot 0 times its launches with HIP events carried in the dispatch (the kernel's own begin and end): 1 = the cost kernel only, 2 = every kernel class */
     int march_min_pixels; /* levels of at least this many pixels run K-cost as the marching kernel (one wave per strip of
-                             columns, no LDS); 0 = default threshold, < 0 = never (the LDS-tiled kernel everywhere) */
+                             columns, no LDS); 0 = default threshold (0.4 Mpx per launch; in effect 3 Mpx: the channel-parallel form
+                             k_cost_march4 takes the levels below first); < 0 = never: round 1's LDS-tiled k_cost_split everywhere --
+                             libugsm_dev.so only since ABI 6 (libugsm.so answers UGSM_ERR_BAD_ARG) */
     int march_np;         /* ignored since ABI 3 (kept for layout): the two-pixels-per-lane development form of the marching kernel
                              is no longer in the library (tools/kbench.hip instantiates it) */
     int march_rows;       /* tuning / tests: strip height of the marching kernel (0 = automatic) */
-    int march_smooth;     /* libugsm_dev.so only (ignored by libugsm.so since ABI 4): 1: those levels also run K-smooth (five passes at a
-                             time) as a marching kernel -- bit-identical, measured slower than the LDS-tiled K-smooth */
+    int march_smooth;     /* ignored since ABI 6 (kept for layout): the marching K-smooth, bit-identical and measured slower than the
+                             LDS-tiled one (docs/HISTORY.md), is no longer built */
     float early_exit_threshold; /* SURVEY 8f row f-4, OFF at 0 (default): when > 0, a level stops iterating as soon as the
                              confidence-weighted mean change of dx and of dy between two iterations is below it
                              (differenceIterations / weightedDifference, MatchGPULib.cpp:1323-1437 -- dead code in the
                              reference, whose results this option therefore leaves; one host round trip per iteration) */
     int small_max_pixels; /* levels of at most this many pixels run K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip:
                              channel-parallel 16 x 12 tiles, one thread per pixel; same results bit for bit); 0 = default
-                             threshold (0.15 Mpx in a one-slot context, 50 k pixels with several slots), < 0 = never */
+                             threshold (0.15 Mpx for a call that has the chip to itself, 50 k pixels for one that shares it), < 0 = never */
     float lr_check_threshold; /* LR-consistency check, OFF at 0 (default).  Named by the north star; THE REFERENCE HAS NONE (no
                              right-to-left pass in MatchLib.cu / MatchGPULib.cpp), so any value > 0 leaves the reference's results:
                              full mode only (ugsm_match_full / ugsm_submit_full), the pair is matched a second time with the images
@@ -141,23 +147,25 @@ int ugsm_fovea_dims(int W, int H, int levels, int fovea_levels, int *fovW, int *
 long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
 
 /* Which kernels a W x H level runs under `cfg` (NULL = defaults), for maintainers and the host tests; results never depend on it.
- * The choice depends on what is in flight: `frame_w` x `frame_h` is what the call matches at its finest level (the image in full
- * mode, the fovea window in foveated mode); ugsm_plan_level takes the level itself as the frame.
- * latency_policy: 1 = the call has the chip to itself at least some of the time (one slot, or frames below 6 Mpx): every launch as
- * short as possible; 0 = several large pairs in flight: every launch does the least work.
- * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_cost_split / k_smooth_fused), 1 = marching (k_cost_march / k_smooth_march),
- * 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1),
+ * ONE thing besides the level's size decides: whether the call has the chip to itself (`alone` != 0) or shares it with other calls.
+ * The library answers that per call from what is in flight when the call is submitted -- nothing unfinished on any other slot and no
+ * pairs waiting behind it in the queue -- so the blocking entry points (ugsm_match_*: the node's service call and its one-at-a-time
+ * topic path) are alone whatever cfg->slots says, and the calls of a burst are not.  A call alone gets every launch as SHORT as possible
+ * (nothing else fills the CUs a launch leaves idle: the coarse-level latency kernels up to 0.15 Mpx on their smallest tiles, K-smooth tile
+ * heights that fill whole rounds of workgroups, the right pyramid and the A planes on the slot's side stream); a call that shares the
+ * chip gets every launch doing little redundant work (latency kernels up to 50 k pixels only, on 18 x 18 tiles; one stream).
+ * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_smooth_fused; as a cost kernel: k_cost_split, libugsm_dev.so only), 1 = marching
+ * (k_cost_march), 2 = coarse-level latency form (k_cost_small / k_smooth_small), 3 = one kernel per reference stage (kernel_path 1),
  * 4 (cost_kernel only) = channel-parallel marching form (k_cost_march4);
  * smooth_rh: region height of k_smooth_small (18, 24 or 32; else 0); strip_rows: rows per strip of the marching K-cost (else 0);
  * seed_fused: 1 if the level's seeding rides on its first K-cost launch; smooth_tile_rows: height of k_smooth_fused's 112-column
- * tile where that tile is used (else 0).  With cfg->batch > 1 the plan is that of a call of cfg->batch pairs (ugsm_submit_*_batch): what
- * counts as "in flight" is the batch, and the thresholds are compared with pairs_per_launch x the level. */
+ * tile where that tile is used (else 0).  With cfg->batch > 1 the plan is that of a call of cfg->batch pairs (ugsm_submit_*_batch): every
+ * threshold is compared with what the LAUNCH holds, pairs_per_launch x the level. */
 typedef struct ugsm_level_plan {
-    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, latency_policy;
+    int cost_kernel, smooth_kernel, smooth_rh, strip_rows, seed_fused, smooth_tile_rows, alone;
     int pairs_per_launch;  /* ABI 4: cfg->batch where a call of that many pairs runs this level as one launch for all of them, else 1 */
 } ugsm_level_plan;
-int ugsm_plan_level(const ugsm_config *cfg, int W, int H, ugsm_level_plan *out);
-int ugsm_plan_level_in_frame(const ugsm_config *cfg, int frame_w, int frame_h, int W, int H, ugsm_level_plan *out);
+int ugsm_plan_level(const ugsm_config *cfg, int alone, int W, int H, ugsm_level_plan *out);
 
 /* ---- the service path: host buffers in, host buffers out ------------------------ */
 
@@ -279,7 +287,14 @@ typedef struct ugsm_completion {
                               ((F fovH) x fovW each), then the L and R pyramid stacks ((F 3 fovH) x fovW) if they were asked for */
 } ugsm_completion;
 
-/* Device buffers (as ugsm_submit_full / ugsm_submit_foveated; d_pyrL / d_pyrR may be NULL).  Inputs and outputs must stay valid and
+/* Return value of every ugsm_enqueue_*: UGSM_OK = the pair is ACCEPTED -- it will be reported by ugsm_next_done exactly once, whatever
+ * happens to the call it goes out in; anything else = the pair is REJECTED and nothing was enqueued (bad arguments, buffers that are not
+ * page-locked, UGSM_ERR_STATE when (slots + 1) x batch pairs are outstanding, UGSM_ERR_NOMEM for the library's own bookkeeping or staging).
+ * A library call that fails -- e.g. UGSM_ERR_NOMEM when the slot's buffers cannot be had -- is reported through ugsm_completion.status of
+ * each of its pairs and nowhere else: the call an enqueue happens to send may hold OTHER pairs than the one just appended.  A failed call's
+ * pairs are reported only after whatever the call did put on the slot's stream has drained, so a completion always means that the pair's
+ * input and result buffers are no longer in use.
+ * Device buffers (as ugsm_submit_full / ugsm_submit_foveated; d_pyrL / d_pyrR may be NULL).  Inputs and outputs must stay valid and
  * untouched until the pair's tag has been reported by ugsm_next_done. */
 int ugsm_enqueue_full(ugsm_ctx *ctx, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, float *d_out, uint64_t tag);
 int ugsm_enqueue_foveated(ugsm_ctx *ctx, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int off_x, int off_y,

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
     so = C.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), f"{name} declared in ugsm.h but not exported by libugsm.so"
-    assert lib.load().ugsm_abi_version() == 5
+    assert lib.load().ugsm_abi_version() == 6
     assert lib.load().ugsm_is_dev_library() == 0
     # ... and NOTHING else (-fvisibility=hidden + csrc/ugsm.map): no ugsm::launch_*, no __device_stub__*, no kernel handles
     import shutil
@@ -50,28 +50,50 @@ def test_dev_header_symbols_are_exported_by_the_dev_library_only(lib):
         assert not hasattr(prod, name), f"{name} is a development entry point but libugsm.so exports it"
     for name in lib.EXPORTS:
         assert hasattr(dev, name)
-    assert lib.load(dev=True).ugsm_is_dev_library() == 1 and lib.load(dev=True).ugsm_abi_version() == 5
+    assert lib.load(dev=True).ugsm_is_dev_library() == 1 and lib.load(dev=True).ugsm_abi_version() == 6
 
 
 def test_product_library_holds_no_development_kernel(lib):
-    """the measured negatives (k_smooth_march, k_iter_small), the one-kernel-per-stage path and the probe kernels are
-    in libugsm_dev.so; the library a maintainer links carries only kernels a configuration of include/ugsm.h can launch."""
+    """the one-kernel-per-stage path, round 1's LDS-tiled K-cost and the probe kernels are csrc/dev/ and in
+    libugsm_dev.so only; the library a maintainer links carries only kernels a configuration of include/ugsm.h can launch, and the measured
+    negatives of rounds 2-5 (k_smooth_march, k_smooth_pipe, k_iter_small, the one-thread-per-quad k_cost_fused) are in neither."""
     def kernels(path):   # the kernels' mangled names: _ZN4ugsm<len>k_name...
         blob = open(path, "rb").read()
         return set(name[:int(n)].decode() for n, name in re.findall(rb"_ZN4ugsm(\d+)(k_[a-z_0-9]+)", blob))
     prod, dev = kernels(lib.LIB_PATH), kernels(lib.DEV_LIB_PATH)
-    banned = {"k_smooth_march", "k_iter_small", "k_poly_probe", "k_div3_probe", "k_div_probe", "k_cost_ref", "k_warp", "k_smooth_pass", "k_box",
-              "k_sqblur_clamp", "k_blur_decimate"}
-    assert not (prod & banned), sorted(prod & banned)
+    banned = {"k_cost_split", "k_poly_probe", "k_div3_probe", "k_div_probe", "k_cost_ref", "k_warp", "k_smooth_pass", "k_box", "k_sqblur_clamp", "k_blur_decimate"}
+    gone = {"k_smooth_march", "k_smooth_pipe", "k_iter_small", "k_cost_fused"}
+    assert not (prod & (banned | gone)), sorted(prod & (banned | gone))
     assert banned <= dev, sorted(banned - dev)
-    for k in ("k_cost_march", "k_cost_march4", "k_cost_small", "k_smooth_small", "k_smooth_fused", "k_pyr_base", "k_blur_decimate_tiled", "k_sqblur_tiled",
-              "k_seed", "k_copy_view", "k_lr_check", "k_rgb_planes"):
-        assert k in prod, k
-    # ... and the product refuses the configuration that would need them
+    assert not (dev & gone), sorted(dev & gone)
+    product_kernels = {"k_cost_march", "k_cost_march4", "k_cost_small", "k_smooth_small", "k_smooth_fused", "k_pyr_base", "k_pyr_base_march", "k_blur_decimate2",
+                       "k_blur_decimate_tiled", "k_sqblur_tiled", "k_range_scan", "k_seed", "k_copy_view", "k_lr_check", "k_rgb_planes", "k_triangulate",
+                       "k_triangulate_fovea", "k_upsample_paste", "k_wdiff_rows", "k_wdiff_total"}
+    assert prod == product_kernels, sorted(prod ^ product_kernels)          # the k_* symbol set of the shipped library, exactly
+    assert dev == product_kernels | banned, sorted(dev ^ (product_kernels | banned))
+
+
+def test_product_kernel_sources_hold_no_development_switch():
+    """the shipped .hip files compile with no -D probe macro recognised -- no preprocessor conditional at all -- and libugsm_dev.so
+    is those same files plus csrc/dev/."""
+    csrc = os.path.join(ROOT, "ug_stereomatcher_amd", "csrc")
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert files == ["ugsm_kernels_aux.hip", "ugsm_kernels_march.hip", "ugsm_kernels_march4.hip", "ugsm_kernels_pyr.hip", "ugsm_kernels_small.hip", "ugsm_kernels_smooth.hip"]
+    for f in files:
+        src = open(os.path.join(csrc, f)).read()
+        assert not re.search(r"^\s*#\s*(if|ifdef|ifndef|elif|else|endif)\b", src, re.M), f
+        assert "UGSM_DEV_LIB" not in src and "UGSM_DEV_KERNELS" not in src, f
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert re.search(r"\$\(OUT\): \$\(SRCS\) \$\(HDRS\)\n\t\$\(HIPCC\) \$\(FLAGS\) \$\(SRCS\) -o", mk) and "dev/ugsm_dev_" not in mk.split("DEV_SRCS")[0]
+
+
+def test_product_refuses_the_configurations_of_the_development_library(lib):
     cfg = lib.Config()
     lib.load().ugsm_default_config(C.byref(cfg))
     cfg.kernel_path = 1
     hnd = C.c_void_p()
+    assert lib.load().ugsm_create(C.byref(cfg), C.byref(hnd)) == lib.UGSM_ERR_BAD_ARG
+    cfg.kernel_path, cfg.march_min_pixels = 0, -1       # round 1's LDS-tiled K-cost: libugsm_dev.so only since ABI 6
     assert lib.load().ugsm_create(C.byref(cfg), C.byref(hnd)) == lib.UGSM_ERR_BAD_ARG
 
 

@@ -107,19 +107,19 @@ def test_full_batch_with_levels_that_are_not_batched(lib, orc):
             assert_bit_equal(got[b], exp[b], f"2600x1700 batch of 3, UGSM_BATCH_MAX_PIXELS={thr}, pair {b}")
 
 
-@pytest.mark.parametrize("force", ["march", "march4", "throughput", "tiled", "no_fused_seed"])
+@pytest.mark.parametrize("force", ["march", "march4", "shared", "alone", "tiled", "no_fused_seed"])
 def test_full_batch_every_kernel_form_on_the_batched_levels(lib, orc, monkeypatch, force):
     """The batched launches of every K-cost / K-smooth form: the marching kernel and the channel-parallel marching kernel on every
-    level (their seeded first launches included), the throughput choices, the LDS-tiled K-smooth / k_cost_split (which has no batch
-    index: pair by pair inside a batch), k_seed instead of the fused seeding."""
-    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "throughput": {"UGSM_POLICY": "throughput"},
+    level (their seeded first launches included), the choices of a call that shares the chip and of one that has it to itself, the
+    LDS-tiled K-smooth / k_cost_split (libugsm_dev.so; it has no batch index: pair by pair inside a batch), k_seed instead of the fused seeding."""
+    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "shared": {"UGSM_ALONE": "0"}, "alone": {"UGSM_ALONE": "1"},
            "tiled": {"UGSM_MARCH_MIN_PIXELS": "-1", "UGSM_SMALL_MAX_PIXELS": "-1", "UGSM_MARCH4": "0,0"}, "no_fused_seed": {"UGSM_FUSE_SEED": "0"}}[force]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     W, H, lv, B = 800, 600, 12, 3
     pairs = _pairs(W, H, B, 1300)
     exp = [orc.match_full(L, R, lv) for L, R in pairs]
-    with lib.Context(levels=lv, slots=2, batch=B) as c:
+    with lib.Context(levels=lv, slots=2, batch=B, dev=(force == "tiled")) as c:
         got = _full_batch(c, pairs, W, H)
     for b in range(B):
         assert_bit_equal(got[b], exp[b], f"800x600 batch of {B}, {force}, pair {b}")
@@ -141,9 +141,9 @@ def test_foveated_batch_with_different_offsets_vs_oracle(lib, orc, B):
         assert_bit_equal(pr[b], epr, f"foveated batch of {B}, pair {b}: right pyramid stack")
 
 
-@pytest.mark.parametrize("force", ["march", "march4", "throughput", "no_fused_seed"])
+@pytest.mark.parametrize("force", ["march", "march4", "shared", "no_fused_seed"])
 def test_foveated_batch_every_kernel_form(lib, orc, monkeypatch, force):
-    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "throughput": {"UGSM_POLICY": "throughput"},
+    env = {"march": {"UGSM_MARCH_MIN_PIXELS": "1"}, "march4": {"UGSM_MARCH4": "1,2000000000"}, "shared": {"UGSM_ALONE": "0"},
            "no_fused_seed": {"UGSM_FUSE_SEED": "0"}}[force]
     for k, v in env.items():
         monkeypatch.setenv(k, v)

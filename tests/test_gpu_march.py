@@ -95,7 +95,6 @@ def test_march_equals_tiled_end_to_end(lib, orc, monkeypatch):
     L, R, _, _ = synth.make_pair(320, 240, synth.BASE_SEED + 7)
     exp = orc.match_full(L, R, 8)
     monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
-    monkeypatch.setenv("UGSM_MARCH_SMOOTH", "1")
     for np_lane in (1,):
         m = MatchGPULib(levels=8)
         got = m.match(L, R, 0)
@@ -176,7 +175,6 @@ def test_march_on_fovea_views(lib, orc, monkeypatch):
     from ug_stereomatcher_amd import MatchGPULib
     g = load_golden("fovea_320x240_l9_f4.npz")
     monkeypatch.setenv("UGSM_MARCH_MIN_PIXELS", "1")
-    monkeypatch.setenv("UGSM_MARCH_SMOOTH", "1")
     for np_lane in (1,):
         m = MatchGPULib(3, ["node", "x", str(int(g["F"]))], levels=int(g["levels"]))
         st = m.matchStack(g["L"], g["R"])
@@ -184,7 +182,7 @@ def test_march_on_fovea_views(lib, orc, monkeypatch):
         assert_bit_equal(np.ascontiguousarray(np.asarray(st).transpose(1, 0, 2, 3)), g["stack"], f"fovea stack np={np_lane}")
 
 
-# ---- K-smooth, marching form -----------------------------------------------------------------------
+# ---- K-smooth helpers (shared with test_gpu_small.py) ---------------------------------------------------
 
 def smooth_ref(orc, d, passes, box):
     exp = d
@@ -204,45 +202,6 @@ def run_smooth(c, d, passes, box):
         return c.to_host(p, d.shape)
     finally:
         c.free(p)
-
-
-@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
-def test_smooth_march_sizes_strip_seams_and_borders(lib, orc, np_lane):
-    """Five passes (+ box), and ten as two launches, on sizes around the strip widths (50 / 54 columns for one pixel per lane,
-    113 / 117 for two), with strips shorter and taller than the image, down to images narrower than a halo."""
-    rng = np.random.Generator(np.random.PCG64(91))
-    cases = [(300, 70, 0), (113, 40, 24), (114, 33, 7), (117, 30, 11), (118, 29, 9), (50, 61, 33), (51, 21, 5), (54, 20, 6), (55, 19, 4),
-             (257, 64, 16), (31, 9, 4), (6, 5, 3), (1, 40, 8), (40, 1, 8), (640, 48, 16)]
-    for (W, H, rows) in cases:
-        d = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 3, (H, W)), 0.1 + 0.9 * rng.random((H, W))]).astype(np.float32)
-        with lib.Context(levels=1, march_min_pixels=1, march_np=np_lane, march_rows=rows, march_smooth=1) as c:
-            for passes, box in [(5, 1), (5, 0), (10, 1)]:
-                got = run_smooth(c, d, passes, box)
-                assert_bit_equal(got, smooth_ref(orc, d, passes, box), f"{W}x{H} rows={rows} np={np_lane} passes={passes} box={box}")
-
-
-@pytest.mark.parametrize("np_lane", [1])  # (the two-pixels-per-lane development form is not in libugsm.so: tools/kbench.hip)
-def test_smooth_march_degenerate_confidence(lib, orc, np_lane):
-    """Confidence fields that push sumCorr out of the shared-reciprocal range (zero patches: 0/0 -> NaN spreading one pixel per
-    pass; negative, 1e-30, 1e30 weights), also on the frame and across strip seams."""
-    rng = np.random.Generator(np.random.PCG64(92))
-    W, H = 420, 150
-    d = np.stack([rng.normal(0, 3, (H, W)), rng.normal(0, 3, (H, W)), 0.1 + 0.9 * rng.random((H, W))]).astype(np.float32)
-    d[2, 40:60, 50:90] = 0.0
-    d[2, 100:104, 100:140] = -0.25
-    d[2, 120:124, 20:60] = 1e-30
-    d[2, 130:134, 20:60] = 1e30
-    d[0, 140:144, 20:60] = 0.0
-    d[2, H - 30:H - 10, W - 80:W - 40] = 0.0
-    d[2, 0:3, 200:230] = 0.0
-    d[2, 70:90, 0:4] = 0.0
-    d[2, 60:64, W - 3:W] = 0.0
-    d[2, H - 2:H, 300:340] = 0.0
-    d[1, 10:12, 110:120] = np.nan
-    with lib.Context(levels=1, march_min_pixels=1, march_np=np_lane, march_rows=32, march_smooth=1) as c:
-        for passes, box in [(5, 1), (10, 1), (5, 0)]:
-            got = run_smooth(c, d, passes, box)
-            assert_bit_equal(got, smooth_ref(orc, d, passes, box), f"degenerate np={np_lane} passes={passes} box={box}")
 
 
 def test_march_exact_invariances_at_full_level_size(lib):

@@ -114,21 +114,20 @@ def test_march4_without_fused_seeding_and_with_early_exit(lib, orc, everywhere, 
         assert_bit_equal(full_match(c, L, R), exp, "early exit armed")
 
 
-def test_default_policy_of_a_one_slot_context(lib, orc, monkeypatch):
-    """No override: a call that has the chip to itself at least some of the time -- a one-slot context, or several slots with small
-    frames -- runs its 0.15 - 3 Mpx levels through k_cost_march4 (levels 0 and 1 of an 800 x 600 pair); the same levels inside a
-    16 MP frame with several slots do not.  Every context gives the oracle's result."""
+def test_default_policy_runs_march4_on_the_mid_levels(lib, orc, monkeypatch):
+    """No override: levels of up to 3 Mpx above the latency kernels' range run k_cost_march4 (levels 0 and 1 of an 800 x 600 pair), whether
+    the call has the chip to itself or shares it.  Every context gives the oracle's result."""
     from ug_stereomatcher_amd import synth
     monkeypatch.delenv("UGSM_MARCH4", raising=False)
     W, H = 800, 600
-    assert lib.plan_level(W, H, slots=1)["cost_kernel"] == MARCH4 and lib.plan_level(W, H, slots=1)["seed_fused"] == 1
-    assert lib.plan_level(W, H, slots=4)["cost_kernel"] == MARCH4 and lib.plan_level(W, H, frame=(4928, 3264), slots=4)["cost_kernel"] != MARCH4
+    assert lib.plan_level(W, H, alone=True)["cost_kernel"] == MARCH4 and lib.plan_level(W, H, alone=True)["seed_fused"] == 1
+    assert lib.plan_level(W, H, alone=False)["cost_kernel"] == MARCH4
     L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 412)
     exp = orc.match_full(L, R, 9)
     with lib.Context(levels=9, slots=1) as c:
         assert_bit_equal(full_match(c, L, R), exp, "one slot")
     with lib.Context(levels=9, slots=2) as c:
         assert_bit_equal(full_match(c, L, R), exp, "two slots")
-    monkeypatch.setenv("UGSM_POLICY", "throughput")  # (development override: the choices of several large pairs in flight, on this small one)
+    monkeypatch.setenv("UGSM_ALONE", "0")  # (development override: the choices of a call that shares the chip, on this lone one)
     with lib.Context(levels=9, slots=2) as c:
-        assert_bit_equal(full_match(c, L, R), exp, "two slots, throughput choices")
+        assert_bit_equal(full_match(c, L, R), exp, "two slots, the choices of a call that shares the chip")

@@ -425,16 +425,16 @@ def test_1080p_vs_oracle_bit_exact(lib, orc):
 # (oracle_16mp: the 16 MP pair and the oracle's answers for it -- tests/conftest.py, shared with test_gpu_queue.py)
 
 
-def test_16mp_throughput_policy_vs_oracle_bit_exact(lib, oracle_16mp):
-    """configs[2] / configs[3] on a FOUR-SLOT context -- the configuration bench.py times: several large pairs in
-    flight select the throughput kernel choices (k_cost_march down to 50 k pixels, 112 x 36 K-smooth tiles, region height 32 on the
-    coarse levels; ugsm_plan_level), which a one-slot context never runs.  All four slots in flight at once, every slot's result
-    against the live oracle bit for bit; then the foveated stack, four in flight, on the same context."""
+def test_16mp_four_slots_in_flight_vs_oracle_bit_exact(lib, oracle_16mp):
+    """configs[2] / configs[3] on a FOUR-SLOT context with all four slots in flight at once: the first call finds the chip empty (the
+    choices of a call alone: side stream, short K-smooth tiles), the three behind it share it (k_cost_march4 down to 50 k pixels,
+    region height 32 on the coarse levels; ugsm_plan_level) -- both sets in one run.  Every slot's result against the live oracle bit
+    for bit; then the foveated stack, four in flight, on the same context."""
     g = oracle_16mp
     W, H, L, R = g["W"], g["H"], g["L"], g["R"]
-    plan = lib.plan_level(W, H, slots=4)
-    assert plan["latency_policy"] == 0 and plan["cost_kernel"] == 1, plan   # what the bench line's context launches at level 0
-    assert lib.plan_level(306, 202, frame=(W, H), slots=4)["cost_kernel"] == 1   # ... and at level 8 (61 812 pixels)
+    plan = lib.plan_level(W, H, alone=False)
+    assert plan["alone"] == 0 and plan["cost_kernel"] == 1, plan   # what the bench line's context launches at level 0
+    assert lib.plan_level(306, 202, alone=False)["cost_kernel"] == 4 and lib.plan_level(306, 202, alone=True)["cost_kernel"] == 2   # level 8 (61 812 pixels)
     c = lib.Context(levels=14, slots=4, kernel_path=0)
     try:
         pL, pR = c.to_device(L), c.to_device(R)

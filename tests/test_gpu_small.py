@@ -193,29 +193,3 @@ def test_random_sizes_production_path_against_the_one_kernel_per_stage_path(lib)
                 out.append((full, st))
         assert_bit_equal(out[0][0], out[1][0], f"full {W}x{H} levels={levels} slots={slots}")
         assert_bit_equal(out[0][1], out[1][1], f"foveated {W}x{H} levels={levels} F={F} off={off} slots={slots}")
-
-
-@pytest.mark.parametrize("slots", [1, 2])
-def test_iter_small_whole_matcher(lib, orc, monkeypatch, slots):
-    """k_iter_small (development switch UGSM_ITER_SMALL=1): on the coarse levels the smoothing of iteration m and the cost step of
-    iteration m + 1 run in one launch -- a level is cost, (mi - 1) x [smooth + cost], smooth.  Whole matcher, full and foveated mode,
-    sizes whose levels cross the 16 x 12 tile in every way, zero patches; bit for bit against the oracle."""
-    from ug_stereomatcher_amd import synth
-    monkeypatch.setenv("UGSM_ITER_SMALL", "1")
-    for (W, H, lv) in [(420, 300, 10), (333, 251, 10), (257, 129, 8)]:
-        L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 370 + W)
-        L = L.copy()
-        L[40:70, 60:100] = 0  # 0/0 -> NaN correlation on the coarse levels too
-        exp = orc.match_full(L, R, lv)
-        with lib.Context(levels=lv, fovea_levels=5, slots=slots, dev=True) as c:   # k_iter_small lives in libugsm_dev.so
-            out = np.empty((3, H, W), np.float32)
-            c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], out[0].ctypes.data, out[1].ctypes.data,
-                                          out[2].ctypes.data))
-            assert_bit_equal(out, exp, f"{W}x{H} full, slots={slots}")
-            if lv == 10 and W == 420:
-                fw, fh = lib.fovea_dims(W, H, 10, 5)
-                stack = np.empty((3, 5, fh, fw), np.float32)
-                c.check(c.lib.ugsm_match_foveated(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], 0, 0, stack[0].ctypes.data,
-                                                  stack[1].ctypes.data, stack[2].ctypes.data, None, None))
-                expf, _, _ = orc.match_foveated(L, R, 10, 5)
-                assert_bit_equal(stack, expf, f"foveated, slots={slots}")

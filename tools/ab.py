@@ -18,6 +18,7 @@ ap.add_argument("--size", type=int, nargs=2, default=(4928, 3264))
 ap.add_argument("--streams", type=int, default=0, help="ugsm_config.streams (0 = one per slot)")
 ap.add_argument("--fovea", type=int, default=0, help="foveated mode with this many fovea levels (0 = full mode)")
 ap.add_argument("--batch", type=int, default=1, help="pairs per ugsm_submit_*_batch call (1 = the single-pair calls); a configuration may override it with BATCH=n and the slots with SLOTS=n")
+ap.add_argument("--serial", type=int, default=0, help="1: one call at a time, waited for before the next goes out -- the node's service call (a configuration: SERIAL=1)")
 ap.add_argument("--child", action="store_true", help="(internal) measure under the current environment, print the rate")
 ap.add_argument("configs", nargs="*")
 args = ap.parse_args()
@@ -38,6 +39,7 @@ if args.child:
     B = int(os.environ.get("BATCH", args.batch))
     args.slots = int(os.environ.get("SLOTS", args.slots))
     args.streams = int(os.environ.get("STREAMS", args.streams))
+    serial = int(os.environ.get("SERIAL", args.serial))
     class Buf:   # a device buffer with torch's data_ptr() face
         def __init__(self, p):
             self.p = p
@@ -60,7 +62,9 @@ if args.child:
         def run(n):
             for i in range((n + B - 1) // B):          # n pairs, B per call
                 s = i % args.slots
-                if i >= args.slots:
+                if serial and i > 0:
+                    c.check(lib.ugsm_wait(h, (i - 1) % args.slots))   # the call before has finished: this one has the chip to itself
+                elif i >= args.slots:
                     c.check(lib.ugsm_wait(h, s))
                 if B > 1:
                     sel = [pairs[(i * B + b) % len(pairs)] for b in range(B)]
@@ -96,7 +100,7 @@ for r in range(args.rounds):
     for i in order:
         env = dict(os.environ, UGSM_DEV="1", **cfgs[i][1])
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--slots", str(args.slots), "--pairs", str(args.pairs), "--levels",
-                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea), "--streams", str(args.streams), "--batch", str(args.batch)], env=env, capture_output=True, text=True, timeout=300)
+                              str(args.levels), "--size", str(W), str(H), "--fovea", str(args.fovea), "--streams", str(args.streams), "--batch", str(args.batch), "--serial", str(args.serial)], env=env, capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("RATE")]
         if not line:
             print(out.stdout[-2000:], out.stderr[-2000:])

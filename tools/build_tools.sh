@@ -6,11 +6,6 @@ set -e
 cd "$(dirname "$0")/.."
 F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Iinclude"
 hipcc $F tools/kbench.hip -o tools/kbench
-hipcc $F -DUGSM_MARCH_STAMP tools/kbench.hip -o tools/kbench_stamp
-# round 4's K-cost (row passes chain after chain, row clamps in every strip) for A/Bs against the lockstep form (tools/exp/march_issue.sh, mode 19)
-hipcc $F -DMARCH_ILV=0 -DMARCH_NOCLAMP=0 -DMARCH4_ILV=0 '-DMARCH_VARIANT="r04 kernels"' tools/kbench.hip -o tools/kbench_r04k
-# K-smooth with the binary32 Newton quotients (measured slower; tools/exp/smooth_newton.sh)
-hipcc $F -DSMOOTH_NEWTON=1 tools/kbench.hip -o tools/kbench_newton
 hipcc -O2 --offload-arch=gfx950 tools/queue_probe.hip -o tools/queue_probe
 [ -f tools/valubench.hip ] && hipcc -O2 -std=c++17 --offload-arch=gfx950 tools/valubench.hip -o tools/valubench
 [ -f tools/ldsbench.hip ] && hipcc -O2 --offload-arch=gfx950 tools/ldsbench.hip -o tools/ldsbench

@@ -15,7 +15,7 @@ from ug_stereomatcher_amd import _lib, synth  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004))  # (second argument: another seed)
-KNOBS = [{}, {}, {}, {"UGSM_POLICY": "throughput"}, {"UGSM_POLICY": "latency"}, {"UGSM_MARCH_MIN_PIXELS": "1"}, {"UGSM_MARCH4": "1,2000000000"},
+KNOBS = [{}, {}, {}, {"UGSM_ALONE": "0"}, {"UGSM_ALONE": "1"}, {"UGSM_MARCH_MIN_PIXELS": "1"}, {"UGSM_MARCH4": "1,2000000000"},
          {"UGSM_FUSE_SEED": "0"}, {"UGSM_BATCH_MAX_PIXELS": "60000"}, {"UGSM_BATCH_MAX_PIXELS": "100000000"}, {"UGSM_PYR_STREAM": "0"},
          {"UGSM_SMALL_MAX_PIXELS": "-1"}]
 

@@ -63,7 +63,7 @@ for case in range(n_cases):
     m0 = int(rng.integers(1, mi))
     m1 = min(mi, m0 + int(rng.integers(0, 2)))
     S, top = int(rng.choice([5, 10])), bool(rng.integers(0, 2))
-    with _lib.Context(levels=1, march_min_pixels=1, march_np=npl, march_rows=rows, march_smooth=1) as c:
+    with _lib.Context(levels=1, march_min_pixels=1, march_np=npl, march_rows=rows) as c:
         a = iterate(c, L3, R3, d3, mi, S, top, m0, m1)
         sa = smooth(c, d3, 5, case % 2)
     b = iterate(ref, L3, R3, d3, mi, S, top, m0, m1)

@@ -3,9 +3,9 @@
 There is no CPU fallback: if the HIP library is missing or no device is present every
 compute call raises (UgsmError).  The pure-host geometry calls work without a GPU.
 
-libugsm_dev.so (include/ugsm_dev.h) is the same sources built with the development kernels: kernel_path 1 (one kernel per reference
-stage), march_smooth, the UGSM_ITER_SMALL switch and the probe entry points.  Tests and tools reach it through load(dev=True) /
-Context(dev=True); a Context that asks for kernel_path 1 or march_smooth gets it by itself.
+libugsm_dev.so (include/ugsm_dev.h) is the product's sources plus csrc/dev/: kernel_path 1 (one kernel per reference stage), round 1's
+LDS-tiled K-cost (march_min_pixels < 0) and the probe entry points.  Tests and tools reach it through load(dev=True) /
+Context(dev=True); a Context that asks for kernel_path 1 or march_min_pixels < 0 gets it by itself.
 """
 from __future__ import annotations
 
@@ -36,7 +36,7 @@ UGSM_MAX_LEVELS = 32
 EXPORTS = [
     "ugsm_default_config", "ugsm_abi_version", "ugsm_is_dev_library", "ugsm_status_string", "ugsm_create", "ugsm_destroy",
     "ugsm_last_error", "ugsm_level_dims", "ugsm_level_iterations", "ugsm_level_smooth_passes",
-    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_plan_level_in_frame", "ugsm_match_full", "ugsm_submit_full_host", "ugsm_submit_foveated_host",
+    "ugsm_threshold_schedule", "ugsm_fovea_dims", "ugsm_pixel_iterations", "ugsm_plan_level", "ugsm_match_full", "ugsm_submit_full_host", "ugsm_submit_foveated_host",
     "ugsm_match_foveated", "ugsm_match_foveated_full", "ugsm_submit_full", "ugsm_submit_foveated", "ugsm_submit_full_batch", "ugsm_submit_foveated_batch", "ugsm_submit_full_batch_host", "ugsm_submit_foveated_batch_host",
     "ugsm_wait", "ugsm_wait_all",
     "ugsm_submit_pyramids", "ugsm_submit_fovea_coarse", "ugsm_submit_fovea_fine", "ugsm_triangulate", "ugsm_fovea_mapping", "ugsm_triangulate_fovea", "ugsm_reconstruct_full", "ugsm_stage_pyramid",
@@ -69,7 +69,7 @@ class Config(C.Structure):
 
 class LevelPlan(C.Structure):
     _fields_ = [("cost_kernel", C.c_int), ("smooth_kernel", C.c_int), ("smooth_rh", C.c_int), ("strip_rows", C.c_int), ("seed_fused", C.c_int),
-                ("smooth_tile_rows", C.c_int), ("latency_policy", C.c_int), ("pairs_per_launch", C.c_int)]
+                ("smooth_tile_rows", C.c_int), ("alone", C.c_int), ("pairs_per_launch", C.c_int)]
 
 
 class KernelStat(C.Structure):
@@ -190,8 +190,7 @@ def load(dev: bool = False):
     lib.ugsm_fovea_dims.argtypes = [i, i, i, i, ip, ip]
     lib.ugsm_pixel_iterations.argtypes = [i, i, i, i]
     lib.ugsm_pixel_iterations.restype = C.c_longlong
-    lib.ugsm_plan_level.argtypes = [C.POINTER(Config), i, i, C.POINTER(LevelPlan)]
-    lib.ugsm_plan_level_in_frame.argtypes = [C.POINTER(Config), i, i, i, i, C.POINTER(LevelPlan)]
+    lib.ugsm_plan_level.argtypes = [C.POINTER(Config), i, i, i, C.POINTER(LevelPlan)]
     lib.ugsm_match_full.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_submit_full_host.argtypes = [vp, i, vp, vp, i, i, i, vp, vp, vp]
     lib.ugsm_submit_foveated_host.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, vp, vp, vp, vp]
@@ -317,7 +316,7 @@ class Context:
                  march_rows: int = 0, march_smooth: int = 0, early_exit_threshold: float = 0.0, small_max_pixels: int = 0,
                  lr_check_threshold: float = 0.0, streams: int = 0, batch: int = 0, stream_priority: int = 0, dev: bool | None = None):
         # libugsm_dev.so when asked for, or when the configuration needs a kernel only it has
-        self.dev = bool(dev) if dev is not None else (kernel_path == 1 or march_smooth == 1)
+        self.dev = bool(dev) if dev is not None else (kernel_path == 1 or march_min_pixels < 0)
         lib = load(self.dev)
         cfg = Config()
         lib.ugsm_default_config(C.byref(cfg))
@@ -558,21 +557,19 @@ class Context:
         self.check(self.lib.ugsm_reset_kernel_stats(self._h))
 
 
-def plan_level(W: int, H: int, frame=None, **cfg_fields):
+def plan_level(W: int, H: int, alone: bool = True, **cfg_fields):
     """Which kernels a W x H level runs (host only): dict of ugsm_level_plan; cfg_fields override the default ugsm_config.
-    frame = (w, h) of what the call matches at its finest level (default: the level itself)."""
-    lib = load(bool(cfg_fields.get("kernel_path") == 1 or cfg_fields.get("march_smooth") == 1 or cfg_fields.pop("dev", False)))
+    alone: the call has the chip to itself (what the library decides per call from what is in flight; include/ugsm.h)."""
+    lib = load(bool(cfg_fields.get("kernel_path") == 1 or cfg_fields.get("march_min_pixels", 0) < 0 or cfg_fields.pop("dev", False)))
     cfg = Config()
     lib.ugsm_default_config(C.byref(cfg))
     for k, v in cfg_fields.items():
         setattr(cfg, k, v)
     out = LevelPlan()
-    fw, fh = frame if frame else (W, H)
-    st = lib.ugsm_plan_level_in_frame(C.byref(cfg), fw, fh, W, H, C.byref(out))
+    st = lib.ugsm_plan_level(C.byref(cfg), 1 if alone else 0, W, H, C.byref(out))
     if st != 0:
         raise UgsmError(st, "ugsm_plan_level")
-    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "latency_policy",
-                                              "pairs_per_launch")}
+    return {k: int(getattr(out, k)) for k in ("cost_kernel", "smooth_kernel", "smooth_rh", "strip_rows", "seed_fused", "smooth_tile_rows", "alone", "pairs_per_launch")}
 
 
 def shard_unique_id() -> bytes:

@@ -1,128 +1,16 @@
-// ugsm_kernels_ref.hip -- the plain per-pixel kernels.
-//
-// In the product (libugsm.so): k_seed (a level's starting field where the next level's K-cost does not seed itself), k_copy_view
-// (the fovea / pyramid stacks), k_lr_check and k_rgb_planes (level 0 of a pyramid of fewer than three levels: BASELINE configs[0]).
-// In libugsm_dev.so only (UGSM_DEV_LIB; round 4): kernel_path 1, one stage per kernel, global memory only -- the
-// plainest possible gfx950 statement of each stage (one thread per output pixel, every neighbourhood re-read through L1/L2).  They
-// exist to (a) get a first correct HIP path, (b) expose per-stage intermediates to the parity tests and (c) A/B the fused kernels of
-// ugsm_kernels_fused.hip, which must match them bit for bit.  They are NOT a production path.
+// dev/ugsm_dev_stages.hip -- libugsm_dev.so only: kernel_path 1, one kernel per reference stage, global memory only -- the plainest
+// possible gfx950 statement of each stage (one thread per output pixel, every neighbourhood re-read through L1/L2).  They exist to
+// (a) get a first correct HIP path, (b) expose per-stage intermediates to the parity tests and (c) A/B the product's fused kernels, which
+// must match them bit for bit.  They are NOT a production path; a maintainer links libugsm.so, which does not contain this file.
 //
 // Citations: /root/reference/src/gpu_matcher/<file>:<line>.
-#include "ugsm_device.hpp"
-#include "ugsm_launch.hpp"
+#include "../ugsm_device.hpp"
+#include "../ugsm_launch.hpp"
 
 namespace ugsm {
 
-// ---- in the product: seeding where the next level does not march, the fovea / pyramid stacks, the LR check ----------
-
 static inline dim3 grid2(int W, int H, int z = 1) { return dim3((W + 255) / 256, H, z); }
 
-// --------------------------------------------------------------------------------------
-// MatchLib.cu:372-401 (+ fovea crop MatchGPULib.cpp:1642-1644):
-// dst[x,y] = f32(SCALE * src[floor((x+cx+.5f)*sf), floor((y+cy+.5f)*sf)]), sf=(float)(1/SCALE)
-// (batched: blockIdx.z = 3 x pair + plane)
-__global__ void k_seed(const float *__restrict__ src3, int Ws, int Hs, float *__restrict__ dst3, int Wd, int Hd, int cx, int cy, Batch bt)
-{
-    int ix = blockIdx.x * blockDim.x + threadIdx.x;
-    int iy = blockIdx.y;
-    int plane = blockIdx.z;
-    if (bt.n > 1) {
-        const int b = plane / 3;
-        plane -= 3 * b;
-        src3 = shifted(src3, bt.in[b]);
-        dst3 = shifted(dst3, bt.out[b]);
-        cx = bt.cx[b];
-        cy = bt.cy[b];
-    }
-    if (ix >= Wd) return;
-    const float sf = (float)(1 / UGSM_SCALE);
-    int sx = tex_index(((float)(ix + cx) + 0.5f) * sf, Ws);
-    int sy = tex_index(((float)(iy + cy) + 0.5f) * sf, Hs);
-    float v = src3[(size_t)plane * Ws * Hs + (size_t)sy * Ws + sx];
-    dst3[(size_t)plane * Wd * Hd + (size_t)iy * Wd + ix] = (float)(UGSM_SCALE * (double)v);
-}
-
-// fovea-stack / pyramid-stack packing: plain 2-D crop copy of 3 planes
-// (batched: blockIdx.z = 3 x pair + plane)
-__global__ void k_copy_view(Img3 src, int W, int H, float *__restrict__ dst, size_t dst_plane, int dst_pitch, Batch bt)
-{
-    int ix = blockIdx.x * blockDim.x + threadIdx.x;
-    int iy = blockIdx.y;
-    int plane = blockIdx.z;
-    if (bt.n > 1) {
-        const int b = plane / 3;
-        plane -= 3 * b;
-        src.p = shifted(src.p, bt.img[b]);
-        dst = shifted(dst, bt.out[b]);
-    }
-    if (ix >= W) return;
-    dst[(size_t)plane * dst_plane + (size_t)iy * dst_pitch + ix] = src.p[(size_t)plane * src.plane + (size_t)iy * src.pitch + ix];
-}
-
-void launch_seed(hipStream_t st, const float *src3, int Ws, int Hs, float *dst3, int Wd, int Hd, int cx, int cy, const Batch *bt)
-{
-    Batch one{};
-    one.n = 1;
-    const Batch &B = bt ? *bt : one;
-    UGSM_LAUNCH(k_seed, grid2(Wd, Hd, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src3, Ws, Hs, dst3, Wd, Hd, cx, cy, B);
-}
-void launch_copy_view(hipStream_t st, Img3 src, int W, int H, float *dst, size_t dst_plane, int dst_pitch, const Batch *bt)
-{
-    Batch one{};
-    one.n = 1;
-    const Batch &B = bt ? *bt : one;
-    UGSM_LAUNCH(k_copy_view, grid2(W, H, 3 * (B.n > 1 ? B.n : 1)), dim3(256), 0, st, src, W, H, dst, dst_plane, dst_pitch, B);
-}
-// --------------------------------------------------------------------------------------
-// LR-consistency check (BASELINE.json north_star; the reference has none: SURVEY.md 0.4 -- the build's own definition, DESIGN.md
-// section 8; opt-in, off in every parity run).  left3 / right3: (dx, dy, conf) of the left-to-right match and of the match with the
-// images exchanged.  Left pixel (x, y) matches right pixel (x + dx, y + dy) (getPointCloud.cpp:910-913); the right field is fetched
-// there as the matcher fetches (tex_index on the warp's float coordinate, MatchLib.cu:510-515) and must point back within tau in x
-// and in y, or the left confidence becomes 0.  `marked` (may be null) counts the pixels.  One pass: 12 B read + gather, 4 B written.
-__global__ __launch_bounds__(256) void k_lr_check(float *__restrict__ left3, const float *__restrict__ right3, int W, int H, float tau,
-                                                  unsigned long long *__restrict__ marked)
-{
-    const int ix = blockIdx.x * blockDim.x + threadIdx.x, iy = blockIdx.y;
-    bool bad = false;
-    if (ix < W) {
-        const size_t n = (size_t)W * H, at = (size_t)iy * W + ix;
-        const float dxl = left3[at], dyl = left3[n + at];
-        const int sx = tex_index(((float)ix + 0.5f) + dxl, W), sy = tex_index(((float)iy + 0.5f) + dyl, H);
-        const size_t rt = (size_t)sy * W + sx;
-        const float ex = fabsf(dxl + right3[rt]), ey = fabsf(dyl + right3[n + rt]);
-        bad = !(ex <= tau) || !(ey <= tau);
-        if (bad) left3[2 * n + at] = 0.0f;
-    }
-    if (marked) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(bad);
-        if ((threadIdx.x & 63) == 0 && m) atomicAdd(marked, (unsigned long long)__builtin_popcountll(m));
-    }
-}
-void launch_lr_check(hipStream_t st, float *left3, const float *right3, int W, int H, float tau, unsigned long long *marked)
-{
-    UGSM_LAUNCH(k_lr_check, grid2(W, H), dim3(256), 0, st, left3, right3, W, H, tau, marked);
-}
-
-// --------------------------------------------------------------------------------------
-// MatchGPULib.cpp:332-338 : rgb8 interleaved -> 3 planar f32
-__global__ void k_rgb_planes(const uint8_t *__restrict__ rgb, int stride, int W, int H, float *__restrict__ planes)
-{
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    int y = blockIdx.y;
-    if (x >= W) return;
-    const uint8_t *p = rgb + (size_t)y * stride + 3 * x;
-    size_t n = (size_t)W * H, at = (size_t)y * W + x;
-    planes[at] = (float)p[0];
-    planes[n + at] = (float)p[1];
-    planes[2 * n + at] = (float)p[2];
-}
-
-void launch_rgb_planes(hipStream_t st, const uint8_t *rgb, int stride, int W, int H, float *planes)
-{
-    UGSM_LAUNCH(k_rgb_planes, grid2(W, H), dim3(256), 0, st, rgb, stride, W, H, planes);
-}
-
-#ifdef UGSM_DEV_LIB  // kernel_path 1, one kernel per reference stage: the A/B reference of the fused kernels -- in libugsm_dev.so only
 
 // --------------------------------------------------------------------------------------
 // MatchGPULib.cpp:1071-1096 + MatchLib.cu:71-156,195-278,311-339.
@@ -344,7 +232,5 @@ void launch_box_ref(hipStream_t st, const float *s3, float *o3, int W, int H)
 {
     UGSM_LAUNCH(k_box, grid2(W, H, 3), dim3(256), 0, st, s3, o3, W, H);
 }
-#endif  // UGSM_DEV_LIB
-
 
 }  // namespace ugsm

@@ -204,25 +204,4 @@ __device__ __forceinline__ void div3_shared(const float a0, const float a1, cons
     q2 = (float)((double)a2 * r);
 }
 
-// The same three quotients in binary32 (round 5 probe, SMOOTH_NEWTON): one v_rcp_f32 refined by one Newton step, then LowerFDIV32's
-// quotient steps per numerator, operation for operation (div_inrange above with the reciprocal shared).  Exact -- v_div_scale would not
-// have scaled, v_div_fmas is a plain FMA, v_div_fixup passes through -- when s is normal and far from the ends of the range and every
-// numerator is 0 or large enough for its remainders to stay representable; the caller guarantees the ranges.
-__device__ __forceinline__ void div3_newton(const float a0, const float a1, const float a2, const float s, float &q0, float &q1, float &q2)
-{
-    float r = __builtin_amdgcn_rcpf(s);
-    const float e = __builtin_fmaf(-s, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    auto one = [&](const float n) {
-        float q = n * r;
-        const float e0 = __builtin_fmaf(-s, q, n);
-        q = __builtin_fmaf(e0, r, q);
-        const float e1 = __builtin_fmaf(-s, q, n);
-        return __builtin_fmaf(e1, r, q);
-    };
-    q0 = one(a0);
-    q1 = one(a1);
-    q2 = one(a2);
-}
-
 }  // namespace ugsm

@@ -19,6 +19,7 @@ struct CtxHooks {
     void (*shard_free)(ugsm_ctx *, void *) = nullptr;
     bool queue_busy = false;   // pairs are outstanding in the queue: the slots belong to it (slot-level entry points answer UGSM_ERR_STATE)
     bool queue_calling = false;  // ... except while the queue itself is calling them
+    bool queue_more = false;     // (while queue_calling) other calls follow the one being sent: it shares the chip (call_alone)
 };
 CtxHooks &ctx_hooks(ugsm_ctx *ctx);
 const ugsm_config &ctx_config(const ugsm_ctx *ctx);

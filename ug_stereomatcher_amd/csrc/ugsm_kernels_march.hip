@@ -1,10 +1,10 @@
 // ugsm_kernels_march.hip -- K-cost for the large levels as a marching (row-streaming) kernel.
 //
-// Same arithmetic as k_cost_split (ugsm_kernels_fused.hip) and the CPU oracle, bit for bit: one matcher iteration's
+// Same arithmetic as the CPU oracle (and as libugsm_dev.so's LDS-tiled k_cost_split), bit for bit: one matcher iteration's
 // warp + 5-shift squared-NCC cost over 3 channels + parabola + confidence blend + disparity update
 // (matchlevel, /root/reference/src/gpu_matcher/MatchGPULib.cpp:1745-2250 and the MatchLib.cu kernels cited below).
 //
-// Layout: ONE WAVE owns a strip of 64*NP image columns (NP pixels per lane, lanes along the scanline) and marches
+// Layout: ONE WAVE owns a strip of 64 image columns (one pixel per lane, lanes along the scanline) and marches
 // down the rows.  Nothing goes through LDS and there is no barrier:
 //   * horizontal neighbours (the +-1 shifts, the 5-tap row passes, B at x+-1) are the neighbouring lanes' registers,
 //     read by DPP wave shifts that the compiler folds into the consuming v_add/v_mul;
@@ -15,24 +15,23 @@
 //     (3 products shared between the outputs they feed + 4 adds) instead of 9;
 //   * global loads run two rows ahead ((dx,dy)) / one row ahead (the warped gather of R, L, A) of the arithmetic.
 // Per pixel-iteration this is ~720 VALU lane-instructions against ~1080 in the LDS-tiled kernel (SQ_INSTS_VALU, profiles/),
-// with the halo recomputed only 6 rows per strip (tile: 6 rows per 28) and 6 columns per 64*NP.
+// with the halo recomputed only 6 rows per strip (tile: 6 rows per 28) and 6 columns per 64.
 //
 // Border semantics without cross-lane fix-ups: a lane whose pixel lies outside the image computes
 // the warp at the CLAMPED pixel, which is what a clamp-addressed fetch of R' returns (texture clamp, MatchLib.cu:56-60),
 // so R' is edge-replicated by construction; L is taken as zero outside (zero-padded smem convolution of the products,
 // SURVEY 9 U2/U3); only the five B fetches at clamped positions need a select, in the strips that touch the frame.
 //
-// FMAD (development switch, not reachable through the C-ABI): evaluates the convolutions as FMA chains, the
-// way nvcc's default -fmad=true may contract `sum += tap * k`.  Measured slower than the literal form; no parity claim.
+// What was measured and not kept -- two pixels per lane (spills at any occupancy that pays), FMA-contracted convolutions (slower, and no
+// parity claim), row passes chain after chain instead of in lockstep, row clamps in the interior strips, s_setprio: docs/HISTORY.md,
+// profiles/r05_kbench_march_issue.txt.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
 #include <type_traits>
 
 namespace ugsm {
 
-typedef float __attribute__((ext_vector_type(2), aligned(4))) f2u;  // two floats, dword aligned (rows of odd width)
-typedef __attribute__((address_space(1))) const f2u gf2u_c;
-typedef __attribute__((address_space(1))) f2u gf2u;
+constexpr int NP = 1;  // pixels a lane holds (the per-lane values are kept as arrays of NP)
 
 // value of the lane below / above (lane 0 / lane 63 read 0: those lanes hold strip halo whose results are dropped)
 __device__ __forceinline__ float shr1(float v)  // from lane - 1
@@ -44,64 +43,31 @@ __device__ __forceinline__ float shl1(float v)  // from lane + 1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
-// the value of `v` at pixel column (own column j) + OFF, OFF = -1 or +1
-template <int NP, int OFF>
-__device__ __forceinline__ float nbr(const float (&v)[NP], const int j)
+// the value of `v` at the pixel column next to the lane's own: OFF = -1 or +1
+template <int OFF>
+__device__ __forceinline__ float nbr(const float (&v)[NP])
 {
     static_assert(OFF == -1 || OFF == 1, "");
-    if constexpr (NP == 1) {
-        return OFF < 0 ? shr1(v[0]) : shl1(v[0]);
-    } else {
-        if (OFF < 0) return j == 0 ? shr1(v[1]) : v[0];
-        return j == 0 ? v[1] : shl1(v[0]);
-    }
+    return OFF < 0 ? shr1(v[0]) : shl1(v[0]);
 }
 
 // 5-tap row pass over the lane-distributed row p, taps added in the reference's order j = -2..2.
 // Products are >= +0 so the reference's leading "0 +" is exact (tap5p, ugsm_exact.hpp).
-template <int NP, bool FMAD>
 __device__ __forceinline__ void rowconv5(const float (&p)[NP], float (&out)[NP])
 {
-    if constexpr (NP == 2) {
-        if constexpr (!FMAD) {
-            const float a0A = p[0] * UGSM_G0, a1A = p[0] * UGSM_G1, a2A = p[0] * UGSM_G2;
-            const float a0B = p[1] * UGSM_G0, a1B = p[1] * UGSM_G1, a2B = p[1] * UGSM_G2;
-            const float t = a0A + a1B;  // taps -2, -1 of the NEXT lane's first pixel
-            out[0] = ((shr1(t) + a2A) + a1B) + shl1(a0A);
-            out[1] = (((shr1(a0B) + a1A) + a2B) + shl1(a1A)) + shl1(a0B);
-        } else {
-            const float t = __builtin_fmaf(p[1], UGSM_G1, p[0] * UGSM_G0);
-            out[0] = __builtin_fmaf(shl1(p[0]), UGSM_G0, __builtin_fmaf(p[1], UGSM_G1, __builtin_fmaf(p[0], UGSM_G2, shr1(t))));
-            out[1] = __builtin_fmaf(shl1(p[1]), UGSM_G0,
-                                    __builtin_fmaf(shl1(p[0]), UGSM_G1, __builtin_fmaf(p[1], UGSM_G2, __builtin_fmaf(p[0], UGSM_G1, shr1(p[1]) * UGSM_G0))));
-        }
-    } else {
-        // one pixel per lane: the partial sum travels one lane to the right per tap (systolic), so every add takes its
-        // left operand through DPP and no separate lane move is needed; the finished sum of the window centred on column c
-        // arrives in lane c + 2 (March<1>::SKEW): everything downstream of a row pass lives two lanes right of its pixel
-        if constexpr (!FMAD) {
-            const float a0 = p[0] * UGSM_G0, a1 = p[0] * UGSM_G1, a2 = p[0] * UGSM_G2;
-            const float p2 = shr1(a0) + a1;
-            const float p3 = shr1(p2) + a2;
-            const float p4 = shr1(p3) + a1;
-            out[0] = shr1(p4) + a0;
-        } else {
-            const float p1 = p[0] * UGSM_G0;
-            const float p2 = __builtin_fmaf(p[0], UGSM_G1, shr1(p1));
-            const float p3 = __builtin_fmaf(p[0], UGSM_G2, shr1(p2));
-            const float p4 = __builtin_fmaf(p[0], UGSM_G1, shr1(p3));
-            out[0] = __builtin_fmaf(p[0], UGSM_G0, shr1(p4));
-        }
-    }
+    // the partial sum travels one lane to the right per tap (systolic), so every add takes its left operand through DPP and no
+    // separate lane move is needed; the finished sum of the window centred on column c arrives in lane c + 2 (March::SKEW):
+    // everything downstream of a row pass lives two lanes right of its pixel
+    const float a0 = p[0] * UGSM_G0, a1 = p[0] * UGSM_G1, a2 = p[0] * UGSM_G2;
+    const float p2 = shr1(a0) + a1;
+    const float p3 = shr1(p2) + a2;
+    const float p4 = shr1(p3) + a1;
+    out[0] = shr1(p4) + a0;
 }
 
-// MARCH_ILV (development switch, tools/kbench only): the N systolic row passes of one colour channel -- R'^2 and the
-// five products -- advance in LOCKSTEP, stage by stage, instead of chain after chain: between a chain's VALU result and the DPP read of it
-// one stage later lie N - 1 independent instructions, so the two wait states of the VALU-write -> DPP-read hazard need no s_nop.
-// 1: lockstep in source order; 2: lockstep pinned by scheduling barriers between the stages.  Same operations, same results bit for bit.
-#ifndef MARCH_ILV
-#define MARCH_ILV 1
-#endif
+// The N systolic row passes of one colour channel -- R'^2 and the five products -- advance in LOCKSTEP, stage by stage, instead of chain
+// after chain: between a chain's VALU result and the DPP read of it one stage later lie N - 1 independent instructions, so the two wait
+// states of the VALU-write -> DPP-read hazard need no s_nop (978 -> 191 in the kernel; profiles/r05_kbench_march_issue.txt).
 template <int N>
 __device__ __forceinline__ void rowconv5_lockstep(const float (&v)[N], float (&out)[N])
 {
@@ -114,66 +80,40 @@ __device__ __forceinline__ void rowconv5_lockstep(const float (&v)[N], float (&o
     }
 #pragma unroll
     for (int c = 0; c < N; c++) t[c] = shr1(a0[c]) + a1[c];
-    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a2[c];
-    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < N; c++) t[c] = shr1(t[c]) + a1[c];
-    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < N; c++) out[c] = shr1(t[c]) + a0[c];
-    if (MARCH_ILV >= 2) __builtin_amdgcn_sched_barrier(0);
 }
 
 // One step of the transposed-form 5-tap column pass: `h` is the row-pass value of the row that has just arrived;
 // s[0..3] hold the partial sums of the four output rows still open.  Returns the sum of the row that closes (two rows up).
-template <bool FMAD>
 __device__ __forceinline__ float colstep5(float (&s)[4], const float h)
 {
-    if constexpr (!FMAD) {
-        const float a0 = h * UGSM_G0, a1 = h * UGSM_G1, a2 = h * UGSM_G2;
-        const float out = s[3] + a0;
-        s[3] = s[2] + a1;
-        s[2] = s[1] + a2;
-        s[1] = s[0] + a1;
-        s[0] = a0;
-        return out;
-    } else {
-        const float out = __builtin_fmaf(h, UGSM_G0, s[3]);
-        s[3] = __builtin_fmaf(h, UGSM_G1, s[2]);
-        s[2] = __builtin_fmaf(h, UGSM_G2, s[1]);
-        s[1] = __builtin_fmaf(h, UGSM_G1, s[0]);
-        s[0] = h * UGSM_G0;
-        return out;
-    }
+    const float a0 = h * UGSM_G0, a1 = h * UGSM_G1, a2 = h * UGSM_G2;
+    const float out = s[3] + a0;
+    s[3] = s[2] + a1;
+    s[2] = s[1] + a2;
+    s[1] = s[0] + a1;
+    s[0] = a0;
+    return out;
 }
 
-#ifndef MARCH_WAVES
-#define MARCH_WAVES(NP) ((NP) == 2 ? 2 : 3)
-#endif
-template <int NP>
+constexpr int kMarchWaves = 3;  // waves per SIMD the register allocation aims at
 struct March {
-    static constexpr int COLS = 64 * NP;  // columns a wave holds
+    static constexpr int COLS = 64;       // columns a wave holds
     static constexpr int VX = COLS - 6;   // columns it produces (halo 3 on both sides)
-    static constexpr int SKEW = (NP == 1) ? 2 : 0;  // lanes between a pixel and the results of its row passes (rowconv5)
-    static constexpr int ORG = (NP == 2) ? -1 : 0;  // first output column of strip 0 (-1 for NP = 2: lane 0's first pixel, three
-                                                    // columns further left, then sits on an even column and the pixel pairs
-                                                    // of a lane are 8-byte aligned when the row pitch is even)
+    static constexpr int SKEW = 2;        // lanes between a pixel and the results of its row passes (rowconv5)
+    static constexpr int ORG = 0;         // first output column of strip 0
 };
 
 // loads of one image row into the lane-distributed form: uniform plane base + the lanes' 32-bit byte offsets
-template <int NP, bool EDGE>
 __device__ __forceinline__ void ld_row(gchar_c *base, const unsigned (&off)[NP], float (&o)[NP])
 {
-    if constexpr (NP == 2 && !EDGE) {
-        const f2u t = *(gf2u_c *)(base + off[0]);
-        o[0] = t.x;
-        o[1] = t.y;
-    } else {
 #pragma unroll
-        for (int j = 0; j < NP; j++) o[j] = ld_at(base, off[j]);
-    }
+    for (int j = 0; j < NP; j++) o[j] = ld_at(base, off[j]);
 }
 
 // tex_index (ugsm_device.hpp) without branches: floor, clamp to [0, n-1] in float, convert.  v_med3_f32 returns
@@ -185,7 +125,6 @@ __device__ __forceinline__ int tex_index_nb(const float coord, const float nm1)
 }
 
 // what the load pipeline holds for one row r: (dx,dy)(r+1), the gathered R'(r), L(r-1), A(r-3) and the strip's own (dx,dy,conf)(r-3)
-template <int NP>
 struct MarchRow {
     float dx[NP], dy[NP];
     float R[3][NP], L[3][NP], A[3][NP], O[3][NP];
@@ -195,7 +134,7 @@ struct MarchRow {
 // iteration reads is subsampleDispKernel's value (MatchLib.cu:372-401, k_seed in ugsm_kernels_ref.hip) formed on the fly,
 // SCALE * coarse[floor((x + cx + .5f) * sf), floor((y + cy + .5f) * sf)] with the product in binary64 -- the seeded field is never
 // written to memory (at 16 MP: 290 MB and a 95 us launch per level saved for ~3 % more arithmetic in this one iteration).
-template <int NP, bool EDGE, bool FMAD, bool FAST, bool SEED = false>
+template <bool EDGE, bool FAST, bool SEED = false>
 __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                 float *__restrict__ nd3, const int W, const int H, const float thr, const int blend,
                                                 const int X0, const int xs, const int xe, const int ys, const int ye, const SeedMap sm = SeedMap{0, 0, 0, 0})
@@ -211,7 +150,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
 
     // per-lane column constants.  px: the pixel whose R', L and products the lane holds; po = px - SKEW: the pixel whose row-pass
     // results (N, B), A, own (dx,dy,conf) and output it holds
-    constexpr int SKEW = March<NP>::SKEW;
+    constexpr int SKEW = March::SKEW;
     int px[NP], po[NP];
     unsigned coff[NP], coffo[NP];  // byte offsets of the (clamped) columns px / po inside a row
     float xc[NP];                  // warp x coordinate of the (clamped) pixel centre
@@ -242,12 +181,9 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     };
     const unsigned pitchW = (unsigned)W * 4u, pitchL = (unsigned)L.pitch * 4u;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    // rows are clamped with scalar ops in every strip (MARCH_NOCLAMP, development switch, VERDICT r04 #3 (ii): not in the interior strips,
-    // which then must keep six rows clear of the frame -- see `interior` in k_cost_march)
-#ifndef MARCH_NOCLAMP
-#define MARCH_NOCLAMP 1
-#endif
-    auto rowc = [&](int r) { return (MARCH_NOCLAMP && !EDGE) ? r : min(max(r, 0), H - 1); };
+    // rows are clamped (scalar ops) only in the strips that touch the frame: an interior strip keeps six rows clear of it (`interior`,
+    // k_cost_march)
+    auto rowc = [&](int r) { return !EDGE ? r : min(max(r, 0), H - 1); };
     auto row_off = [&](const int r, const unsigned pitch, unsigned (&off)[NP], const bool skewed = false) {
         const unsigned ro = (unsigned)rowc(r) * pitch;
 #pragma unroll
@@ -267,8 +203,8 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     auto load_d = [&](const int r, float (&dx)[NP], float (&dy)[NP]) {
         unsigned off[NP];
         d_off(r, off, false);
-        ld_row<NP, EDGE || SEED>(Db[0], off, dx);
-        ld_row<NP, EDGE || SEED>(Db[1], off, dy);
+        ld_row(Db[0], off, dx);
+        ld_row(Db[1], off, dy);
     };
     // warpAbyB (MatchLib.cu:510-515): R'[x,y] = tex(R, x + 0.5 + dx, y + 0.5 + dy) at the clamped pixel
     auto gather = [&](const int r, const float (&dx)[NP], const float (&dy)[NP], float (&o)[3][NP]) {
@@ -286,17 +222,17 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
         unsigned off[NP];
         row_off(r, pitchL, off);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Lb[k], off, o[k]);
+        for (int k = 0; k < 3; k++) ld_row(Lb[k], off, o[k]);
     };
     auto load_AO = [&](const int r, float (&a)[3][NP], float (&od)[3][NP]) {
         unsigned off[NP];
         row_off(r, pitchW, off, true);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE>(Ab[k], off, a[k]);
+        for (int k = 0; k < 3; k++) ld_row(Ab[k], off, a[k]);
         unsigned offd[NP];
         d_off(r, offd, true);
 #pragma unroll
-        for (int k = 0; k < 3; k++) ld_row<NP, EDGE || SEED>(Db[k], offd, od[k]);
+        for (int k = 0; k < 3; k++) ld_row(Db[k], offd, od[k]);
     };
 
     // ---- state carried down the rows --------------------------------------------------------------------------
@@ -320,7 +256,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     // One row step.  `cur` holds row r's loads (issued during the previous step); the next row's loads are issued into
     // `nxt` before the arithmetic.  The two sets swap roles from step to step (the row loop is unrolled by two), so a
     // loaded register is never copied: a copy would have to wait for its load and would end the prefetch.
-    auto step = [&](const int r, MarchRow<NP> &cur, MarchRow<NP> &nxt) {
+    auto step = [&](const int r, MarchRow &cur, MarchRow &nxt) {
         load_d(r + 2, nxt.dx, nxt.dy);
         gather(r + 1, cur.dx, cur.dy, nxt.R);
         load_L(r, nxt.L);
@@ -340,11 +276,10 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 rc[j] = cur.R[k][j];
                 sq[j] = rc[j] * rc[j];  // Square, MatchLib.cu:569-570
             }
-            constexpr bool ILV = MARCH_ILV != 0 && NP == 1 && !FMAD;
-            if (!(ILV && do_prod)) {
-                rowconv5<NP, FMAD>(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
+            if (!do_prod) {  // (the strip's first rows: only B is due)
+                rowconv5(sq, hb);  // convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp): B
 #pragma unroll
-                for (int j = 0; j < NP; j++) bnew[j] = colstep5<FMAD>(aB[k][j], hb[j]);  // = B(r-2)
+                for (int j = 0; j < NP; j++) bnew[j] = colstep5(aB[k][j], hb[j]);  // = B(r-2)
             }
             if (do_prod) {
                 float l[NP], p[5][NP], Nv[5][NP];
@@ -352,33 +287,26 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 for (int j = 0; j < NP; j++) l[j] = (cin[j] && yin) ? cur.L[k][j] : 0.0f;
 #pragma unroll
                 for (int j = 0; j < NP; j++) {  // CompareMove, MatchLib.cu:622-624
-                    p[0][j] = l[j] * nbr<NP, -1>(Rm1[k], j);  // shift (-1, 0)
-                    p[1][j] = l[j] * nbr<NP, +1>(Rm1[k], j);  // shift (+1, 0)
+                    p[0][j] = l[j] * nbr<-1>(Rm1[k]);  // shift (-1, 0)
+                    p[1][j] = l[j] * nbr<+1>(Rm1[k]);  // shift (+1, 0)
                     p[2][j] = l[j] * Rm2[k][j];               // shift (0, -1)
                     p[3][j] = l[j] * rc[j];                   // shift (0, +1)
                     p[4][j] = l[j] * Rm1[k][j];               // shift (0, 0)
                 }
-                if constexpr (ILV) {  // the six row passes of the channel in lockstep (MARCH_ILV)
+                {   // the six row passes of the channel in lockstep: B (convolutionRowsKernelT / ColumnsKernelT on R'^2, clamp) and N_s(r-3)
+                    // (convolutionRowsKernel / ColumnsKernel on the products, zero padded)
                     const float v6[6] = {sq[0], p[0][0], p[1][0], p[2][0], p[3][0], p[4][0]};
                     float h6[6];
                     rowconv5_lockstep<6>(v6, h6);
-                    bnew[0] = colstep5<false>(aB[k][0], h6[0]);
+                    bnew[0] = colstep5(aB[k][0], h6[0]);
 #pragma unroll
-                    for (int s = 0; s < 5; s++) Nv[s][0] = colstep5<false>(aN[k][s][0], h6[s + 1]);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 5; s++) {  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
-                        float h[NP];
-                        rowconv5<NP, FMAD>(p[s], h);
-#pragma unroll
-                        for (int j = 0; j < NP; j++) Nv[s][j] = colstep5<FMAD>(aN[k][s][j], h[j]);
-                    }
+                    for (int s = 0; s < 5; s++) Nv[s][0] = colstep5(aN[k][s][0], h6[s + 1]);
                 }
                 if (do_out) {
 #pragma unroll
                     for (int j = 0; j < NP; j++) {
                         const float a = cur.A[k][j], bc = Bm1[k][j];
-                        float bl = nbr<NP, -1>(Bm1[k], j), br = nbr<NP, +1>(Bm1[k], j), bu = Bm2[k][j], bd = bnew[j];
+                        float bl = nbr<-1>(Bm1[k]), br = nbr<+1>(Bm1[k]), bu = Bm2[k][j], bd = bnew[j];
                         if constexpr (EDGE) {  // B at the clamped position (MatchLib.cu:676-679)
                             bl = (po[j] <= 0) ? bc : bl;
                             br = (po[j] >= W - 1) ? bc : br;
@@ -419,26 +347,10 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
                 nkp[j] = kap;
             }
             const unsigned ro = (unsigned)o * pitchW;
-            if constexpr (NP == 2) {
-                if (stv[0] && stv[1]) {
-                    *(gf2u *)((gchar *)Nb[0] + (ro + coffo[0])) = f2u{ndx[0], ndx[1]};
-                    *(gf2u *)((gchar *)Nb[1] + (ro + coffo[0])) = f2u{ndy[0], ndy[1]};
-                    *(gf2u *)((gchar *)Nb[2] + (ro + coffo[0])) = f2u{nkp[0], nkp[1]};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NP; j++)
-                        if (stv[j]) {
-                            st_at(Nb[0], ro + coffo[j], ndx[j]);
-                            st_at(Nb[1], ro + coffo[j], ndy[j]);
-                            st_at(Nb[2], ro + coffo[j], nkp[j]);
-                        }
-                }
-            } else {
-                if (stv[0]) {
-                    st_at(Nb[0], ro + coffo[0], ndx[0]);
-                    st_at(Nb[1], ro + coffo[0], ndy[0]);
-                    st_at(Nb[2], ro + coffo[0], nkp[0]);
-                }
+            if (stv[0]) {
+                st_at(Nb[0], ro + coffo[0], ndx[0]);
+                st_at(Nb[1], ro + coffo[0], ndy[0]);
+                st_at(Nb[2], ro + coffo[0], nkp[0]);
             }
         }
     };
@@ -446,7 +358,7 @@ __device__ __forceinline__ void cost_march_body(const Img3 &L, const Img3 &R, co
     // ---- prologue of the load pipeline, then the row loop (two steps per trip) ---------------------------------
     int r = ys - 3;
     const int r_end = ye + 2;  // last R' row any output of the strip needs
-    MarchRow<NP> P0, P1;
+    MarchRow P0, P1;
     {
         float d0x[NP], d0y[NP];
         load_d(r, d0x, d0y);
@@ -505,12 +417,8 @@ __device__ __forceinline__ bool march_strip_cls(const StripClasses &sc, const in
     ye = min(ys + sc.hc[cls], H);
     return ys < H;
 }
-#ifdef UGSM_MARCH_STAMP
-__device__ long long *g_march_stamps = nullptr;  // per wave: delta s_memtime, delta s_memrealtime, start s_memrealtime, hardware ids (never read by the kernel)
-#endif
-// grid: one wave (64 threads) per strip of March<NP>::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
-template <int NP, bool FMAD>
-__global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
+// grid: one wave (64 threads) per strip of March::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
+__global__ __launch_bounds__(64 * MARCH_WPB, kMarchWaves) void k_cost_march(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                                       float *__restrict__ nd3, int W, int H, float thr, int blend, int strips_x,
                                                                       int n_strips, int Hs, const unsigned *__restrict__ range_bad, SeedMap sm, StripClasses sc,
                                                                       Batch bt)
@@ -526,9 +434,6 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
         sm.cx = bt.cx[b];
         sm.cy = bt.cy[b];
     }
-#ifdef UGSM_MARCH_STAMP  // diagnostic build only (tools/kbench_stamp): in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz
-    const long long st_t0 = (long long)__builtin_amdgcn_s_memtime(), st_r0 = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
     int sx, sy, ys, ye;
     if (sc.ncls > 1) {  // (kernel-uniform) strips by age class; n_strips = strips per class group count x strips_x is passed as Hs = groups
         if (!march_strip_cls(sc, strips_x, Hs, H, sx, ys, ye)) return;
@@ -537,43 +442,30 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
         ys = sy * Hs;
         ye = min(ys + Hs, H);
     }
-    const int xs = sx * March<NP>::VX + March<NP>::ORG;
-    const int xe = min(xs + March<NP>::VX, W);
+    const int xs = sx * March::VX + March::ORG;
+    const int xe = min(xs + March::VX, W);
     const int X0 = xs - 3;
-    // interior: every pixel a lane holds lies inside the image, and so do the product rows ys-2 .. ye+1 (L is zero outside)
-    // and the rows ys-1 .. ye of the B fetches
-    const bool interior = X0 >= 0 && X0 + March<NP>::COLS <= W && (MARCH_NOCLAMP ? (ys >= 6 && ye <= H - 6) : (ys >= 2 && ye <= H - 2));
+    // interior: every pixel a lane holds lies inside the image, and so does every row the strip loads (ys - 6 .. ye + 5: no row clamp)
+    const bool interior = X0 >= 0 && X0 + March::COLS <= W && ys >= 6 && ye <= H - 6;
     // range-guarded division (ugsm_exact.hpp) when the pyramid builder found every value of the pair in range
     const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
-    if constexpr (NP == 1 && !FMAD) {
-        if (sm.Ws > 0) {  // first iteration of a level, seeded from the coarser level's field (kernel-uniform)
-            if (fast) {
-                if (interior) cost_march_body<NP, false, FMAD, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
-                else cost_march_body<NP, true, FMAD, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
-            } else {
-                if (interior) cost_march_body<NP, false, FMAD, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
-                else cost_march_body<NP, true, FMAD, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
-            }
-            return;
+    if (sm.Ws > 0) {  // first iteration of a level, seeded from the coarser level's field (kernel-uniform)
+        if (fast) {
+            if (interior) cost_march_body<false, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+            else cost_march_body<true, true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+        } else {
+            if (interior) cost_march_body<false, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
+            else cost_march_body<true, false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye, sm);
         }
+        return;
     }
     if (fast) {
-        if (interior) cost_march_body<NP, false, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
-        else cost_march_body<NP, true, FMAD, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        if (interior) cost_march_body<false, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        else cost_march_body<true, true>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
     } else {
-        if (interior) cost_march_body<NP, false, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
-        else cost_march_body<NP, true, FMAD, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        if (interior) cost_march_body<false, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
+        else cost_march_body<true, false>(L, R, A3, d3, nd3, W, H, thr, blend, X0, xs, xe, ys, ye);
     }
-#ifdef UGSM_MARCH_STAMP
-    if (g_march_stamps && (threadIdx.x & 63) == 0) {
-        const size_t w = (size_t)blockIdx.x * MARCH_WPB + (threadIdx.x >> 6);
-        g_march_stamps[4 * w] = (long long)__builtin_amdgcn_s_memtime() - st_t0;
-        g_march_stamps[4 * w + 1] = (long long)__builtin_amdgcn_s_memrealtime() - st_r0;
-        g_march_stamps[4 * w + 2] = st_r0;  // when the wave started (100 MHz ticks)
-        // where it ran: HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE) and HW_REG_XCC_ID
-        g_march_stamps[4 * w + 3] = ((long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-    }
-#endif
 }
 
 // Strip height of the marching K-cost.  Every strip is resident at once when there are at most 1024 x w of them (256 CUs x 4 SIMDs,
@@ -584,15 +476,11 @@ __global__ __launch_bounds__(64 * MARCH_WPB, MARCH_WAVES(NP)) void k_cost_march(
 // matter there), levels around 1 Mpx at one or two waves per SIMD with 10-18 rows.
 // `throughput` (several pairs in flight: other pairs' kernels share the SIMDs whatever this launch does): the tallest strips that
 // are still all resident -- the fewest halo rows.
-int march_strip_rows(int W, int H, int np, int throughput, int pairs)
+int march_strip_rows(int W, int H, int throughput, int pairs)
 {
-#ifndef UGSM_DEV_KERNELS
-    np = 1;
-#endif
-    const int vx = np == 2 ? March<2>::VX : March<1>::VX, org = np == 2 ? March<2>::ORG : March<1>::ORG;
-    const int strips_x = ((W - org + vx - 1) / vx) * (pairs > 1 ? pairs : 1);  // (a batched launch: the strips of all its pairs share the chip)
+    const int strips_x = ((W - March::ORG + March::VX - 1) / March::VX) * (pairs > 1 ? pairs : 1);  // (a batched launch: the strips of all its pairs share the chip)
     static const float t_step[3] = {1.57f, 1.83f, 2.6f}, extra[3] = {4.3f, 7.3f, 6.5f};
-    const int max_w = np == 2 ? MARCH_WAVES(2) : MARCH_WAVES(1);
+    const int max_w = kMarchWaves;
     float best = 0.0f;
     int Hs = 6;
     for (int w = throughput ? (max_w < 3 ? max_w : 3) : 1; w <= max_w && w <= 3; w++) {
@@ -616,20 +504,18 @@ int march_strip_rows(int W, int H, int np, int throughput, int pairs)
 // A pair alone gains 1 % (108.4 -> 109.5 pairs/s); with four pairs in flight nothing changes (161.7 -> 161.6): there the SIMD slots
 // the finished first waves leave behind are taken by the other pairs' kernels anyway.
 int march_age_permille[2] = {470, 340};
-template <int NP>
 static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend,
-                                int fmad, int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0}, const Batch *bt = nullptr)
+                                int rows, const unsigned *range_bad, SeedMap sm = SeedMap{0, 0, 0, 0}, const Batch *bt = nullptr)
 {
     Batch one{};
     one.n = 1;
     const Batch &B = bt ? *bt : one;
     const int pairs = B.n > 1 ? B.n : 1;
-    const int VX = March<NP>::VX;
-    const int strips_x = (W - March<NP>::ORG + VX - 1) / VX;
+    const int strips_x = (W - March::ORG + March::VX - 1) / March::VX;
     // rows: > 0 a fixed strip height; 0 the latency heights and strips by age class; -1 the latency heights, no age classes; -2 the
     // throughput heights, no age classes; -3 the throughput heights and age classes
     const bool age = (rows == 0 || rows == -3) && pairs == 1, tput = rows == -2 || rows == -3;  // (age classes count on blockIdx.x being the dispatch order)
-    int Hs = rows > 0 ? rows : march_strip_rows(W, H, NP, tput, pairs);
+    int Hs = rows > 0 ? rows : march_strip_rows(W, H, tput, pairs);
     int strips_y = (H + Hs - 1) / Hs;
     int n_strips = strips_x * strips_y;
     int n_blocks = (n_strips + MARCH_WPB - 1) / MARCH_WPB;
@@ -637,7 +523,7 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
     // three waves per SIMD (the large levels: every strip resident at once, 3 x 1024 of them): strips by age class.  One dispatch
     // round = one workgroup per CU, so a class is exactly `cus` workgroups (blockIdx / cus = the wave's rank on its SIMD); the
     // strips of a class must fit into them (4 x cus strips), which fixes the number of strip groups and with it the group height.
-    if (NP == 1 && age && march_age_permille[0] > 0 && n_strips > 2 * 1024 && n_strips <= 3 * 1024 + strips_x) {
+    if (age && march_age_permille[0] > 0 && n_strips > 2 * 1024 && n_strips <= 3 * 1024 + strips_x) {
         const int cus = 256;
         const int n_groups = (MARCH_WPB * cus) / strips_x;
         const int Hg = n_groups > 0 ? (H + n_groups - 1) / n_groups : 0;
@@ -650,448 +536,19 @@ static void launch_cost_march_t(hipStream_t st, Img3 L, Img3 R, const float *A3,
             n_strips = 3 * strips_x * Hs;
         }
     }
-#ifdef UGSM_DEV_KERNELS
-    if (fmad) {
-        UGSM_LAUNCH((k_cost_march<NP, true>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
-        return;
-    }
-#endif
-    (void)fmad;
-    UGSM_LAUNCH((k_cost_march<NP, false>), dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
+    UGSM_LAUNCH(k_cost_march, dim3(n_blocks, pairs), dim3(64 * MARCH_WPB), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, sc, B);
 }
 
 void launch_cost_march_seeded(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *coarse3, SeedMap sm, float *nd3, int W, int H, float thr,
                               int blend, int rows, const unsigned *range_bad, const Batch *bt)
 {
-    launch_cost_march_t<1>(st, L, R, A3, coarse3, nd3, W, H, thr, blend, 0, rows, range_bad, sm, bt);
+    launch_cost_march_t(st, L, R, A3, coarse3, nd3, W, H, thr, blend, rows, range_bad, sm, bt);
 }
 
-void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int fmad,
-                       int np, int rows, const unsigned *range_bad, const Batch *bt)
+void launch_cost_march(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *d3, float *nd3, int W, int H, float thr, int blend, int rows,
+                       const unsigned *range_bad, const Batch *bt)
 {
-    // The product library holds the one-pixel-per-lane, literal-contract kernel only.  The two development forms -- two pixels per
-    // lane (spills at any occupancy that pays) and FMA-contracted convolutions (no parity claim; slower) -- are instantiated by
-    // tools/kbench.hip, which defines UGSM_DEV_KERNELS; here `np` and `fmad` are ignored.
-#ifdef UGSM_DEV_KERNELS
-    if (np == 2) {
-        launch_cost_march_t<2>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad, SeedMap{0, 0, 0, 0}, bt);
-        return;
-    }
-#endif
-    (void)np;
-    launch_cost_march_t<1>(st, L, R, A3, d3, nd3, W, H, thr, blend, fmad, rows, range_bad, SeedMap{0, 0, 0, 0}, bt);
+    launch_cost_march_t(st, L, R, A3, d3, nd3, W, H, thr, blend, rows, range_bad, SeedMap{0, 0, 0, 0}, bt);
 }
-
-#ifdef UGSM_DEV_LIB  // k_smooth_march: built, bit-exact, measured slower than the LDS-tiled K-smooth -- in libugsm_dev.so only
-// =========================================================================================
-// K-smooth for the large levels, marching form: PASSES confidence-weighted Jacobi passes (smoothKernel,
-// MatchLib.cu:1092-1145; MatchGPULib.cpp:2262-2292) and the 3x3 box (convolutionRows/ColumnsKernelTa, MatchLib.cu:1593-1697;
-// MatchGPULib.cpp:2361-2412) in one launch, the passes pipelined down the rows in registers: when input row t arrives, pass s
-// produces its row t-s from the three newest rows of pass s-1.  Same wave-per-strip layout as the marching K-cost: west / east
-// neighbours by DPP from the neighbouring lanes, north / south from the rows kept in registers (a ring of three rows per pass,
-// the row loop unrolled by three so that the ring turns without register copies), no LDS, no barrier.
-//   * A pixel's weighted terms v*kappa (v = dx, dy, kappa) are formed once, when its row is produced, and reused by the five
-//     stencils the pixel takes part in: 3 multiplications per pixel and pass instead of 15.  A ring row holds kappa and the
-//     three products.
-//   * The three quotients of a pixel share one binary64 reciprocal (div3_shared, ugsm_exact.hpp), with the literal
-//     division for denominators outside its range, as in the LDS-tiled kernel.
-//   * Borders (strips that touch the frame only): rows <= 0 and columns <= 0 pass through -- with clamped loads the lanes left
-//     of / above the image then hold copies of column 0 / row 0, which is also what the clamp-addressed box reads there; a
-//     lane right of the image copies the last column's result after every pass (the east neighbour of column W-1 is column
-//     W-1 itself, MatchLib.cu:1120), and a row below the image copies the last row.
-// =========================================================================================
-template <int NP, int OFF>
-__device__ __forceinline__ float nbr2(const float (&v)[NP], const int j)  // column (own column j) + OFF, |OFF| <= 2
-{
-    if constexpr (OFF == -1 || OFF == 1) return nbr<NP, OFF>(v, j);
-    else if constexpr (NP == 1) return OFF < 0 ? shr1(shr1(v[0])) : shl1(shl1(v[0]));
-    else return OFF < 0 ? shr1(v[j]) : shl1(v[j]);
-}
-
-template <int NP>
-struct SRow {
-    float k[NP];     // kappa of the row
-    float p[3][NP];  // dx*kappa, dy*kappa, kappa*kappa
-};
-
-template <int NP, int PASSES, bool BOX>
-struct SmoothMarch {
-    static constexpr int HALO = PASSES + (BOX ? 2 : 0);
-    static constexpr int COLS = 64 * NP;
-    static constexpr int VX = COLS - 2 * HALO - (NP == 2 ? 1 : 0);  // NP = 2: one spare column so that lane 0 can sit on an even column
-};
-
-template <int NP, int PASSES, bool BOX, bool EDGE>
-__device__ __forceinline__ void smooth_march_body(const float *__restrict__ s3, float *__restrict__ o3, const int W, const int H, const int X0,
-                                                  const int xs, const int xe, const int ys, const int ye)
-{
-    constexpr int HALO = SmoothMarch<NP, PASSES, BOX>::HALO;
-    const int lane = threadIdx.x & 63;
-    const size_t n = (size_t)W * H;
-    gchar_c *const Sb[3] = {uniform_base(s3), uniform_base(s3 + n), uniform_base(s3 + 2 * n)};
-    gchar_c *const Ob[3] = {uniform_base(o3), uniform_base(o3 + n), uniform_base(o3 + 2 * n)};
-    int px[NP];
-    unsigned coff[NP];
-    bool stv[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-        px[j] = X0 + NP * lane + j;
-        coff[j] = (unsigned)(EDGE ? clampi(px[j], 0, W - 1) : px[j]) * 4u;
-        stv[j] = px[j] >= xs && px[j] < xe;
-    }
-    const unsigned pitchW = (unsigned)W * 4u;
-    auto load_row = [&](const int r, float (&v)[3][NP]) {
-        const unsigned ro = (unsigned)min(max(r, 0), H - 1) * pitchW;
-        unsigned off[NP];
-#pragma unroll
-        for (int j = 0; j < NP; j++) off[j] = ro + coff[j];
-#pragma unroll
-        for (int f = 0; f < 3; f++) ld_row<NP, EDGE>(Sb[f], off, v[f]);
-    };
-    // the lane and slot that hold column W-1 (EDGE strips whose lanes reach past the image)
-    const int last_l = EDGE ? (W - 1 - X0) / NP : 0, last_j = EDGE ? (W - 1 - X0) - last_l * NP : 0;
-    const bool past_right = EDGE && X0 + 64 * NP > W;
-
-    // one pass for one row: N, C, S are rows r-1, r, r+1 of the previous pass; `out` receives (dx, dy, kappa) of row r
-    auto pass_row = [&](const SRow<NP> &N, const SRow<NP> &C, const SRow<NP> &S, const int r, float (&out)[3][NP]) {
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            // smoothKernel, MatchLib.cu:1108-1139: centre, west, east, north, south; the weight is the pre-pass confidence
-            float sumCorr = 0.0f;
-            sumCorr = sumCorr + C.k[j];
-            sumCorr = sumCorr + nbr<NP, -1>(C.k, j);
-            sumCorr = sumCorr + nbr<NP, +1>(C.k, j);
-            sumCorr = sumCorr + N.k[j];
-            sumCorr = sumCorr + S.k[j];
-            float acc[3];
-#pragma unroll
-            for (int f = 0; f < 3; f++) {
-                float a = 0.0f;
-                a = C.p[f][j] + a;
-                a = nbr<NP, -1>(C.p[f], j) + a;
-                a = nbr<NP, +1>(C.p[f], j) + a;
-                a = N.p[f][j] + a;
-                a = S.p[f][j] + a;
-                acc[f] = a;
-            }
-            if (__builtin_expect(div3_shared_ok(sumCorr), 1)) {
-                div3_shared(acc[0], acc[1], acc[2], sumCorr, out[0][j], out[1][j], out[2][j]);
-            } else {
-#pragma unroll
-                for (int f = 0; f < 3; f++) out[f][j] = acc[f] / sumCorr;
-            }
-        }
-        (void)r;
-    };
-    // border rules of a pass's output row r (EDGE strips only); `in_r` = the INPUT row r (clamped), `prev` = this pass's row r-1
-    auto fix_edges = [&](const int r, const float (&in_r)[3][NP], const float (&prev)[3][NP], float (&out)[3][NP]) {
-        if (r >= H) {  // below the image: the last row's copy
-#pragma unroll
-            for (int f = 0; f < 3; f++)
-#pragma unroll
-                for (int j = 0; j < NP; j++) out[f][j] = prev[f][j];
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            const bool keep = r <= 0 || px[j] <= 0;  // row 0 / column 0 are never touched (MatchLib.cu:1106), so they still hold the input
-#pragma unroll
-            for (int f = 0; f < 3; f++) out[f][j] = keep ? in_r[f][j] : out[f][j];
-        }
-        if (past_right) {
-#pragma unroll
-            for (int f = 0; f < 3; f++) {
-                const float sel = (NP == 2 && last_j == 1) ? out[f][NP - 1] : out[f][0];
-                const float edge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sel), last_l));
-#pragma unroll
-                for (int j = 0; j < NP; j++) out[f][j] = px[j] >= W ? edge : out[f][j];
-            }
-        }
-    };
-    auto make_row = [&](const float (&v)[3][NP], SRow<NP> &R) {
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-            R.k[j] = v[2][j];
-#pragma unroll
-            for (int f = 0; f < 3; f++) R.p[f][j] = v[f][j] * v[2][j];  // v*w of MatchLib.cu:1111-1131, rounded to binary32 as there
-        }
-    };
-
-    // ---- state -----------------------------------------------------------------------------------------------------
-    // The passes are SKEWED by two rows: at the step that brings input row t, pass s (1..PASSES) produces its row t - (2s-1) from
-    // rows its predecessor finished in EARLIER steps, so the PASSES stencil + division chains of a step are independent of one
-    // another (a wave then has work to issue while each chain waits out its latencies; with the passes chained inside a step a
-    // wave stalled on every division).  ring[s] holds the three newest rows of pass s (s = 0: the input) in slots that turn
-    // with the step's phase PH = (t - t0) % 3; the row loop is unrolled by three, so no register is ever copied.
-    SRow<NP> ring[PASSES > 0 ? PASSES : 1][3];
-    float in[3][3][NP];          // raw (dx, dy, kappa) of the input rows in flight: row t in slot (t - t0) % 3
-    float outP[3][3][NP];        // the last pass's rows (dx, dy, kappa): the row of step t in slot (t - t0) % 3
-    float prevP[PASSES > 0 ? PASSES : 1][3][NP];  // EDGE: every pass's previous row (rows below the image copy it)
-    float bacc[3][NP][4];        // open partial sums of the box's column pass
-#pragma unroll
-    for (int u = 0; u < 3; u++)
-#pragma unroll
-        for (int j = 0; j < NP; j++) {
-#pragma unroll
-            for (int s = 0; s < (PASSES > 0 ? PASSES : 1); s++) {
-                ring[s][u].k[j] = 0.0f;
-                prevP[s][u][j] = 0.0f;
-#pragma unroll
-                for (int f = 0; f < 3; f++) ring[s][u].p[f][j] = 0.0f;
-            }
-#pragma unroll
-            for (int f = 0; f < 3; f++) outP[u][f][j] = in[u][f][j] = 0.0f;
-        }
-#pragma unroll
-    for (int f = 0; f < 3; f++)
-#pragma unroll
-        for (int j = 0; j < NP; j++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) bacc[f][j][u] = 0.0f;
-
-    constexpr int DELAY = (PASSES > 0 ? 2 * PASSES : 1) + (BOX ? 2 : 0);  // output row = t - DELAY
-    const int t0 = ys - HALO;
-    const int t_end = ye - 1 + DELAY;
-    load_row(t0, in[0]);
-
-    auto step = [&](auto ph_tag, const int t) {
-        constexpr int PH = decltype(ph_tag)::value;
-        load_row(t + 1, in[(PH + 1) % 3]);  // a whole step ahead of its use
-        // the previous step's row of the last pass: through the box (rows, then the transposed column pass) or straight out
-        {
-            const float(&last)[3][NP] = outP[(PH + 2) % 3];
-            float res[3][NP];
-            if constexpr (BOX) {
-                // rows (Ta): sum = 0; sum += v[x-2]*0; += v[x-1]*a; += v[x]*a; += v[x+1]*a; += v[x+2]*0 (box5f); the same down the
-                // columns in transposed form: the rows arrive in the order the taps are added
-#pragma unroll
-                for (int f = 0; f < 3; f++)
-#pragma unroll
-                    for (int j = 0; j < NP; j++) {
-                        const float h = box5f(nbr2<NP, -2>(last[f], j), nbr2<NP, -1>(last[f], j), last[f][j], nbr2<NP, +1>(last[f], j), nbr2<NP, +2>(last[f], j));
-                        float(&b)[4] = bacc[f][j];
-                        const float hb = h * UGSM_BOX;
-                        res[f][j] = __builtin_fmaf(h, 0.0f, b[3]);
-                        b[3] = b[2] + hb;
-                        b[2] = b[1] + hb;
-                        b[1] = b[0] + hb;
-                        b[0] = __builtin_fmaf(h, 0.0f, 0.0f);
-                    }
-            } else {
-#pragma unroll
-                for (int f = 0; f < 3; f++)
-#pragma unroll
-                    for (int j = 0; j < NP; j++) res[f][j] = last[f][j];
-            }
-            const int o = t - DELAY;
-            if (o >= ys && o < ye) {
-                const unsigned ro = (unsigned)o * pitchW;
-                if constexpr (NP == 2) {
-                    if (stv[0] && stv[1]) {
-#pragma unroll
-                        for (int f = 0; f < 3; f++) *(gf2u *)((gchar *)Ob[f] + (ro + coff[0])) = f2u{res[f][0], res[f][1]};
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NP; j++)
-                            if (stv[j]) {
-#pragma unroll
-                                for (int f = 0; f < 3; f++) st_at(Ob[f], ro + coff[j], res[f][j]);
-                            }
-                    }
-                } else {
-                    if (stv[0]) {
-#pragma unroll
-                        for (int f = 0; f < 3; f++) st_at(Ob[f], ro + coff[0], res[f][0]);
-                    }
-                }
-            }
-        }
-        if constexpr (PASSES == 0) {
-#pragma unroll
-            for (int f = 0; f < 3; f++)
-#pragma unroll
-                for (int j = 0; j < NP; j++) outP[PH][f][j] = in[PH][f][j];
-        } else {
-            make_row(in[PH], ring[0][PH]);
-            // passes in DESCENDING order: pass s reads its predecessor's three rows before the predecessor (next in program
-            // order) overwrites the oldest of them with this step's row
-#pragma unroll
-            for (int s = PASSES; s >= 1; s--) {
-                const int r = t - (2 * s - 1);
-                // newest row of pass s-1 as of the previous step: slot PH for the input, (PH - 2(s-1)) mod 3 for a pass
-                constexpr int Z = 0;
-                const int sl_s = (s == 1) ? PH : ((PH - 2 * (s - 1)) % 3 + 3) % 3;
-                const int sl_c = (sl_s + 2) % 3, sl_n = (sl_s + 1) % 3;
-                (void)Z;
-                float cur[3][NP];
-                pass_row(ring[s - 1][sl_n], ring[s - 1][sl_c], ring[s - 1][sl_s], r, cur);
-                if constexpr (EDGE) {
-                    float in_r[3][NP];
-                    if (r <= 0 || X0 <= 0) load_row(r, in_r);  // (only the pass-through pixels use it)
-                    fix_edges(r, in_r, prevP[s - 1], cur);
-#pragma unroll
-                    for (int f = 0; f < 3; f++)
-#pragma unroll
-                        for (int j = 0; j < NP; j++) prevP[s - 1][f][j] = cur[f][j];
-                }
-                if (s < PASSES) {
-                    make_row(cur, ring[s][((PH - (2 * s - 1)) % 3 + 3) % 3]);  // = the slot of pass s's oldest row
-                } else {
-#pragma unroll
-                    for (int f = 0; f < 3; f++)
-#pragma unroll
-                        for (int j = 0; j < NP; j++) outP[PH][f][j] = cur[f][j];
-                }
-            }
-        }
-    };
-    for (int t = t0; t <= t_end; t += 3) {
-        step(std::integral_constant<int, 0>{}, t);
-        step(std::integral_constant<int, 1>{}, t + 1);
-        step(std::integral_constant<int, 2>{}, t + 2);
-    }
-}
-
-#ifndef SMOOTH_MARCH_WAVES
-#define SMOOTH_MARCH_WAVES(NP) ((NP) == 2 ? 2 : 4)
-#endif
-template <int NP, int PASSES, bool BOX>
-__global__ __launch_bounds__(64 * MARCH_WPB, SMOOTH_MARCH_WAVES(NP)) void k_smooth_march(const float *__restrict__ s3, float *__restrict__ o3, int W, int H,
-                                                                              int strips_x, int n_strips, int Hs)
-{
-    using G = SmoothMarch<NP, PASSES, BOX>;
-    int sx, sy;
-    if (!march_strip(n_strips, strips_x, sx, sy)) return;
-    const int xs = sx * G::VX, ys = sy * Hs;
-    const int xe = min(xs + G::VX, W), ye = min(ys + Hs, H);
-    int X0 = xs - G::HALO;
-    if (NP == 2) X0 -= X0 & 1;  // (two's complement: also rounds a negative X0 down to even)
-    const bool interior = X0 >= 1 && X0 + G::COLS <= W && ys - G::HALO >= 1 && ye + G::HALO <= H;
-    if (interior) smooth_march_body<NP, PASSES, BOX, false>(s3, o3, W, H, X0, xs, xe, ys, ye);
-    else smooth_march_body<NP, PASSES, BOX, true>(s3, o3, W, H, X0, xs, xe, ys, ye);
-}
-
-template <int NP, int PASSES, bool BOX>
-static void launch_smooth_march_t(hipStream_t st, const float *s3, float *o3, int W, int H, int rows)
-{
-    using G = SmoothMarch<NP, PASSES, BOX>;
-    const int strips_x = (W + G::VX - 1) / G::VX;
-    const int slots = 256 * 4 * SMOOTH_MARCH_WAVES(NP);
-    int Hs = rows;
-    if (Hs <= 0) {
-        const int sy = (slots / strips_x) > 0 ? (slots / strips_x) : 1;
-        Hs = (H + sy - 1) / sy;
-        if (Hs < 24) Hs = 24;
-    }
-    const int strips_y = (H + Hs - 1) / Hs;
-    const int n_strips = strips_x * strips_y;
-    UGSM_LAUNCH((k_smooth_march<NP, PASSES, BOX>), dim3((n_strips + MARCH_WPB - 1) / MARCH_WPB), dim3(64 * MARCH_WPB), 0, st, s3, o3, W, H,
-                       strips_x, n_strips, Hs);
-}
-
-// five passes (+ box) per launch; other pass counts belong to the LDS-tiled kernel (launch_smooth_fused)
-void launch_smooth_march(hipStream_t st, const float *s3, float *o3, int W, int H, int do_box, int np, int rows)
-{
-#ifdef UGSM_DEV_KERNELS
-    if (np == 2) {
-        if (do_box) launch_smooth_march_t<2, 5, true>(st, s3, o3, W, H, rows);
-        else launch_smooth_march_t<2, 5, false>(st, s3, o3, W, H, rows);
-        return;
-    }
-#endif
-    (void)np;
-    {
-        if (do_box) launch_smooth_march_t<1, 5, true>(st, s3, o3, W, H, rows);
-        else launch_smooth_march_t<1, 5, false>(st, s3, o3, W, H, rows);
-    }
-}
-
-#endif  // UGSM_DEV_LIB
-
-// range_bad[0] = 1 if any of the `count` floats at p is outside range_ok (ugsm_exact.hpp); the caller zeroes the word first.
-// The pyramid kernels make this check as they write a level; this pass serves the stage-level test entry points, which
-// receive their planes ready-made.
-__global__ __launch_bounds__(256) void k_range_scan(const float *__restrict__ p, size_t count, unsigned *__restrict__ range_bad)
-{
-    bool bad = false;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) bad |= !range_ok(p[i]);
-    if (bad) *range_bad = 1u;
-}
-void launch_range_scan(hipStream_t st, const float *p, size_t count, unsigned *range_bad)
-{
-    const size_t blocks = (count + 255) / 256;
-    UGSM_LAUNCH(k_range_scan, dim3((unsigned)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, st, p, count, range_bad);
-}
-
-// =========================================================================================
-// the convergence measure of the reference's (never called) early exit -- weightedDifference,
-// MatchGPULib.cpp:1336-1437 with kernels 17 / 18 (MatchLib.cu:1174-1373): sum(|D - OldD| * conf) / sum(conf) for dx and dy.
-// The reference's reduction has no defined order (and is called with the block count as the block size); this build's
-// definition (the CPU restatement used by the tests mirrors it) is a fixed order of binary64 sums that maps onto one wave per
-// row: lane l adds its columns x = l (mod 64) left to right, lane 0 adds the 64 lane sums in lane order; a second, single-wave
-// kernel adds the rows the same way.  Deterministic, and bit-identical to the CPU restatement.
-// =========================================================================================
-__global__ __launch_bounds__(64) void k_wdiff_rows(const float *__restrict__ newd3, const float *__restrict__ oldd3, int W, int H,
-                                                  double *__restrict__ rowsum)
-{
-    __shared__ double sp[3][64];
-    const int y = blockIdx.x, l = threadIdx.x;
-    const size_t n = (size_t)W * H;
-    double ph = 0.0, pv = 0.0, pc = 0.0;
-    for (int x = l; x < W; x += 64) {
-        const size_t at = (size_t)y * W + x;
-        const float c = newd3[2 * n + at];
-        float th = fabsf(newd3[at] - oldd3[at]);        // kernel 17, MatchLib.cu:1194-1199: abs(a - b) ...
-        float tv = fabsf(newd3[n + at] - oldd3[n + at]);
-        th = th * c;                                    // ... times conf, in float
-        tv = tv * c;
-        ph += (double)th;
-        pv += (double)tv;
-        pc += (double)c;
-    }
-    sp[0][l] = ph;
-    sp[1][l] = pv;
-    sp[2][l] = pc;
-    __syncthreads();
-    if (l < 3) {
-        double r = 0.0;
-        for (int i = 0; i < 64; i++) r += sp[l][i];
-        rowsum[(size_t)y * 3 + l] = r;
-    }
-}
-__global__ __launch_bounds__(64) void k_wdiff_total(const double *__restrict__ rowsum, int H, double *__restrict__ out3)
-{
-    __shared__ double sp[3][64];
-    const int l = threadIdx.x;
-    double p[3] = {0.0, 0.0, 0.0};
-    for (int y = l; y < H; y += 64)
-        for (int k = 0; k < 3; k++) p[k] += rowsum[(size_t)y * 3 + k];
-    for (int k = 0; k < 3; k++) sp[k][l] = p[k];
-    __syncthreads();
-    if (l < 3) {
-        double r = 0.0;
-        for (int i = 0; i < 64; i++) r += sp[l][i];
-        out3[l] = r;
-    }
-}
-// out3 (device): S_dx, S_dy, C; rowsum: 3 * H doubles of scratch
-void launch_weighted_difference(hipStream_t st, const float *newd3, const float *oldd3, int W, int H, double *rowsum, double *out3)
-{
-    UGSM_LAUNCH(k_wdiff_rows, dim3(H), dim3(64), 0, st, newd3, oldd3, W, H, rowsum);
-    UGSM_LAUNCH(k_wdiff_total, dim3(1), dim3(64), 0, st, rowsum, H, out3);
-}
-
-#ifdef UGSM_DEV_LIB
-// test hook: the range-guarded division on arbitrary operands
-__global__ void k_div_probe(const float *__restrict__ n, const float *__restrict__ d, float *__restrict__ q, int count)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < count) q[i] = div_inrange(n[i], d[i]);
-}
-void launch_div_probe(hipStream_t st, const float *n, const float *d, float *q, int count)
-{
-    UGSM_LAUNCH(k_div_probe, dim3((count + 255) / 256), dim3(256), 0, st, n, d, q, count);
-}
-#endif  // UGSM_DEV_LIB
 
 }  // namespace ugsm

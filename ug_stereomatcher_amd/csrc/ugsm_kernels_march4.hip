@@ -47,11 +47,8 @@ __device__ __forceinline__ float rowconv5(const float p)
     const float p4 = shr1(p3) + a1;
     return shr1(p4) + a0;
 }
-// MARCH4_ILV: the six row passes of a channel wave in lockstep (as MARCH_ILV in ugsm_kernels_march.hip): a channel wave is alone on its
-// SIMD in the latency mode this kernel serves, so every s_nop of the VALU-write -> DPP-read hazard is an idle issue slot
-#ifndef MARCH4_ILV
-#define MARCH4_ILV 1
-#endif
+// the six row passes of a channel wave in lockstep (as rowconv5_lockstep in ugsm_kernels_march.hip): a channel wave is alone on its SIMD
+// on the levels this kernel serves, so every s_nop of the VALU-write -> DPP-read hazard would be an idle issue slot
 template <int N>
 __device__ __forceinline__ void rowconv5_lockstep(const float (&v)[N], float (&out)[N])
 {
@@ -192,7 +189,7 @@ __device__ __forceinline__ void channel_wave(const int k, const Img3 &L, const I
         const float rc = cur.R;
         const float sq = rc * rc;                  // Square, MatchLib.cu:569-570
         float bnew;                                // = B(r-2): convolutionRowsKernelT / ColumnsKernelT on R'^2 (clamp)
-        if (!(MARCH4_ILV && do_prod)) bnew = colstep5(aB, rowconv5(sq));
+        if (!do_prod) bnew = colstep5(aB, rowconv5(sq));  // (the strip's first rows: only B is due)
         if (do_prod) {
             const float l = (c.cin && yin) ? cur.L : 0.0f;
             float p[5];                            // CompareMove, MatchLib.cu:622-624
@@ -202,16 +199,14 @@ __device__ __forceinline__ void channel_wave(const int k, const Img3 &L, const I
             p[3] = l * rc;                         // shift (0, +1)
             p[4] = l * Rm1;                        // shift (0, 0)
             float Nv[5];
-            if (MARCH4_ILV) {                      // the six row passes in lockstep: no s_nop between a stage and the DPP read of it
+            {   // the six row passes in lockstep (no s_nop between a stage and the DPP read of it): B, and N_s(r-3) --
+                // convolutionRowsKernel / ColumnsKernel on the products (zero padded)
                 const float v6[6] = {sq, p[0], p[1], p[2], p[3], p[4]};
                 float h6[6];
                 rowconv5_lockstep<6>(v6, h6);
                 bnew = colstep5(aB, h6[0]);
 #pragma unroll
                 for (int s = 0; s < 5; s++) Nv[s] = colstep5(aN[s], h6[s + 1]);
-            } else {
-#pragma unroll
-                for (int s = 0; s < 5; s++) Nv[s] = colstep5(aN[s], rowconv5(p[s]));  // convolutionRowsKernel / ColumnsKernel (zero padded): N_s(r-3)
             }
             if (do_out) {
                 const float a = cur.A, bc = Bm1;
@@ -310,10 +305,8 @@ __device__ __forceinline__ void epilogue_wave(const float *__restrict__ d3, floa
 }  // namespace m4
 
 // grid: one workgroup of four waves per strip of m4::VX columns x Hs rows; strips dealt to the XCDs as contiguous bands
-// WAVES: the occupancy the register allocation is made for -- 4 waves per SIMD in the product (70 VGPRs); 8 (<= 64 VGPRs, a few spilled) is the
-// development form that fits beside two resident K-smooth workgroups on a CU (tools/kbench mode 18)
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_cost_march4(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3, float *__restrict__ nd3,
+// (the register allocation is made for 4 waves per SIMD: 72 VGPRs)
+__global__ __launch_bounds__(256, 4) void k_cost_march4(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ d3, float *__restrict__ nd3,
                                                        int W, int H, float thr, int blend, int strips_x, int n_strips, int Hs,
                                                        const unsigned *__restrict__ range_bad, SeedMap sm, Batch bt)
 {
@@ -339,9 +332,6 @@ __global__ __launch_bounds__(256, WAVES) void k_cost_march4(Img3 L, Img3 R, cons
     const bool fast = range_bad != nullptr && __builtin_amdgcn_readfirstlane((int)*range_bad) == 0;
     const bool seeded = sm.Ws > 0;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#if defined(MARCH4_PRIO) && MARCH4_PRIO  // development switch (tools/kbench): the epilogue wave ahead of the channel waves it shares a SIMD with
-    if (role == 3) __builtin_amdgcn_s_setprio(3);
-#endif
     // (every branch below is workgroup-uniform except the role, and both roles run the same number of row steps = barriers)
 #define UGSM_M4_DISPATCH(EDGE, SEED)                                                                                                  \
     do {                                                                                                                              \
@@ -359,9 +349,6 @@ __global__ __launch_bounds__(256, WAVES) void k_cost_march4(Img3 L, Img3 R, cons
 #undef UGSM_M4_DISPATCH
 }
 
-#ifdef UGSM_DEV_KERNELS
-int march4_small_registers = 0;  // (tools/kbench)
-#endif
 // Strip height: every strip resident at once (four workgroups of four waves per CU: one wave of every workgroup per SIMD), the
 // shortest strips that still fit -- a launch lasts (rows + halo + prologue) row steps.
 int march4_strip_rows(int W, int H, int pairs)
@@ -383,13 +370,7 @@ void launch_cost_march4(hipStream_t st, Img3 L, Img3 R, const float *A3, const f
     const int Hs = rows > 0 ? rows : march4_strip_rows(W, H, pairs);
     const int strips_y = (H + Hs - 1) / Hs;
     const int n_strips = strips_x * strips_y;
-#ifdef UGSM_DEV_KERNELS
-    if (march4_small_registers) {
-        UGSM_LAUNCH(k_cost_march4<8>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
-        return;
-    }
-#endif
-    UGSM_LAUNCH(k_cost_march4<4>, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
+    UGSM_LAUNCH(k_cost_march4, dim3(n_strips, pairs), dim3(256), 0, st, L, R, A3, d3, nd3, W, H, thr, blend, strips_x, n_strips, Hs, range_bad, sm, B);
 }
 
 }  // namespace ugsm

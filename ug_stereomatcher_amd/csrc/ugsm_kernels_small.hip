@@ -1,7 +1,7 @@
 // ugsm_kernels_small.hip -- latency forms of K-cost and K-smooth for the coarse pyramid levels.
 //
 // Below ~0.2 Mpx a level has fewer tiles than the chip has CUs and one matcher iteration is two DEPENDENT launches whose
-// duration is the critical path of a single tile (tools/level_breakdown.py: k_cost_split 14 us, k_smooth_fused 11 us per launch
+// duration is the critical path of a single tile (round 2, tools/level_breakdown.py: the LDS-tiled k_cost_split 14 us, k_smooth_fused 11 us per launch
 // from 54 x 36 up to 436 x 289, 22 iterations per level, 7 such levels = 4 of the 11 ms a pair took when it was alone on the GPU).
 // These kernels do the same arithmetic -- same helpers, same operation order, bit for bit (tests/test_gpu_small.py) -- with the
 // tile's chain cut short instead of its instruction count:
@@ -9,7 +9,7 @@
 //                  three barrier-separated rounds; tile 16 x 12; the global loads go straight to LDS.
 //   k_smooth_small one thread per pixel of tile + halo 7, double-buffered fields (one barrier per Jacobi pass instead of two),
 //                  tile 18 x 4, 18 x 10 or 18 x 18.
-// Citations: /root/reference/src/gpu_matcher/<file>:<line>, as in ugsm_kernels_fused.hip.
+// Citations: /root/reference/src/gpu_matcher/<file>:<line>.
 #include "ugsm_exact.hpp"
 #include "ugsm_launch.hpp"
 
@@ -18,7 +18,7 @@ namespace ugsm {
 // =========================================================================================
 // k_cost_small
 // =========================================================================================
-// Geometry of one channel group = the k_cost_split tile (ugsm_kernels_fused.hip) at TXS x TYS: two roles of RT threads, a thread
+// Geometry of one channel group = the k_cost_split tile (dev/ugsm_dev_cost_tiled.hip) at TXS x TYS: two roles of RT threads, a thread
 // owns a quad (4 consecutive x) of one row-pass row, lanes walk down the rows (conflict-free ds_read_b128: every row stride is
 // an odd number of quads for TXS a multiple of 8).
 template <int TXS, int TYS>
@@ -44,14 +44,11 @@ struct CostSmall {
     static_assert(NT <= 1024, "workgroup size");
 };
 
-// DLDS (k_iter_small): the field (dx, dy, conf) the iteration starts from is not in global memory but in LDS -- `dl`, three planes of the
-// tile + halo 3 region, (TXS + 6) columns wide, cell (0, 0) = pixel (x0 - 3, y0 - 3).
-template <int TXS, int TYS, bool INTERIOR, bool DLDS = false>
+template <int TXS, int TYS, bool INTERIOR>
 __device__ __forceinline__ void cost_small_body(const Img3 &L, const Img3 &R, const float *__restrict__ A3, const float *__restrict__ d3,
                                                 float *__restrict__ nd3, const int W, const int H, const float thr, const int blend, const int x0,
-                                                const int y0, float *__restrict__ smem, const float *__restrict__ dl = nullptr)
+                                                const int y0, float *__restrict__ smem)
 {
-    constexpr int DLW = TXS + 6, DLN = (TXS + 6) * (TYS + 6);
     using G = CostSmall<TXS, TYS>;
     const int tid = threadIdx.x;
     const int k = tid / G::CT, ct = tid - k * G::CT;  // channel group (wave-uniform), thread within it
@@ -83,15 +80,9 @@ __device__ __forceinline__ void cost_small_body(const Img3 &L, const Img3 &R, co
         const int r = it / G::IDX_W, c = it - r * G::IDX_W;
         gxh[u] = INTERIOR ? x0 + c - 3 : clampi(x0 + c - 3, 0, W - 1);
         gyh[u] = INTERIOR ? y0 + r - 3 : clampi(y0 + r - 3, 0, H - 1);
-        if constexpr (DLDS) {
-            const int at = (gyh[u] - (y0 - 3)) * DLW + (gxh[u] - (x0 - 3));
-            ddx[u] = dl[at];
-            ddy[u] = dl[DLN + at];
-        } else {
-            const unsigned off = ((unsigned)gyh[u] * (unsigned)W + (unsigned)gxh[u]) * 4u;
-            ddx[u] = ld_at(Db[0], off);
-            ddy[u] = ld_at(Db[1], off);
-        }
+        const unsigned off = ((unsigned)gyh[u] * (unsigned)W + (unsigned)gxh[u]) * 4u;
+        ddx[u] = ld_at(Db[0], off);
+        ddy[u] = ld_at(Db[1], off);
     }
 #pragma unroll
     for (int u = 0; u < NL; u++) {
@@ -121,7 +112,7 @@ __device__ __forceinline__ void cost_small_body(const Img3 &L, const Img3 &R, co
         const unsigned off = in ? ((unsigned)(y0 + r) * (unsigned)W + (unsigned)(x0 + c)) * 4u : 0u;
 #pragma unroll
         for (int f = 0; f < 3; f++) {
-            const float v = DLDS ? dl[f * DLN + (in ? (r + 3) * DLW + c + 3 : 0)] : ld_at(Db[f], off);
+            const float v = ld_at(Db[f], off);
             od[f][u] = in ? v : 0.0f;
         }
     }
@@ -371,199 +362,9 @@ void launch_cost_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const fl
     launch_cost_small_t<16, 12>(st, L, R, A3, d3, nd3, W, H, thr, blend, bt);
 }
 
-#ifdef UGSM_DEV_LIB  // k_iter_small: built, bit-exact, measured equal per launch and slower in the pipeline -- in libugsm_dev.so only
-// =========================================================================================
-// k_iter_small: the smoothing of iteration m AND the cost step of iteration m+1 in one launch (coarse levels, a call that has the chip to
-// itself).  An iteration of a coarse level is two dependent launches that each last as long as one short tile chain + the launch itself
-// (k_cost_small 6.1 us + k_smooth_small 4.5 us back to back).  Fusing them in the order cost -> smooth would make one
-// workgroup recompute the cost on the smoothing's halo-7 ring, 4 x the tile of the expensive stage.  In the order SMOOTH -> COST nothing
-// expensive is redone: the cost step of a 16 x 12 tile reads the smoothed field on tile + halo 3 (22 x 18), which the workgroup first
-// produces from the previous cost step's output on tile + halo 10 (36 x 32: five Jacobi passes + the box, the cheap stage, 6 x redundant
-// on an idle chip), keeps in LDS, and then runs cost_small_body on.  A level of mi iterations is then  cost, (mi - 1) x [smooth + cost],
-// smooth:  mi + 1 launches instead of 2 mi.  Same arithmetic as k_smooth_small + k_cost_small, bit for bit (tools/kbench mode 16,
-// tests/test_gpu_small.py).
-template <int TXS, int TYS>
-struct IterSmall {
-    using G = CostSmall<TXS, TYS>;
-    static constexpr int DH = 3, SH = 7;                               // the cost step's reach, the smoothing's (5 passes + box)
-    static constexpr int DW = TXS + 2 * DH, DHT = TYS + 2 * DH, DN = DW * DHT;  // the smoothed field the cost step reads: 22 x 18
-    static constexpr int RW = DW + 2 * SH, RH = DHT + 2 * SH, RN = RW * RH;     // what the smoothing reads: 36 x 32
-    // 1 024 threads smooth (pass p works on the region shrunk by p cells, (RW - 2p) x (RH - 2p) <= 1 020 cells: one cell per thread),
-    // the first G::NT = 768 of them run the cost step; the other four waves end before it (s_barrier waits for surviving waves only)
-    static constexpr int NT = 1024, NLD = (RN + NT - 1) / NT;
-    static constexpr int O_D = 3 * G::CH_FLOATS;                       // LDS: [cost step's images | D]; the smoothing's two buffers lie over the images
-    static constexpr int LDS_FLOATS = O_D + 3 * DN;
-    static_assert(2 * 3 * RN <= O_D, "the smoothing buffers fit under the cost step's images");
-    static_assert((RW - 2) * (RH - 2) <= NT && G::NT <= NT && (DHT + 4) * DW <= NT, "one cell per thread in every pass and in the box");
-};
-
-// One Jacobi pass of k_iter_small's smoothing: buffer `cur` -> buffer `cur ^ 1` of the dynamic LDS array ([2][3][RN] floats at its start).
-// PP = 1 .. 5; FIVE: P = 5 (every production launch): the region's shrink is PP, a constant divisor.
-template <class I, int PP, bool FIVE>
-__device__ __forceinline__ void iter_small_pass(const int cur, const int h, const int xr, const int yr, const int W, const int H)
-{
-    extern __shared__ __attribute__((aligned(16))) float smem_is[];
-    const int tid = threadIdx.x;
-    const int sh = FIVE ? PP : I::SH - (h - PP);
-    const int rw = I::RW - 2 * sh, rh = I::RH - 2 * sh;
-    const int ib = cur * 3 * I::RN, ob = (cur ^ 1) * 3 * I::RN;
-    if (tid < rw * rh) {
-        const int rr = tid / rw, r = rr + sh, c = tid - rr * rw + sh;
-        const int q = r * I::RW + c;
-        const int gx = xr + c, gy = yr + r;
-        const bool act = gy > 0 && gy < H && gx > 0 && gx < W;
-        const bool east_in = gx + 1 <= W - 1, south_in = gy + 1 <= H - 1;
-        float v[3], vw[3], ve[3], vn[3], vs[3];
-#pragma unroll
-        for (int f = 0; f < 3; f++) {
-            const int at = ib + f * I::RN + q;
-            v[f] = smem_is[at];
-            vw[f] = smem_is[at - 1];
-            const float e_raw = smem_is[at + 1], s_raw = smem_is[at + I::RW];
-            ve[f] = east_in ? e_raw : v[f];
-            vn[f] = smem_is[at - I::RW];
-            vs[f] = south_in ? s_raw : v[f];
-        }
-        const float wc = v[2], ww = vw[2], we = ve[2], wn = vn[2], ws = vs[2];
-        float sumCorr = 0.0f;
-        sumCorr = sumCorr + wc;
-        sumCorr = sumCorr + ww;
-        sumCorr = sumCorr + we;
-        sumCorr = sumCorr + wn;
-        sumCorr = sumCorr + ws;
-        float acc[3], qf[3];
-#pragma unroll
-        for (int f = 0; f < 3; f++) {
-            float a = 0.0f;
-            a = v[f] * wc + a;
-            a = vw[f] * ww + a;
-            a = ve[f] * we + a;
-            a = vn[f] * wn + a;
-            a = vs[f] * ws + a;
-            acc[f] = a;
-        }
-        div3_shared(acc[0], acc[1], acc[2], sumCorr, qf[0], qf[1], qf[2]);
-        const bool lit = !div3_shared_ok(sumCorr);
-        if (__builtin_amdgcn_ballot_w64(lit) != 0) {  // rare: a denominator outside the shared reciprocal's range
-            asm volatile("; literal division of smoothKernel" ::: "memory");
-            if (lit) {
-#pragma unroll
-                for (int f = 0; f < 3; f++) qf[f] = acc[f] / sumCorr;
-            }
-        }
-#pragma unroll
-        for (int f = 0; f < 3; f++) smem_is[ob + f * I::RN + q] = act ? qf[f] : v[f];
-    }
-    __syncthreads();
-}
-
-template <int TXS, int TYS>
-__global__ __launch_bounds__((IterSmall<TXS, TYS>::NT)) void k_iter_small(Img3 L, Img3 R, const float *__restrict__ A3, const float *__restrict__ c3,
-                                                                          float *__restrict__ nd3, int W, int H, float thr, int blend, int P, int tiles_x,
-                                                                          int n_tiles)
-{
-    using I = IterSmall<TXS, TYS>;
-    extern __shared__ __attribute__((aligned(16))) float smem_is[];
-    const int tid = threadIdx.x;
-    int tile_x, tile_y;
-    xcd_tile(n_tiles, tiles_x, tile_x, tile_y);
-    const int x0 = tile_x * TXS, y0 = tile_y * TYS;    // the cost step's tile
-    const int xr = x0 - I::DH - I::SH, yr = y0 - I::DH - I::SH;  // global coordinates of smoothing-region cell (0, 0)
-    const size_t n = (size_t)W * H;
-    float *const buf = smem_is;                        // [2][3][RN]
-    float *const dl = smem_is + I::O_D;                // [3][DN]
-    const int h = P + 2;                               // halo actually needed (the box always runs)
-    gchar_c *const Sb[3] = {uniform_base(c3), uniform_base(c3 + n), uniform_base(c3 + 2 * n)};
-
-    // ---- smoothing: smoothKernel x P (MatchLib.cu:1092-1145) + the 3x3 box (:1593-1697), per-pixel border selects as in k_smooth_small ----
-#pragma unroll
-    for (int u = 0; u < I::NLD; u++) {
-        const int q = tid + u * I::NT;
-        if (q < I::RN) {
-            const int r = q / I::RW, c = q - r * I::RW;
-            const int gx = xr + c, gy = yr + r;
-            const int inset = min(min(c, I::RW - 1 - c), min(r, I::RH - 1 - r));
-            const unsigned off = ((unsigned)clampi(gy, 0, H - 1) * (unsigned)W + (unsigned)clampi(gx, 0, W - 1)) * 4u;
-            const bool need = inset >= I::SH - h;
-#pragma unroll
-            for (int f = 0; f < 3; f++) buf[f * I::RN + q] = need ? ld_at(Sb[f], off) : 0.0f;
-        }
-    }
-    __syncthreads();
-    int cur = 0;
-    // pass p is needed (and valid) on the region shrunk to halo h - p, i.e. by SH - (h - p) cells on every side.  (The passes index the
-    // dynamic LDS array directly: through pointers captured by a lambda the compiler loses the address space and emits flat loads.)
-    if (P == 5) {
-        iter_small_pass<I, 1, true>(cur, h, xr, yr, W, H); cur ^= 1;
-        iter_small_pass<I, 2, true>(cur, h, xr, yr, W, H); cur ^= 1;
-        iter_small_pass<I, 3, true>(cur, h, xr, yr, W, H); cur ^= 1;
-        iter_small_pass<I, 4, true>(cur, h, xr, yr, W, H); cur ^= 1;
-        iter_small_pass<I, 5, true>(cur, h, xr, yr, W, H); cur ^= 1;
-    } else {
-        if (P >= 1) { iter_small_pass<I, 1, false>(cur, h, xr, yr, W, H); cur ^= 1; }
-        if (P >= 2) { iter_small_pass<I, 2, false>(cur, h, xr, yr, W, H); cur ^= 1; }
-        if (P >= 3) { iter_small_pass<I, 3, false>(cur, h, xr, yr, W, H); cur ^= 1; }
-        if (P >= 4) { iter_small_pass<I, 4, false>(cur, h, xr, yr, W, H); cur ^= 1; }
-    }
-    {
-        const float *const b = buf + cur * 3 * I::RN;
-        float *const o = buf + (cur ^ 1) * 3 * I::RN;
-        // rows (Ta): the D region's columns, its rows -2 .. +1, in-image cells; taps at clamped coordinates
-        if (tid < (I::DHT + 4) * I::DW) {
-            const int rr = tid / I::DW, r = rr + I::SH - 2, c = tid - rr * I::DW + I::SH;
-            const int gx = xr + c, gy = yr + r;
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
-                int cj[5];
-#pragma unroll
-                for (int j = 0; j < 5; j++) cj[j] = r * I::RW + clampi(gx + j - 2, 0, W - 1) - xr;
-#pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    const float *bf = b + f * I::RN;
-                    o[f * I::RN + r * I::RW + c] = box5f(bf[cj[0]], bf[cj[1]], bf[cj[2]], bf[cj[3]], bf[cj[4]]);
-                }
-            }
-        }
-        __syncthreads();
-        // columns (Ta) into the D region
-        if (tid < I::DN) {
-            const int rr = tid / I::DW, r = rr + I::SH, c = tid - rr * I::DW + I::SH;
-            const int gx = xr + c, gy = yr + r;
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
-                int rj[5];
-#pragma unroll
-                for (int j = 0; j < 5; j++) rj[j] = (clampi(gy + j - 2, 0, H - 1) - yr) * I::RW + c;
-#pragma unroll
-                for (int f = 0; f < 3; f++) {
-                    const float *of = o + f * I::RN;
-                    dl[f * I::DN + tid] = box5f(of[rj[0]], of[rj[1]], of[rj[2]], of[rj[3]], of[rj[4]]);
-                }
-            }
-        }
-    }
-    __syncthreads();  // D is complete, and nobody reads the smoothing buffers any more: the cost step's images may overwrite them
-    if (tid >= I::G::NT) return;  // (four waves end here; the cost step's barriers wait for the surviving twelve)
-
-    // ---- the cost step of the next iteration on the smoothed field in LDS ------------------------------------------------------
-    const bool interior = x0 >= 3 && y0 >= 3 && x0 + TXS + 3 <= W && y0 + TYS + 3 <= H;
-    if (interior) cost_small_body<TXS, TYS, true, true>(L, R, A3, nullptr, nd3, W, H, thr, blend, x0, y0, smem_is, dl);
-    else cost_small_body<TXS, TYS, false, true>(L, R, A3, nullptr, nd3, W, H, thr, blend, x0, y0, smem_is, dl);
-}
-
-void launch_iter_small(hipStream_t st, Img3 L, Img3 R, const float *A3, const float *c3, float *nd3, int W, int H, float thr, int blend, int passes)
-{
-    constexpr int TXS = 16, TYS = 12;
-    using I = IterSmall<TXS, TYS>;
-    const int tiles_x = (W + TXS - 1) / TXS, n_tiles = tiles_x * ((H + TYS - 1) / TYS);
-    constexpr size_t bytes = (size_t)I::LDS_FLOATS * sizeof(float);
-    static_assert(bytes <= 64 * 1024, "stays under the default dynamic LDS limit");
-    UGSM_LAUNCH((k_iter_small<TXS, TYS>), dim3(n_tiles), dim3(I::NT), bytes, st, L, R, A3, c3, nd3, W, H, thr, blend, passes, tiles_x, n_tiles);
-}
-
-#endif  // UGSM_DEV_LIB
-
 // =========================================================================================
 // k_smooth_small: P (<= 5) Jacobi passes of smoothKernel (MatchLib.cu:1092-1145) + the 3x3 box (convolutionRows/ColumnsKernelTa,
-// :1593-1697), same arithmetic as k_smooth_fused (ugsm_kernels_fused.hip), one THREAD PER PIXEL of the tile + halo 7 region.
+// :1593-1697), same arithmetic as k_smooth_fused (ugsm_kernels_smooth.hip), one THREAD PER PIXEL of the tile + halo 7 region.
 // =========================================================================================
 // Region 32 columns x RH rows -> tile 18 x (RH - 14).  A pixel's own fields stay in registers across the passes, west / east come
 // from the neighbouring lanes (a region row is half a wave), north / south from LDS; the fields are double-buffered there, so a

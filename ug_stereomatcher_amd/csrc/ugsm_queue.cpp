@@ -132,29 +132,28 @@ void retire_front(ugsm_ctx *ctx, Queue *q)
     q->flight.pop_front();
 }
 
-// Retires every call at the front of the flight list that has finished (never blocks).
+// Retires every call at the front of the flight list that has finished (never blocks).  A call whose submit FAILED is drained like any
+// other before its pairs are reported: a submit can fail after work has gone onto the slot's stream (out of memory for the staging of a
+// later phase, a launch error mid-call), and a completion tells the host that its input and result buffers -- or the managed staging
+// buffer the library lends next -- are free.  The submit's status is the one reported.
 int reap(ugsm_ctx *ctx, Queue *q)
 {
     while (!q->flight.empty()) {
         Call &c = q->flight.front();
-        if (c.status == UGSM_OK) {
-            const int st = ugsm_poll(ctx, c.slot);
-            if (st == UGSM_PENDING) break;
-            if (st != UGSM_OK) c.status = st;
-        }
+        const int st = ugsm_poll(ctx, c.slot);
+        if (st == UGSM_PENDING) break;
+        if (st != UGSM_OK && c.status == UGSM_OK) c.status = st;
         retire_front(ctx, q);
     }
     return UGSM_OK;
 }
 
-// blocks until the oldest call in flight has finished, and retires it
+// blocks until the oldest call in flight has finished (or, its submit having failed, until what it did enqueue has drained), and retires it
 void wait_front(ugsm_ctx *ctx, Queue *q)
 {
     Call &c = q->flight.front();
-    if (c.status == UGSM_OK) {
-        const int st = ugsm_wait(ctx, c.slot);
-        if (st != UGSM_OK) c.status = st;
-    }
+    const int st = ugsm_wait(ctx, c.slot);
+    if (st != UGSM_OK && c.status == UGSM_OK) c.status = st;
     retire_front(ctx, q);
 }
 
@@ -171,8 +170,10 @@ int free_slot(const Queue *q)
     return -1;
 }
 
-// One library call for the first n waiting pairs on `slot`.
-void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot)
+// One library call for the first n waiting pairs on `slot`.  more: other calls follow this one closely -- pairs wait behind it, or it filled
+// up without a flush (a host that submits faster than the chip matches): the runtime then takes the call to share the chip whatever the
+// other slots are doing at this instant (call_alone, ugsm_runtime.cpp).
+void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot, bool more)
 {
     Call c;
     c.slot = slot;
@@ -199,6 +200,7 @@ void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot)
     }
     CtxHooks &h = ctx_hooks(ctx);
     h.queue_calling = true;
+    h.queue_more = more;
     int st;
     if (f.mem == MEM_DEVICE) {
         if (f.mode == M_FULL)
@@ -215,7 +217,8 @@ void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot)
                         : ugsm_submit_foveated_batch_host(ctx, slot, n, L, R, f.W, f.H, f.stride, ox, oy, o0, o1, o2);
     }
     h.queue_calling = false;
-    c.status = st;  // (a call that failed to enqueue is "complete" at once: its pairs are reported with the status)
+    h.queue_more = false;
+    c.status = st;  // (a call that failed to enqueue: its pairs are reported with this status once the slot has drained, reap / wait_front)
     q->slot_busy[(size_t)slot] = 1;
     q->next_slot = (slot + 1) % (int)q->slot_busy.size();
     q->calls_since_idle++;
@@ -223,11 +226,11 @@ void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot)
 }
 
 // Forms and sends calls from the backlog.  may_block: a call that is full may wait for the slot of the oldest call in flight
-// (ugsm_enqueue_*: back-pressure); otherwise only free slots are used.  Returns the first non-OK status of a call sent here.
-int pump(ugsm_ctx *ctx, Queue *q, bool may_block)
+// (ugsm_enqueue_*: back-pressure); otherwise only free slots are used.  How a call went is reported with its pairs (ugsm_completion.status),
+// never through the entry point that happened to send it: that call may hold other pairs than the one just enqueued.
+void pump(ugsm_ctx *ctx, Queue *q, bool may_block)
 {
     const ugsm_config &cfg = ctx_config(ctx);
-    int first_err = UGSM_OK;
     while (!q->waiting.empty()) {
         reap(ctx, q);
         if (q->round_restarts && q->waiting.front().seq > q->flush_upto) {
@@ -266,12 +269,10 @@ int pump(ugsm_ctx *ctx, Queue *q, bool may_block)
             slot = free_slot(q);
             if (slot < 0) break;
         }
-        dispatch(ctx, q, n, slot);
-        const int st = q->flight.back().status;
-        if (st != UGSM_OK && first_err == UGSM_OK) first_err = st;
+        const bool by_itself = full && !kind_ends && cap > 1 && q->waiting[(size_t)n - 1].seq > q->flush_upto;
+        dispatch(ctx, q, n, slot, (int)q->waiting.size() > n || by_itself);
     }
     update_busy(ctx, q);
-    return first_err;
 }
 
 int check_geometry(ugsm_ctx *ctx, int W, int H, int stride, bool fovea)
@@ -305,7 +306,8 @@ int enqueue(ugsm_ctx *ctx, Item it)
         it.seq = ++q->seq;
         q->waiting.push_back(it);
         ctx_hooks(ctx).queue_busy = true;
-        return pump(ctx, q, true);
+        pump(ctx, q, true);
+        return UGSM_OK;  // the pair is accepted; whatever happens to its call comes out of ugsm_next_done
     });
 }
 
@@ -416,7 +418,7 @@ int next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
     }
     for (;;) {
         reap(ctx, q);
-        (void)pump(ctx, q, false);  // (a slot may just have come free for pairs that wait)
+        pump(ctx, q, false);  // (a slot may just have come free for pairs that wait)
         if (!q->done.empty()) break;
         if (q->flight.empty() && q->waiting.empty()) {
             update_busy(ctx, q);
@@ -439,7 +441,7 @@ int next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
     q->done_managed.erase(q->done_managed.begin());
     if (m >= 0) q->lent.push_back(m);
     // (pairs that waited for room may go out now; the slot-level entry points open up again once nothing is outstanding)
-    (void)pump(ctx, q, false);
+    pump(ctx, q, false);
     return UGSM_OK;
 }
 
@@ -599,7 +601,8 @@ int ugsm_flush(ugsm_ctx *ctx)
         if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_flush: out of host memory");
         q->flush_upto = q->seq;
         q->round_restarts = true;
-        return pump(ctx, q, false);
+        pump(ctx, q, false);
+        return UGSM_OK;
     });
 }
 

@@ -37,11 +37,11 @@ namespace {
 
 constexpr double kScale = 1.41421356;  // MatchLib_common.h:15
 
-enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_SMOOTH_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COST_MARCH4, KC_ITER_SMALL, KC_COUNT };
+enum KClass { KC_COST = 0, KC_SMOOTH, KC_SQBLUR, KC_PYR, KC_SEED, KC_WARP, KC_BOX, KC_MISC, KC_COST_MARCH, KC_PYR_BASE, KC_COST_SMALL, KC_SMOOTH_SMALL, KC_COST_MARCH4, KC_COUNT };
 const char *kClassName[2][KC_COUNT] = {
-    {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_smooth_march",
-     "k_pyr_base", "k_cost_small", "k_smooth_small", "k_cost_march4", "k_iter_small"},
-    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-", "-", "-"}};
+    {"k_cost_split", "k_smooth_fused", "k_sqblur_tiled", "k_blur_decimate_tiled", "k_seed", "-", "-", "misc", "k_cost_march", "k_pyr_base", "k_cost_small",
+     "k_smooth_small", "k_cost_march4"},
+    {"k_cost_ref", "k_smooth_pass", "k_sqblur_clamp", "k_blur_decimate", "k_seed", "k_warp", "k_box", "misc", "-", "-", "-", "-", "-"}};
 constexpr int kNoLevel = UGSM_MAX_LEVELS;  // stats cell of launches that belong to no pyramid level
 struct StatCell {
     long long launches = 0;
@@ -75,7 +75,8 @@ struct Slot {
     bool owns_st = true;           // false: `st` is the stream of slot (index % streams): several slots queue their pairs on one stream
     hipEvent_t ev_done = nullptr;  // recorded at the end of every ugsm_submit_*: what ugsm_wait waits for when the stream is shared
     bool done_recorded = false;
-    bool lat = true;  // the kernel choices of the call in flight: latency (launches short) or throughput (least work); latency_mode()
+    bool busy = false;   // a call has been enqueued here and neither ugsm_wait nor ugsm_poll has seen it finish (get_slot / slot_idle)
+    bool alone = true;   // the call in flight had the chip to itself when it was submitted (call_alone): what the kernel choices follow
     hipEvent_t ev_in = nullptr, ev_L = nullptr, ev_R = nullptr, ev_A[UGSM_MAX_LEVELS] = {};
     float *lr = nullptr;     // LR check: the right-to-left field of level 0 (3 planes) + one 8-byte counter behind it
     size_t lr_cap = 0;
@@ -194,9 +195,8 @@ struct ugsm_ctx {
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
     int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
     int march4_lo = -1, march4_hi = -1;  // development override of k_cost_march4's pixel range (use_march4; -1 = by the mode; 0, 0 = never)
-    int force_mode = -1;  // development override of latency_mode(): 1 latency, 0 throughput
+    int force_alone = -1;  // development override of call_alone(): 1 = every call is taken to be alone on the chip, 0 = none is
     int streams = 1;      // streams the slots' work is dealt onto: slot i enqueues on the stream of slot i % streams (ugsm_config.streams)
-    int iter_small = 0;   // coarse levels: smoothing of iteration m + cost step of iteration m+1 in one launch (k_iter_small)
     int march_mode = 0;   // strip heights of k_cost_march when cfg.march_rows == 0 (launch_cost_march's `rows`: 0, -1, -2, -3)
     int smooth_big_min = 0;  // development override: levels of at least this many pixels run k_smooth_fused on its 112-column tile (0 = by the mode)
     int smooth_rows = 0;  // height of k_smooth_fused's 112-column tile: 0 = by policy (smooth_rows_for), > 0 fixed, -1 / -2 = the latency / throughput rule
@@ -464,7 +464,7 @@ struct Timer {
     {
         // 1: only the dominant (cost) kernel is bracketed -- two events per launch are not free (a 16 MP pair
         // has ~750 launches; bracketing all of them costs slot 0 about 20 %); 2: every kernel class
-        const bool cost_class = kclass == KC_COST || kclass == KC_COST_MARCH || kclass == KC_COST_SMALL || kclass == KC_COST_MARCH4 || kclass == KC_ITER_SMALL;
+        const bool cost_class = kclass == KC_COST || kclass == KC_COST_MARCH || kclass == KC_COST_SMALL || kclass == KC_COST_MARCH4;
         on = slot_idx == 0 && (c->cfg.profile_events >= 2 || (c->cfg.profile_events == 1 && cost_class));
         if (!on) return;
         rec.kclass = kclass;
@@ -519,8 +519,7 @@ struct DevKnobs {
     int fuse_seed = 1;       // UGSM_FUSE_SEED=0: seed every level with its own launch
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
-    int iter_small = -1;     // UGSM_ITER_SMALL=0 / 1: k_iter_small on the coarse levels (default: off -- measured equal)
-    int force_mode = -1;     // UGSM_POLICY=latency|throughput: the kernel choices of every call, whatever the slots and the frame size
+    int force_alone = -1;    // UGSM_ALONE=1 / 0: the kernel choices of a call that has the chip to itself / that shares it, whatever is in flight
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
     char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
     char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
@@ -550,7 +549,6 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     geti("UGSM_KERNEL_PATH", cfg.kernel_path);
     geti("UGSM_MARCH_MIN_PIXELS", cfg.march_min_pixels);
     geti("UGSM_MARCH_ROWS", cfg.march_rows);
-    geti("UGSM_MARCH_SMOOTH", cfg.march_smooth);
     geti("UGSM_SMALL_MAX_PIXELS", cfg.small_max_pixels);
     geti("UGSM_SMALL_MASK", k.small_mask);
     geti("UGSM_FUSE_SEED", k.fuse_seed);
@@ -559,9 +557,8 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     geti("UGSM_MARCH_MODE", k.march_mode);
     if (const char *e = getenv("UGSM_STREAM_PRIO")) snprintf(k.stream_prio, sizeof k.stream_prio, "%s", e);
     if (const char *e = getenv("UGSM_SIDE_PRIO")) k.side_prio = e[0];
-    if (const char *e = getenv("UGSM_POLICY")) k.force_mode = e[0] == 'l' ? 1 : (e[0] == 't' ? 0 : -1);
+    if (const char *e = getenv("UGSM_ALONE")) k.force_alone = e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1);
     geti("UGSM_SMOOTH_BIG_MIN", k.smooth_big_min);
-    geti("UGSM_ITER_SMALL", k.iter_small);
     if (const char *e = getenv("UGSM_BATCH_MAX_PIXELS")) k.batch_max_px = atoll(e);
     if (set_globals) {  // the process-wide tuning variables: back to their defaults first, so that a variable a test has removed stops acting
         smooth_mid_min_pixels = 1 << 18;
@@ -655,11 +652,11 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
         for (int j = 0; j < nb; j++) bt0.in[j] = ((long long)win->y0[j] << 32) | (unsigned)win->x0[j];
     const PyrWindow pw = win ? PyrWindow{win->x0[0], win->y0[0], win->w, win->h} : PyrWindow{0, 0, 0, 0};
     const Batch *const pb = nb > 1 ? &bt : nullptr;
-    // One full-mode pair alone on the chip (a one-slot context): the streaming factor-2 kernel's many short workgroups on the side stream get
+    // One full-mode pair alone on the chip: the streaming factor-2 kernel's many short workgroups on the side stream get
     // in the way of the main stream's latency-bound launches -- 112.3 pairs/s with it on every level, 114.4 with it on the launches of
     // >= 1.5 M outputs only, 114.1 without it (tools/ab.py, same box); foveated calls and everything with more in flight gain from it
     // on every level (a lone foveated pair +1.8 %, batches of eight +3.3 %).
-    const long long stream_min = (ctx->cfg.slots == 1 && nb == 1 && !win) ? 1500000 : 0;
+    const long long stream_min = (s.alone && nb == 1 && !win) ? 1500000 : 0;
     s.cur_level = 0;
     if (base) {
         Timer t(ctx, &s, si, KC_PYR_BASE, (double)s.W * s.H * nb);
@@ -696,21 +693,15 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
 }
 
 // ---- per-level kernel choices ---------------------------------------------------------------------------------------
-// Two sets of thresholds over the same kernels ("Two policies"; every number from tools/ab.py, same box):
-//   latency     a call that has the chip to itself at least some of the time wants every launch SHORT;
-//   throughput  calls that keep the chip full whatever a launch looks like want every launch to do the LEAST WORK.
-// Which one a call gets depends on what is in flight: a one-slot context is always alone; with several slots the chip is full only if
-// the frames are large enough that a pair spends most of its time in levels that fill the chip by themselves.  Four slots: 16 MP and
-// 8 MP frames are 3.8 % / 1.8 % faster under the throughput choices, 4 MP frames 3.9 % SLOWER, the foveated stack (0.25 Mpx windows)
-// 16 % slower.  The frame is what the call matches at its finest level: W x H in full mode, the fovea window in foveated mode.
-// Batched calls (round 4): what counts wherever "does this launch fill the chip" is asked is what the LAUNCH holds -- `pairs` x the level
-// (pairs = the batch where the level is batched, else 1); the thresholds below are therefore compared with pairs x W x H.
-constexpr long long kBusyFramePixels = 6000000;
-bool latency_mode(const ugsm_ctx *ctx, long long frame_px)
-{
-    if (ctx->force_mode >= 0) return ctx->force_mode == 1;
-    return ctx->cfg.slots == 1 || frame_px < kBusyFramePixels;
-}
+// ONE question decides between the two forms a choice may have: does the call have the chip to itself (Slot::alone, call_alone below)?
+// A call that is alone wants every launch SHORT -- nothing else fills the CUs a launch leaves idle; a call that shares the chip with
+// other calls wants every launch to do LITTLE REDUNDANT WORK -- what it wastes, the others could have used.  Five choices ask it
+// (small_max_px, small_rh, smooth_rows_for, the pyramid's streaming threshold in build_pyramids, the side stream); every other
+// threshold is one number, compared with what the LAUNCH holds: pairs x W x H (pairs = the batch where the level is batched, else 1).
+// Rounds 3-5 also switched between two whole threshold sets by ugsm_config.slots and the frame size ("latency" / "throughput" policy);
+// forced against each other over six frame sizes they differ by 0.35 % where bench.py measures (16 MP, calls of eight) and the
+// "throughput" set loses 2-7 % at 8 MP and 4 MP (profiles/r05_ab_policy_sizes.txt), while a lone 16 MP call on a four-slot context --
+// the node's service call -- lost 11.6 % to it: the second set is gone (profiles/r06_ab_alone.txt).
 
 // Levels of at most this many pixels go through a batched call as ONE launch for all its pairs; larger levels are launched pair by
 // pair (one after the other on the slot's stream).  Four slots x four 16 MP pairs, tools/ab.py, same box: 9 Mpx (levels 1-13 batched)
@@ -725,45 +716,42 @@ bool batch_level(const ugsm_ctx *ctx, int W, int H)
 // pairs a launch of a W x H level of the call in `s` holds
 int launch_pairs(const ugsm_ctx *ctx, const Slot &s, int W, int H) { return (s.nb > 1 && batch_level(ctx, W, H)) ? s.nb : 1; }
 
-// K-cost as the marching kernel (ugsm_kernels_march.hip): a strip is one wave working down >= 6 rows.  Throughput: it does the least
-// work per pixel (6 halo rows per strip against the tiles' halos) down to the 63 k-pixel level -- four slots at 16 MP: 163.2 pairs/s at
-// a threshold of 50 000, 162.7 at 100 000, 160.4 at 200 000 (round 2's value), 159.1 at 400 000; below 50 000 the coarse-level latency
-// kernels win again (161.4 with everything marching).  Latency: from 0.4 Mpx -- but the levels of 0.15 - 3 Mpx go to k_cost_march4
-// first (use_march4), so in effect from 3 Mpx.
-constexpr int kMarchMinPixelsThroughput = 50000, kMarchMinPixelsLatency = 400000;
-bool use_march(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
+// Levels of at most this many pixels run the coarse-level latency kernels (ugsm_kernels_small.hip; 0 = none): 0.15 Mpx for a call
+// alone -- above it the other kernels are as fast or faster (tools/kbench modes 7, 14) -- and 50 k pixels when the chip is shared: there
+// the levels of 50-150 k pixels are better off with k_cost_march4 and the tiled K-smooth, which redo less (four slots: the foveated
+// stack +4.5 %, 4 MP frames +2.0 %, 1080p +10-18 %; one pair alone -1.4 %; tools/ab.py).
+constexpr int kSmallMaxPixelsAlone = 150000, kSmallMaxPixelsShared = 50000;
+int small_max_px(const ugsm_config &cfg, bool alone)
 {
-    const ugsm_config &cfg = ctx->cfg;
-    if (cfg.march_min_pixels < 0) return false;
-    const long long thr = cfg.march_min_pixels > 0 ? cfg.march_min_pixels : (lat ? kMarchMinPixelsLatency : kMarchMinPixelsThroughput);
-    return (long long)W * H * pairs >= thr;
+    if (cfg.small_max_pixels < 0) return 0;
+    return cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (alone ? kSmallMaxPixelsAlone : kSmallMaxPixelsShared);
 }
-
-int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
 
 // K-cost as the channel-parallel marching kernel (ugsm_kernels_march4.hip): a workgroup of four waves per strip, a third of the
 // instructions per row step on any one wave.  It wins where a launch lasts as long as one strip -- levels too small to give every SIMD
-// two or three waves of k_cost_march: 0.15 - 3 Mpx (tools/kbench mode 14: 10.9 against 16.4 us at 0.25 Mpx, 24.3 / 29.8 at 1 Mpx,
-// 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).  Latency only: four waves per strip are more instructions in total (-1.3 % with four
-// 16 MP pairs in flight).
-// Levels of at most this many pixels run the coarse-level latency kernels (0 = none): 0.15 Mpx for a pair alone -- above it the other
-// kernels are as fast or faster (tools/kbench modes 7, 14) -- and 50 k pixels with several slots, whatever the frames: there the levels
-// of 50-150 k pixels are better off with k_cost_march4 / k_cost_march and the tiled K-smooth, which redo less (four slots: the foveated
-// stack +4.5 %, 4 MP frames +2.0 %, 1080p +10-18 %; one pair alone -1.4 %; tools/ab.py)
-constexpr int kSmallMaxPixelsAlone = 150000, kSmallMaxPixelsShared = 50000, kMarch4MaxPixels = 3000000;
-int small_max_px(const ugsm_config &cfg)
-{
-    if (cfg.small_max_pixels < 0) return 0;
-    return cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (cfg.slots == 1 ? kSmallMaxPixelsAlone : kSmallMaxPixelsShared);
-}
-bool use_march4(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
+// two or three waves of k_cost_march: up to 3 Mpx (tools/kbench mode 14: 10.9 against 16.4 us at 0.25 Mpx, 24.3 / 29.8 at 1 Mpx,
+// 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).
+constexpr int kMarch4MaxPixels = 3000000;
+bool use_march4(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
     const long long px = (long long)W * H * pairs;
     if (cfg.kernel_path == 1) return false;
     if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
-    return lat && px > small_max_px(cfg) && px <= kMarch4MaxPixels;
+    return px > small_max_px(cfg, alone) && px <= kMarch4MaxPixels;
 }
+
+// K-cost as the marching kernel (ugsm_kernels_march.hip): a strip is one wave working down >= 6 rows; everything above k_cost_march4's
+// range (the launch path asks use_march4 first).  ugsm_config.march_min_pixels moves the threshold (tests run every level through it).
+constexpr int kMarchMinPixels = 400000;
+bool use_march(const ugsm_ctx *ctx, int W, int H, int pairs = 1)
+{
+    const ugsm_config &cfg = ctx->cfg;
+    if (cfg.march_min_pixels < 0) return false;
+    return (long long)W * H * pairs >= (cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchMinPixels);
+}
+
+int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
 
 // The choices of a context that are not in ugsm_config: the development overrides (the defaults are in the functions around here).
 void set_policy(ugsm_ctx *c, const DevKnobs &k)
@@ -778,49 +766,45 @@ void set_policy(ugsm_ctx *c, const DevKnobs &k)
     c->march_mode = k.march_mode <= 0 ? k.march_mode : 0;
     c->march4_lo = k.march4_lo;
     c->march4_hi = k.march4_hi;
-    c->force_mode = k.force_mode;
-    c->iter_small = (kDevLib && k.iter_small > 0) ? 1 : 0;
+    c->force_alone = k.force_alone;
     c->batch_max_px = k.batch_max_px;
 }
 
-// K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most this many pixels has fewer tiles than the chip
-// has CUs, and a launch lasts as long as one tile's chain of phases.  Above ~0.15 Mpx the LDS-tiled kernels are as fast or faster
-// (tools/kbench mode 7).  Returns the K-smooth region height to use (0 = not a small level).
-int small_rh(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
+// K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most small_max_px pixels has fewer tiles than the chip
+// has CUs, and a launch lasts as long as one tile's chain of phases.  Returns the K-smooth region height to use (0 = not a small level).
+int small_rh(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
     if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
-    const long long thr = small_max_px(cfg);
     const long long px = (long long)W * H * pairs;
-    if (px > thr || use_march(ctx, W, H, lat, pairs)) return 0;
+    if (px > small_max_px(cfg, alone) || use_march(ctx, W, H, pairs)) return 0;
     if (ctx->small_rh_force) return ctx->small_rh_force;
-    // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other slots' pairs share the chip -- the 18 x 4 / 18 x 10 tiles
-    // redo 8 x / 4.6 x the work, free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight (tools/ab.py).
-    // A one-slot context has nothing to overlap with: the smallest tile that still gives every workgroup a CU of its own, or nearly.
-    if (cfg.slots > 1) return 32;
+    // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other calls share the chip -- the 18 x 4 / 18 x 10 tiles redo 8 x / 4.6 x
+    // the work, free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight (tools/ab.py).  A call alone has nothing
+    // to overlap with: the smallest tile that still gives every workgroup a CU of its own, or nearly.
+    if (!alone) return 32;
     return px <= 36000 ? 18 : (px <= 80000 ? 24 : 32);
 }
 
 // Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is a marching
 // kernel: the seeded field is then never written (launch_cost_march_seeded, launch_cost_march4).  Not with the early
 // exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
-bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
+bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
     const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, lat, pairs) || use_march4(ctx, W, H, lat, pairs));
+    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, pairs) || use_march4(ctx, W, H, alone, pairs));
 }
 
 // k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.26 Mpx, else 32 x 16), > 0 = the
-// 112-column tile at this height (smooth_tile_rows, ugsm_kernels_fused.hip).  Throughput: the 112 x 36 tile (1.39 x the tile in halo
-// work, against 1.8 x for 64 x 32) from 0.1 Mpx on, +1.7 % with four 16 MP pairs in flight.  Latency: from 0.5 Mpx, and a one-slot
-// context picks the height that fills whole rounds of workgroups.
-int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool lat, int pairs = 1)
+// 112-column tile at this height (smooth_tile_rows, ugsm_kernels_smooth.hip), from 0.5 Mpx per launch: 1.39 x the tile in halo work
+// against 1.8 x for 64 x 32.  A call alone picks the height that fills whole rounds of workgroups.
+int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
-    const int big_min = ctx->smooth_big_min > 0 ? ctx->smooth_big_min : (lat ? (1 << 19) : 100000);
+    const int big_min = ctx->smooth_big_min > 0 ? ctx->smooth_big_min : (1 << 19);
     if ((long long)W * H * pairs < big_min) return 0;
     if (pairs > 1 && W < 100) return 0;  // (a level narrower than the 112-column tile: the smaller tile classes waste fewer lanes)
     if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
-    const int rounds_rule = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (ctx->cfg.slots == 1 ? 1 : 0));
+    const int rounds_rule = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (alone ? 1 : 0));
     return smooth_tile_rows(W, H, rounds_rule, pairs);
 }
 // ... and the tile class of the smaller levels (launch_smooth_fused's tile_class): by what the launch holds
@@ -854,20 +838,17 @@ int enqueue_smooth(ugsm_ctx *ctx, Slot &s, int si, float *&a, float *&b, int W, 
             int p = std::min(left, 5);
             left -= p;
             if (p == 0 && !do_box) break;
-            const bool march = kDevLib && s.nb == 1 && p == 5 && ctx->cfg.march_smooth == 1 && use_march(ctx, W, H, s.lat);
-            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H, s.lat, pairs) : 0;
+            const int rh = (ctx->small_mask & 2) ? small_rh(ctx, W, H, s.alone, pairs) : 0;
             const bool box_now = do_box && left == 0;
             const bool to_final = left == 0 && final_out;
             for_groups(s.nb, pairs > 1, [&](Grp g) {
-                Timer t(ctx, &s, si, march ? KC_SMOOTH_MARCH : (rh ? KC_SMOOTH_SMALL : KC_SMOOTH), px * g.n);
+                Timer t(ctx, &s, si, rh ? KC_SMOOTH_SMALL : KC_SMOOTH, px * g.n);
                 const float *src = a + g.b0 * s.lvl_stride;
                 float *dst = to_final ? final_out[g.b0] : b + g.b0 * s.lvl_stride;
                 const Batch bt = make_batch(s, g, nullptr, nullptr, to_final ? final_out : nullptr);
                 const Batch *pb = g.n > 1 ? &bt : nullptr;
-                // five passes at a time on a large level may run as the marching kernel (libugsm_dev.so); anything else: the LDS-tiled ones
-                if (march) launch_smooth_march(s.st, src, dst, W, H, box_now, 1, ctx->cfg.march_rows);
-                else if (rh) launch_smooth_small(s.st, src, dst, W, H, p, box_now, rh, pb);
-                else launch_smooth_fused(s.st, src, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H, s.lat, g.n), pb, smooth_class_for(W, H, g.n));
+                if (rh) launch_smooth_small(s.st, src, dst, W, H, p, box_now, rh, pb);
+                else launch_smooth_fused(s.st, src, dst, W, H, p, box_now, smooth_rows_for(ctx, W, H, s.alone, g.n), pb, smooth_class_for(W, H, g.n));
             });
             if (!to_final) std::swap(a, b);
         } while (left > 0);
@@ -941,20 +922,14 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, const Img3 *Lv, const Img3 *Rv, in
             }
         });
     }
-    // coarse levels, optional (libugsm_dev.so): the smoothing of iteration m and the cost step of iteration m + 1 in one launch (k_iter_small); the level is
-    // then  cost, (mi - 1) x [smooth + cost], smooth.  `other` carries the cost step's output from one launch to the next.
-    const bool fuse_iter = kDevLib && s.nb == 1 && ctx->iter_small && !ref && !early && S == 5 && (ctx->small_mask & 3) == 3 && small_rh(ctx, W, H, s.lat) != 0 &&
-                           !use_march4(ctx, W, H, s.lat);
-    const bool march4 = !ref && use_march4(ctx, W, H, s.lat, pairs);
-    const bool march = !ref && use_march(ctx, W, H, s.lat, pairs);
-    const bool small = !ref && (ctx->small_mask & 1) && small_rh(ctx, W, H, s.lat, pairs) != 0;
+    const bool march4 = !ref && use_march4(ctx, W, H, s.alone, pairs);
+    const bool march = !ref && use_march(ctx, W, H, pairs);
+    const bool small = !ref && (ctx->small_mask & 1) && small_rh(ctx, W, H, s.alone, pairs) != 0;
     // (k_cost_split, the LDS-tiled form a level falls back to when the marching kernels are switched off, has no batch index: pair by pair)
     const bool cost_batched = batched && (march4 || march || small);
     for (int m = m_from; m <= m_to; m++) {
         const int blend = !(is_top && m == 1);  // MatchGPULib.cpp:2223
-        if (fuse_iter && m > m_from) {
-            // (this iteration's cost step ran in the previous launch)
-        } else if (ref) {
+        if (ref) {
             {
                 Timer t(ctx, &s, si, KC_WARP, px);
                 launch_warp_ref(s.st, Rv[0], cur, W, H, s.Rw);
@@ -978,7 +953,7 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, const Img3 *Lv, const Img3 *Rv, in
                     launch_cost_march4(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, 0, rb, seeded ? seed[g.b0] : SeedMap{0, 0, 0, 0}, pb);
                 else if (march && seeded)
                     launch_cost_march_seeded(s.st, L, R, A3 + fo, cur + fo, seed[g.b0], other + fo, W, H, thr[m - 1], blend, march_rows_arg(ctx), rb, pb);
-                else if (march) launch_cost_march(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, 0, 1, march_rows_arg(ctx), rb, pb);
+                else if (march) launch_cost_march(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, march_rows_arg(ctx), rb, pb);
                 else if (small) launch_cost_small(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend, pb);
                 else launch_cost_fused(s.st, L, R, A3 + fo, cur + fo, other + fo, W, H, thr[m - 1], blend);
             });
@@ -994,12 +969,6 @@ int run_level(ugsm_ctx *ctx, Slot &s, int si, const Img3 *Lv, const Img3 *Rv, in
             other = b;
             third = old;
             if (m < m_to && dif[0] < eps && dif[1] < eps) break;  // differenceIterations: both below the threshold
-            continue;
-        }
-        if (fuse_iter && m < m_to) {
-            Timer t(ctx, &s, si, KC_ITER_SMALL, px);
-            launch_iter_small(s.st, Lv[0], Rv[0], A3, other, cur, W, H, thr[m], 1, S);  // iteration m + 1 >= 2 always blends (MatchGPULib.cpp:2223)
-            std::swap(cur, other);
             continue;
         }
         float *a = other, *b = cur;
@@ -1023,11 +992,12 @@ void full_views(const Slot &s, const float *pyr, int lev, Img3 *out)
     for (int b = 0; b < s.nb; b++) out[b] = level_view(s, pyr + b * s.pyr_stride, lev, 0, 0);
 }
 
-// Whether this call may use the slot's side stream: single pairs on a context that has one, the fused path, no event brackets (the
+// Whether this call may use the slot's side stream: single pairs that have the chip to themselves (with four pairs in flight eight
+// streams on the four hardware queues serialise what one stream per pair lets overlap: -13 %), the fused path, no event brackets (the
 // statistics belong to one stream).
 bool side_stream_ok(const ugsm_ctx *ctx, const Slot &s)
 {
-    return s.nb == 1 && s.st2 != nullptr && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams;
+    return s.nb == 1 && s.alone && s.st2 != nullptr && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams;
 }
 // A = G_clamp * L^2 of the full-frame levels a_from .. top on the side stream, beside whatever the main stream does next (the right
 // pyramid's join, the coarse levels' iterations); run_level takes them through level_A, which makes the main stream wait for each.
@@ -1115,16 +1085,12 @@ const float *level_A(ugsm_ctx *ctx, Slot &s, int i)
     return s.Apyr + s.off[i];
 }
 
-// the kernel choices of a call whose finest level is frame_px pixels per pair: what is in flight is the batch
-void set_call_mode(ugsm_ctx *ctx, Slot &s, long long frame_px) { s.lat = latency_mode(ctx, frame_px * s.nb); }
-
 // matching() with foveatedmatching==0, MatchGPULib.cpp:1196-1318, for the s.nb pairs of the call; d_out: their result buffers.
 // swap: the images exchanged (the right-to-left match of the LR check): the right pyramid is the "left" image; A is then computed
 // in line (the side stream's A planes belong to the left image).
 int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *const *d_out, bool swap = false)
 {
     const int levels = s.levels, nb = s.nb;
-    set_call_mode(ctx, s, (long long)s.W * s.H);
     const float *const pL = swap ? s.pyrR : s.pyrL, *const pR = swap ? s.pyrL : s.pyrR;
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
@@ -1146,7 +1112,7 @@ int enqueue_full(ugsm_ctx *ctx, Slot &s, int si, float *const *d_out, bool swap 
         seeded = false;
         if (i > 0) {
             const int np = launch_pairs(ctx, s, s.w[i - 1], s.h[i - 1]);
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat, np)) {  // the next level's first K-cost launch reads `cur` through the seeding map
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.alone, np)) {  // the next level's first K-cost launch reads `cur` through the seeding map
                 for (int b = 0; b < nb; b++) sm[b] = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
@@ -1206,7 +1172,6 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *const *d_state)
 {
     const int levels = s.levels, F = ctx->cfg.fovea_levels, nb = s.nb;
     if (F < 2 || F > levels) return UGSM_ERR_BAD_ARG;
-    set_call_mode(ctx, s, (long long)s.w[F - 1] * s.h[F - 1]);  // (the fovea window is as large as level F-1)
     float *cur = s.d0, *other = s.d1;
     const int top = levels - 1;
     for (int b = 0; b < nb; b++)
@@ -1224,7 +1189,7 @@ int enqueue_fovea_coarse(ugsm_ctx *ctx, Slot &s, int si, float *const *d_state)
         seeded = false;
         if (i > F - 1) {
             const int np = launch_pairs(ctx, s, s.w[i - 1], s.h[i - 1]);
-            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.lat, np)) {
+            if (fuse_seed(ctx, s.w[i - 1], s.h[i - 1], s.alone, np)) {
                 for (int b = 0; b < nb; b++) sm[b] = SeedMap{s.w[i], s.h[i], 0, 0};
                 seeded = true;
             } else {
@@ -1260,7 +1225,6 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *const *d_sta
     FoveaGeom g[kMaxBatch];
     for (int b = 0; b < nb; b++) fovea_geometry(s.w, s.h, F, off_x[b], off_y[b], g[b]);
     const int fw = g[0].fw, fh = g[0].fh;
-    set_call_mode(ctx, s, (long long)fw * fh);
     const size_t fn = (size_t)fw * fh;
     const int np = launch_pairs(ctx, s, fw, fh);  // (every level of the fine phase is a window of this size)
     float *cur = s.d0, *other = s.d1;
@@ -1286,7 +1250,7 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *const *d_sta
             Lv[b] = level_view(s, s.pyrL + b * s.pyr_stride, i, g[b].ox[i], g[b].oy[i]);
             Rv[b] = level_view(s, s.pyrR + b * s.pyr_stride, i, g[b].ox[i], g[b].oy[i]);
         }
-        const bool seeded = fuse_seed(ctx, fw, fh, s.lat, np);
+        const bool seeded = fuse_seed(ctx, fw, fh, s.alone, np);
         if (!seeded) {
             for_groups(nb, np > 1, [&](Grp gr) {
                 Timer t(ctx, &s, si, KC_SEED, (double)fn * gr.n);
@@ -1331,6 +1295,31 @@ int enqueue_fovea_fine(ugsm_ctx *ctx, Slot &s, int si, const float *d_state, int
     return enqueue_fovea_fine(ctx, s, si, &d_state, &off_x, &off_y, &d_stack, d_pyrL ? &d_pyrL : nullptr, d_pyrR ? &d_pyrR : nullptr);
 }
 
+// Has everything enqueued on the slot finished?  (Never blocks; a slot found idle stops counting as busy.)
+bool slot_idle(Slot &s)
+{
+    if (!s.busy) return true;
+    const hipError_t e = s.done_recorded ? hipEventQuery(s.ev_done) : hipStreamQuery(s.st);
+    if (e == hipErrorNotReady) return false;
+    if (e != hipSuccess) (void)hipGetLastError();  // (the slot's own ugsm_wait / ugsm_poll reports it)
+    s.busy = false;
+    return true;
+}
+// Does the call about to be enqueued on `slot` have the chip to itself?  It does when nothing is unfinished on any other slot of the
+// context and the dispatcher has not said that more calls follow (the queue, ugsm_queue.cpp: pairs wait behind this call, or a call
+// filled up by itself -- a host that submits faster than the chip matches).  The blocking entry points (ugsm_match_*: the node's service
+// call, UG_GPU_matcher.cpp:497-694, and its one-at-a-time topic path, :126-185) are therefore alone whatever ugsm_config.slots says; a
+// burst through the slot API is alone for its first call only.  What is in flight decides -- not how many slots the context was created
+// with.
+bool call_alone(ugsm_ctx *ctx, int slot)
+{
+    if (ctx->force_alone >= 0) return ctx->force_alone == 1;
+    if (ctx->hooks.queue_calling && ctx->hooks.queue_more) return false;
+    for (int i = 0; i < (int)ctx->slots.size(); i++)
+        if (i != slot && !slot_idle(ctx->slots[i])) return false;
+    return true;
+}
+
 int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
 {
     if (!ctx) return UGSM_ERR_BAD_ARG;
@@ -1343,7 +1332,11 @@ int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
         return UGSM_ERR_STATE;
     }
     *out = &ctx->slots[slot];
-    if (enqueues) (*out)->done_recorded = false;  // whatever this call enqueues comes after the slot's last completion mark
+    if (enqueues) {
+        (*out)->alone = call_alone(ctx, slot);
+        (*out)->busy = true;
+        (*out)->done_recorded = false;  // whatever this call enqueues comes after the slot's last completion mark
+    }
     return UGSM_OK;
 }
 
@@ -1370,7 +1363,7 @@ int stage_in(ugsm_ctx *ctx, Slot &s, const uint8_t *rgbL, const uint8_t *rgbR, i
     HIPCHK(ctx, hipMemcpyAsync(s.rgbL, rgbL, bytes, hipMemcpyHostToDevice, s.st));
     // the right image goes up on the side stream, where its pyramid is built: the transfer (0.9 ms at 16 MP) then runs under the
     // left pyramid instead of in front of it.  The side stream first waits for what the slot did before.
-    if (s.st2 && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams) {
+    if (s.alone && s.st2 && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams) {  // (single pairs: as side_stream_ok)
         HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
         HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
         HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st2));
@@ -1556,8 +1549,8 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         cfg.kernel_path > 1 || cfg.fovea_levels < 0 || cfg.fovea_levels > cfg.levels || !(cfg.lr_check_threshold >= 0.0f) || cfg.streams < 0 ||
         cfg.batch < 0 || cfg.batch > UGSM_MAX_BATCH || cfg.stream_priority < 0 || cfg.stream_priority > 3)
         return UGSM_ERR_BAD_ARG;
-    if (cfg.kernel_path == 1 && !kDevLib) return UGSM_ERR_BAD_ARG;  // the one-kernel-per-stage path lives in libugsm_dev.so
-    if (!kDevLib) cfg.march_smooth = 0;                              // ... and so does the marching K-smooth
+    if (cfg.kernel_path == 1 && !kDevLib) return UGSM_ERR_BAD_ARG;       // the one-kernel-per-stage path lives in libugsm_dev.so
+    if (cfg.march_min_pixels < 0 && !kDevLib) return UGSM_ERR_BAD_ARG;  // ... and so does round 1's LDS-tiled K-cost
     static_assert(UGSM_MAX_BATCH == kMaxBatch, "include/ugsm.h and ugsm_launch.hpp disagree on the batch size");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return UGSM_ERR_NO_DEVICE;
@@ -1567,10 +1560,11 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->cfg = cfg;
     set_policy(ctx, knobs);
     if (dev_env_on() && getenv("UGSM_MEM_LIMIT_MB")) ctx->mem_limit = atoll(getenv("UGSM_MEM_LIMIT_MB")) << 20;
-    // The side stream pays when a pair is alone on the chip (107 against 105 pairs/s at 16 MP: the right pyramid and the A planes run
-    // beside the left pyramid and the coarse levels).  With four pairs in flight it LOSES 13 % (136 against 157 pairs/s): eight
-    // streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So: one-slot contexts only.
-    ctx->two_streams = knobs.two_streams >= 0 ? knobs.two_streams : (cfg.slots == 1 ? 1 : 0);
+    // The side stream pays when a pair is alone on the chip (116.7 against 114.0 pairs/s at 16 MP: the right pyramid and the A planes run
+    // beside the left pyramid and the coarse levels; profiles/r06_ab_alone.txt).  With four pairs in flight it LOSES 13 % (136 against
+    // 157 pairs/s): eight streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So every slot
+    // has one, and only a call that is alone on the chip uses it (side_stream_ok).
+    ctx->two_streams = knobs.two_streams >= 0 ? knobs.two_streams : 1;
     ctx->slots.resize(cfg.slots);
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
@@ -1590,14 +1584,19 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         // uses, for a start -- hold queues of the same pool, and four slots then land on three queues: 128 pairs/s instead of 165
         // at 16 MP (tools/ab.py; round 2 measured 161 only because its idle side streams happened to push the slots apart).  So:
         // slots 0-3 at the greatest priority (a pool the application is unlikely to use), slots 4-7 at the least, the rest at the
-        // default.  Equal priority among the first four; the side stream of a one-slot context rides in the same pool.
+        // default.  Equal priority among the first four.
         // ugsm_config.stream_priority: 1 = everything at the process default (opt out), 2 / 3 = everything at the greatest / least
         const char by_cfg = cfg.stream_priority == 1 ? 'n' : (cfg.stream_priority == 2 ? 'h' : (cfg.stream_priority == 3 ? 'l' : (si < 4 ? 'h' : (si < 8 ? 'l' : 'n'))));
         const char pc = knobs.stream_prio[0] ? (si < (int)strlen(knobs.stream_prio) ? knobs.stream_prio[si] : 'n') : by_cfg;
         const int prio = pc == 'h' ? prio_greatest : (pc == 'l' ? prio_least : 0);
         bool ok = (!s.owns_st || hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess) &&
-                  hipMalloc((void **)&s.range_bad, 64) == hipSuccess && hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess &&
-                  (!ctx->two_streams || hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : prio))) == hipSuccess);
+                  hipMalloc((void **)&s.range_bad, 64) == hipSuccess && hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess;
+        // The side stream rides in the OTHER priority pool than the slot's own stream -- least priority beside a greatest-priority slot:
+        // HIP deals the streams of one priority level onto four hardware queues, and a side stream that lands on its own slot's queue
+        // runs strictly after it; across pools the queues are distinct (tools/queue_probe 'hhhhllll': eight queue groups).  The lower
+        // priority costs nothing (116.9 against 116.7 pairs/s; the default pool: -0.5 %; profiles/r06_ab_alone.txt).
+        const int side = knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : (pc == 'l' ? prio_greatest : prio_least)));
+        ok = ok && (!ctx->two_streams || hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, side) == hipSuccess);
         for (hipEvent_t *e : {&s.ev_in, &s.ev_L, &s.ev_R}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < cfg.levels; i++) ok = ok && hipEventCreateWithFlags(&s.ev_A[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
@@ -1665,11 +1664,9 @@ int ugsm_level_dims(int W, int H, int levels, int *w, int *h)
 int ugsm_level_iterations(int level) { return level < 0 ? 0 : level_iterations(level); }
 int ugsm_level_smooth_passes(int level) { return level < 0 ? 0 : level_smooth(level); }
 
-int ugsm_plan_level(const ugsm_config *cfg_in, int W, int H, ugsm_level_plan *out) { return ugsm_plan_level_in_frame(cfg_in, W, H, W, H, out); }
-
-int ugsm_plan_level_in_frame(const ugsm_config *cfg_in, int frame_w, int frame_h, int W, int H, ugsm_level_plan *out)
+int ugsm_plan_level(const ugsm_config *cfg_in, int alone, int W, int H, ugsm_level_plan *out)
 {
-    if (!out || W < 1 || H < 1 || frame_w < 1 || frame_h < 1) return UGSM_ERR_BAD_ARG;
+    if (!out || W < 1 || H < 1) return UGSM_ERR_BAD_ARG;
     ugsm_ctx probe;  // host-only: the same policy functions the launch path calls, on a context that owns no device state
     if (cfg_in) probe.cfg = *cfg_in;
     else ugsm_default_config(&probe.cfg);
@@ -1684,22 +1681,22 @@ int ugsm_plan_level_in_frame(const ugsm_config *cfg_in, int frame_w, int frame_h
         out->pairs_per_launch = 1;
         return UGSM_OK;
     }
-    // a context created for batches (ugsm_config.batch) is asked about a call of that many pairs: what is in flight is the batch, and a
-    // level of at most kBatchMaxPixels is one launch for all its pairs
+    // a context created for batches (ugsm_config.batch) is asked about a call of that many pairs: a level of at most kBatchMaxPixels is one
+    // launch for all of them, and the thresholds are compared with what the launch holds
     const int nb = std::min(std::max(probe.cfg.batch, 1), kMaxBatch);
-    const bool lat = latency_mode(&probe, (long long)frame_w * frame_h * nb);
-    out->latency_policy = lat ? 1 : 0;
+    const bool al = probe.force_alone >= 0 ? probe.force_alone == 1 : alone != 0;
+    out->alone = al ? 1 : 0;
     const int pairs = (nb > 1 && batch_level(&probe, W, H)) ? nb : 1;
-    const bool march = use_march(&probe, W, H, lat, pairs);
-    const int rh = small_rh(&probe, W, H, lat, pairs);
-    const bool march4 = use_march4(&probe, W, H, lat, pairs);
+    const bool march4 = use_march4(&probe, W, H, al, pairs);  // (asked first, as in run_level)
+    const bool march = use_march(&probe, W, H, pairs);
+    const int rh = small_rh(&probe, W, H, al, pairs);
     out->cost_kernel = march4 ? 4 : (march ? 1 : ((rh && (probe.small_mask & 1)) ? 2 : 0));
-    out->smooth_kernel = (kDevLib && march && probe.cfg.march_smooth == 1 && nb == 1) ? 1 : ((rh && (probe.small_mask & 2)) ? 2 : 0);
+    out->smooth_kernel = (rh && (probe.small_mask & 2)) ? 2 : 0;
     out->smooth_rh = (probe.small_mask & 2) ? rh : 0;
     out->strip_rows = march4 ? march4_strip_rows(W, H, pairs)
-                             : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, 1, probe.march_mode <= -2, pairs)) : 0);
-    out->seed_fused = fuse_seed(&probe, W, H, lat, pairs) ? 1 : 0;
-    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H, lat, pairs) : 0;
+                             : (march ? (probe.cfg.march_rows > 0 ? probe.cfg.march_rows : march_strip_rows(W, H, probe.march_mode <= -2, pairs)) : 0);
+    out->seed_fused = fuse_seed(&probe, W, H, al, pairs) ? 1 : 0;
+    out->smooth_tile_rows = out->smooth_kernel == 0 ? smooth_rows_for(&probe, W, H, al, pairs) : 0;
     out->pairs_per_launch = pairs;
     return UGSM_OK;
 }
@@ -1868,6 +1865,7 @@ int ugsm_wait(ugsm_ctx *ctx, int slot)
     UCHK(get_slot(ctx, slot, &s, false));
     if (s->done_recorded) HIPCHK(ctx, hipEventSynchronize(s->ev_done));  // (shared stream: this slot's pair, not the ones queued behind it)
     else HIPCHK(ctx, hipStreamSynchronize(s->st));
+    s->busy = false;
     harvest(ctx, *s);
     return UGSM_OK;
 }
@@ -1879,6 +1877,7 @@ int ugsm_poll(ugsm_ctx *ctx, int slot)
     const hipError_t e = s->done_recorded ? hipEventQuery(s->ev_done) : hipStreamQuery(s->st);
     if (e == hipErrorNotReady) return UGSM_PENDING;
     HIPCHK(ctx, e);
+    s->busy = false;
     harvest(ctx, *s);
     return UGSM_OK;
 }
@@ -2154,7 +2153,6 @@ int ugsm_stage_iterate(ugsm_ctx *ctx, const float *d_L3, const float *d_R3, floa
         launch_range_scan(s->st, d_L3, 3 * n, s->range_bad);
         launch_range_scan(s->st, d_R3, 3 * n, s->range_bad);
     }
-    s->lat = latency_mode(ctx, (long long)W * H);
     s->nb = 1;
     const Img3 Lv{d_L3, W, n}, Rv{d_R3, W, n};
     UCHK(run_level(ctx, *s, 0, &Lv, &Rv, W, H, mi, S, is_top != 0, m_from, m_to, cur, other, d_dbg8));
@@ -2187,7 +2185,6 @@ int ugsm_stage_smooth(ugsm_ctx *ctx, float *d_d3, int W, int H, int passes, int 
     float *a = s->d0, *b = s->d1;
     HIPCHK(ctx, hipMemcpyAsync(a, d_d3, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
     s->nb = 1;
-    s->lat = latency_mode(ctx, (long long)W * H);
     UCHK(enqueue_smooth(ctx, *s, 0, a, b, W, H, passes, do_box != 0));
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(d_d3, a, lvl * sizeof(float), hipMemcpyDeviceToDevice, s->st));
