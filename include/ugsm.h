@@ -52,6 +52,8 @@ extern "C" {
 #define UGSM_ERR_STATE         7  /* e.g. fine phase without coarse phase */
 #define UGSM_PENDING           8  /* not an error: ugsm_poll / ugsm_next_done(block = 0) -- the work asked about has not finished yet */
 #define UGSM_EMPTY             9  /* not an error: ugsm_next_done -- every pair enqueued so far has been reported */
+#define UGSM_ERR_PEER          10 /* the fovea shard: another rank failed its part of the step (this rank's result is not valid), or no rank answered
+                                     within the deadline and the communicator was aborted; ugsm_last_error says which */
 
 #define UGSM_MAX_LEVELS 32
 #define UGSM_MAX_BATCH 16  /* pairs per ugsm_submit_*_batch call */
@@ -353,7 +355,20 @@ int ugsm_submit_fovea_fine(ugsm_ctx *ctx, int slot, const float *d_state, int of
  * the result equals ugsm_submit_foveated's, bit for bit.  The reference has one centred fovea on one GPU (MatchGPULib.cpp:1173-1176),
  * seeded from level F-1 (:1230-1240, :1283-1293); the window offset and the shard are this build's (BASELINE.json north_star).
  * librccl.so.1 is loaded on first use (dlopen: a host that never shards does not pay for a 570 MB library); UGSM_ERR_NO_DEVICE when it
- * cannot be found, UGSM_ERR_DEVICE + ugsm_last_error for RCCL failures. */
+ * cannot be found, UGSM_ERR_DEVICE + ugsm_last_error for RCCL failures.
+ *
+ * WHEN A RANK FAILS (ABI 6).  A collective is a promise to the other ranks, so the library keeps it whatever happens locally:
+ *   - what every rank refuses alike (bad arguments, bad geometry, a context whose queue is busy) is refused BEFORE anything is enqueued, on
+ *     every rank, and no collective goes out;
+ *   - a rank whose pyramids or coarse phase fail afterwards (UGSM_ERR_NOMEM, UGSM_ERR_DEVICE) STILL takes part in the broadcast, then returns
+ *     its status from ugsm_submit_fovea_shard.  The state the source sends carries a status word: where the source failed, every other rank's
+ *     ugsm_wait / ugsm_poll on that slot answers UGSM_ERR_PEER (ugsm_last_error names the rank and its status; d_stack is not valid).  A
+ *     non-source rank that fails harms nobody: the others' results are valid.  The communicator stays usable: the next step runs;
+ *   - a rank that never reaches the exchange (a crashed process; a rank that could not even allocate the 3 MB state buffer) cannot be told
+ *     from a slow one, so there is a deadline: ugsm_shard_set_timeout(ctx, ms).  A step still unfinished `ms` after its submission makes
+ *     ugsm_wait abort the communicator (ncclCommAbort), and answer UGSM_ERR_PEER; every later shard call answers UGSM_ERR_STATE until the host
+ *     has called ugsm_shard_finalize and ugsm_shard_init again (on every surviving rank, with a new id).  0 (default): no deadline.
+ * ugsm_shard_gather is a collective like the others: after a failed step every rank still makes the gather call its protocol has. */
 #define UGSM_SHARD_ID_BYTES 128  /* sizeof(ncclUniqueId) */
 /* Rank 0 makes an id (ncclGetUniqueId) and hands its 128 bytes to the other ranks by whatever means the host has (a ROS parameter, a
  * file, MPI, torch.distributed's store): out-of-band, once. */
@@ -372,6 +387,8 @@ int ugsm_shard_rank(const ugsm_ctx *ctx, int *rank, int *world);
 int ugsm_shard_count_ranks(ugsm_ctx *ctx, int *ranks);
 int ugsm_submit_fovea_shard(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int off_x,
                             int off_y, float *d_stack, int src_rank);
+/* Deadline of a shard step, in milliseconds from its submission (0 = none); see "when a rank fails" above. */
+int ugsm_shard_set_timeout(ugsm_ctx *ctx, long long milliseconds);
 /* Optional: every rank's fovea stack (3 x (F fovH) x fovW floats, 21 MB at 16 MP) to the one consumer rank -- ncclSend on the others,
  * ncclRecv x (world - 1) + one device copy on dst_rank, on the slot's stream (ordered after the slot's shard call).  d_all (dst_rank
  * only, else NULL): world x stack_floats. */

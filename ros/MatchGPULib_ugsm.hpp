@@ -147,11 +147,14 @@ public:
     // ((levels 3 fovH) x fovW, :203-226).  The planes belong to the library and stay valid until the next nextDone.
     struct Done {
         uint64_t tag;
+        int status;      // UGSM_OK, or the status of the library call the pair went out in (planes are then null: nothing to publish)
         bool foveated, pyramids;
         int rows, cols;  // of the image
         float *planes[5];
     };
-    // true: *out filled.  false: nothing outstanding, or (block == false) the oldest pair has not finished, or its call failed (stderr).
+    // true: *out filled -- the oldest pair has been REPORTED and no longer counts as outstanding; out->status says how its call went (a
+    // failed call: logged to stderr, planes null; the caller drops whatever it keeps under the tag).  false: nothing outstanding, or
+    // (block == false) the oldest pair has not finished.
     bool nextDone(bool block, Done *out)
     {
         ugsm_completion c;
@@ -159,9 +162,8 @@ public:
         if (st != UGSM_OK) { if (st != UGSM_PENDING && st != UGSM_EMPTY) report(st); return false; }
         const Kind k = kinds_[c.tag];
         kinds_.erase(c.tag);
-        if (c.status != UGSM_OK) { report(c.status); return false; }
-        out->tag = c.tag; out->foveated = k.foveated; out->pyramids = k.pyramids; out->rows = k.H; out->cols = k.W;
-        for (int i = 0; i < 5; i++) out->planes[i] = c.result[i];
+        out->tag = c.tag; out->status = report(c.status); out->foveated = k.foveated; out->pyramids = k.pyramids; out->rows = k.H; out->cols = k.W;
+        for (int i = 0; i < 5; i++) out->planes[i] = c.status == UGSM_OK ? c.result[i] : nullptr;
         return true;
     }
 

@@ -113,6 +113,10 @@ private:
         if (in_flight_.empty() || !mgpu_->nextDone(block, &d)) return false;
         const InFlight f = in_flight_[d.tag];
         in_flight_.erase(d.tag);
+        if (d.status != UGSM_OK) {  // the frame's call failed (reference: exit()): the frame is dropped, the node lives on
+            ROS_ERROR("ugsm: frame %llu dropped: %s", (unsigned long long)d.tag, ugsm_status_string(d.status));
+            return true;
+        }
         if (d.foveated) {
             const int fh = mgpu_->getFoveaHeight();
             if (d.pyramids) {
@@ -182,6 +186,7 @@ private:
             // frames_in_flight pairs are outstanding
             const uint64_t tag = next_tag_++;
             if (fov == 1) mgpu_->initStack(L, R);
+            // (a status other than UGSM_OK = the pair was REJECTED and nothing is outstanding under the tag: include/ugsm.h, ugsm_enqueue_*)
             const int st = fov == 1 ? mgpu_->enqueueStack(L, R, true, tag) : mgpu_->enqueueMatch(L, R, tag);
             if (st != UGSM_OK) { ROS_ERROR("ugsm enqueue failed: %s", ugsm_status_string(st)); return; }
             in_flight_[tag] = InFlight{L->header, R->header};

@@ -10,7 +10,11 @@ of an off-centre window.  Runs in a process of its own so that a hang inside RCC
   C  ugsm_shard_gather: the consumer rank's own stack lands in d_all (one rank: the device copy; no send / receive);
   D  call-sequence errors: a shard call on a context that has not joined (UGSM_ERR_STATE), a second ugsm_shard_init (UGSM_ERR_STATE), a
      source rank outside the communicator (UGSM_ERR_BAD_ARG) -- all refused BEFORE any collective is enqueued;
-  E  after ugsm_shard_finalize the context works as before (ugsm_submit_foveated).
+  E  after ugsm_shard_finalize the context works as before (ugsm_submit_foveated);
+  F  the deadline (round 6, include/ugsm.h "when a rank fails"): with ugsm_shard_set_timeout(1 ms) a step that is still running at its deadline
+     makes ugsm_wait abort the communicator (ncclCommAbort of the REAL library) and answer UGSM_ERR_PEER; every later shard call answers
+     UGSM_ERR_STATE; after ugsm_shard_finalize + ugsm_shard_init (a new id) a step is bit-exact again;
+  G  ugsm_shard_init_all with one context (ncclCommInitAll), a step, ugsm_shard_finalize.
 
 Prints one line "RCCL_SHARD_OK ..." on success; any failure raises.
 """
@@ -116,8 +120,39 @@ def main():
         ctx.check(lib.ugsm_submit_foveated(h, 1, pairs[1][0].data_ptr(), pairs[1][1].data_ptr(), W, H, stride, off[0], off[1], o2.data_ptr(), None, None))
         ctx.check(lib.ugsm_wait(h, 1))
         same(o2, expect[1], "E: ugsm_submit_foveated after ugsm_shard_finalize")
+        # ---- F: a step that misses its deadline -----------------------------------------------------------------------------------
+        ud.shard_init(ctx, rank, world)
+        ctx.shard_set_timeout(1)
+        t_f = "skipped (the step finished inside its millisecond)"
+        for attempt in range(3):           # (a 16 MP step takes ~2 ms: the deadline passes while it runs; smaller frames may need the queue behind them)
+            for q in range(3):
+                ctx.submit_fovea_shard(0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off, outs[0].data_ptr(), 0)
+            st = lib.ugsm_wait(h, 0)
+            if st == _lib.UGSM_ERR_PEER:
+                t_f = "deadline fired"
+                msg = lib.ugsm_last_error(h).decode()
+                assert "did not finish within 1 ms" in msg and "aborted" in msg, msg
+                st2 = lib.ugsm_submit_fovea_shard(h, 0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off[0], off[1], outs[0].data_ptr(), 0)
+                assert st2 == _lib.UGSM_ERR_STATE and "aborted" in lib.ugsm_last_error(h).decode(), (st2, lib.ugsm_last_error(h))
+                assert lib.ugsm_shard_count_ranks(h, C.byref(r_)) == _lib.UGSM_ERR_STATE
+                break
+            assert st == _lib.UGSM_OK, st
+        ctx.shard_finalize()
+        ud.shard_init(ctx, rank, world)          # a fresh communicator: the shard works again
+        ctx.submit_fovea_shard(1, pairs[1][0].data_ptr(), pairs[1][1].data_ptr(), W, H, stride, off, outs[1].data_ptr(), 0)
+        ctx.check(lib.ugsm_wait(h, 1))
+        same(outs[1], expect[1], "F: a step after ugsm_shard_finalize + ugsm_shard_init")
+        ctx.shard_finalize()
+
+        # ---- G: one process that owns the GPUs of the shard (here: one) --------------------------------------------------------------
+        ctx.shard_init_all()
+        assert ctx.shard_count_ranks() == 1
+        ctx.submit_fovea_shard(0, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), W, H, stride, off, outs[0].data_ptr(), 0)
+        ctx.check(lib.ugsm_wait(h, 0))
+        same(outs[0], expect[0], "G: a step over ugsm_shard_init_all")
+        ctx.shard_finalize()
     dist.destroy_process_group()
-    print(f"RCCL_SHARD_OK steps={steps} slots={slots} offset={off} fovea={fw}x{fh} rccl_ranks={counted} exchange=inside-the-library", flush=True)
+    print(f"RCCL_SHARD_OK deadline: {t_f}; steps={steps} slots={slots} offset={off} fovea={fw}x{fh} rccl_ranks={counted} exchange=inside-the-library", flush=True)
 
 
 if __name__ == "__main__":

@@ -415,7 +415,7 @@ def test_out_of_device_memory_is_a_status_code_and_the_context_lives_on(lib, orc
         dL, dR = c.to_device(L), c.to_device(R)
         outs = [c.alloc(3 * W * H * 4) for _ in range(5)]
         rets = [c.lib.ugsm_enqueue_full(c.handle, dL, dR, W, H, 3 * W, outs[k], 10 + k) for k in range(4)]   # one slot: the first call takes four
-        assert rets[:3] == [0, 0, 0] and rets[3] == lib.UGSM_ERR_NOMEM, rets      # the enqueue that completed the call reports its failure
+        assert rets == [0, 0, 0, 0], rets   # every pair was ACCEPTED (ABI 6: a return value speaks of the pair just enqueued, never of a call it happened to send)
         got = []
         while c.lib.ugsm_next_done(c.handle, C.byref(comp), 1) == lib.UGSM_OK:
             got.append((comp.tag, comp.status, comp.call_pairs))
@@ -424,6 +424,17 @@ def test_out_of_device_memory_is_a_status_code_and_the_context_lives_on(lib, orc
         d = c.next_done(True)
         assert d.tag == 99 and d.status == 0 and d.call_pairs == 1
         assert_bit_equal(c.to_host(outs[4], (3, H, W)), exp, "a one-pair call after the refused call of four")
+        # the Python binding: a failed pair raises WITH its tag (it has been reported; whoever keeps per-tag state drops it first), and the
+        # reference-shaped mirror forgets it -- outstanding() goes back to zero, nothing hangs
+        for k in range(4):
+            c.enqueue_full(dL, dR, W, H, 3 * W, outs[k], 200 + k)
+        tags = []
+        for k in range(4):
+            with pytest.raises(lib.UgsmError) as ei:
+                c.next_done(True)
+            assert ei.value.status == lib.UGSM_ERR_NOMEM
+            tags.append(ei.value.tag)
+        assert tags == [200, 201, 202, 203] and c.next_done(True) is None
         for p in [dL, dR] + outs:
             c.free(p)
 

@@ -356,6 +356,89 @@ def test_node_mirror_pipelined_topic_path_equals_the_blocking_one(lib):
                 assert (ma.im_width, ma.im_height, ma.roi_width, ma.roi_height, ma.num_levels) == (mb.im_width, mb.im_height, mb.roi_width, mb.roi_height, mb.num_levels)
 
 
+def test_node_mirror_survives_frames_whose_call_fails(lib, monkeypatch):
+    """a failed pair used to stay in MatchGPULib._tags / GPUMatcher._pending for good (Context.next_done raised after the completion
+    had been consumed), and after frames_in_flight failed frames the back-pressure loop of mainRoutine never ended.  Every frame's call is
+    refused here (UGSM_MEM_LIMIT_MB far below what a 640 x 480 pair needs): every frame is dropped, counted, forgotten -- and nothing hangs."""
+    from ug_stereomatcher_amd import service as sv, synth
+    monkeypatch.setenv("UGSM_MEM_LIMIT_MB", "4")
+    W, H = 640, 480
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 760)
+    log = []
+    node = sv.GPUMatcher(2, ["node", "x", "5"], params={sv.FOVEATEDQ: 0}, publish=lambda t, m: log.append(t), frames_in_flight=2)
+    try:
+        for k in range(5):
+            hl, hr = sv.Header(seq=k, stamp=1.0 + k, frame_id="left"), sv.Header(seq=k, stamp=1.0 + k, frame_id="right")
+            node.mainRoutine(sv.Image.from_array(L, "rgb8", hl), sv.Image.from_array(R, "rgb8", hr))      # (used to spin for ever at k = 2)
+            assert node._matcher().outstanding() < 2
+        node.drain()
+        assert node.failed_frames == 5 and not node._pending and node._matcher().outstanding() == 0 and log == []
+        rsp = sv.GetDisparitiesGPUResponse()                    # the blocking service call fails the same way: false, as for a cv_bridge failure
+        assert node.disparitySrv(sv.GetDisparitiesGPURequest(sv.Image.from_array(L, "rgb8", hl), sv.Image.from_array(R, "rgb8", hr)), rsp) is False
+    finally:
+        node._matcher().close()
+
+
+def test_kernel_choices_follow_what_is_in_flight(lib, orc):
+    """which choices a call gets is decided from what is in flight when it is submitted, not from ugsm_config.slots.  Visible
+    from outside through the launch statistics (profile_events = 2 brackets slot 0's launches by kernel class): the 434 x 287 level of an
+    872 x 576 pair runs k_cost_small when the call is alone on the chip and k_cost_march4 when another slot is busy -- on the SAME four-slot
+    context; the blocking entry point is always alone.  Results are the oracle's either way."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv = 872, 576, 10
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 770)
+    exp = orc.match_full(L, R, lv)
+    lw, lh = lib.level_dims(W, H, lv)
+    mid = [i for i in range(lv) if 50000 < lw[i] * lh[i] <= 150000]
+    assert mid, (lw, lh)
+
+    def cost_kernels(c, level):
+        return sorted({s["name"] for s in c.kernel_stats() if s["level"] == level and s["name"].startswith("k_cost")})
+
+    with lib.Context(levels=lv, slots=4, profile_events=2) as c:
+        dL, dR = c.to_device(L), c.to_device(R)
+        outs = [c.alloc(3 * W * H * 4) for _ in range(2)]
+        # alone: nothing else in flight
+        c.check(c.lib.ugsm_submit_full(c.handle, 0, dL, dR, W, H, 3 * W, outs[0]))
+        c.check(c.lib.ugsm_wait(c.handle, 0))
+        assert_bit_equal(c.to_host(outs[0], (3, H, W)), exp, "alone")
+        assert cost_kernels(c, mid[0]) == ["k_cost_small"], cost_kernels(c, mid[0])
+        c.reset_kernel_stats()
+        # shared: slot 1 is busy when slot 0's call is submitted
+        c.check(c.lib.ugsm_submit_full(c.handle, 1, dL, dR, W, H, 3 * W, outs[1]))
+        c.check(c.lib.ugsm_submit_full(c.handle, 0, dL, dR, W, H, 3 * W, outs[0]))
+        c.check(c.lib.ugsm_wait_all(c.handle))
+        assert_bit_equal(c.to_host(outs[0], (3, H, W)), exp, "shared, slot 0")
+        assert_bit_equal(c.to_host(outs[1], (3, H, W)), exp, "shared, slot 1")
+        assert cost_kernels(c, mid[0]) == ["k_cost_march4"], cost_kernels(c, mid[0])
+        c.reset_kernel_stats()
+        # the blocking entry point (the node's service call) on the same four-slot context: alone again
+        out = np.empty((3, H, W), np.float32)
+        c.check(c.lib.ugsm_match_full(c.handle, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
+        assert_bit_equal(out, exp, "ugsm_match_full")
+        assert cost_kernels(c, mid[0]) == ["k_cost_small"], cost_kernels(c, mid[0])
+        c.reset_kernel_stats()
+        # through the queue: a flushed pair with nothing else in flight is alone; a burst that fills calls is not
+        c.enqueue_full(dL, dR, W, H, 3 * W, outs[0], 1)
+        c.flush()
+        assert [d.tag for d in c.drain()] == [1]
+        assert cost_kernels(c, mid[0]) == ["k_cost_small"], cost_kernels(c, mid[0])
+        for p in [dL, dR] + outs:
+            c.free(p)
+    with lib.Context(levels=lv, slots=2, batch=2, profile_events=2) as c:
+        dL, dR = c.to_device(L), c.to_device(R)
+        outs = [c.alloc(3 * W * H * 4) for _ in range(6)]
+        for k in range(6):                                       # calls of two fill up by themselves: a host that submits faster than the chip matches
+            c.enqueue_full(dL, dR, W, H, 3 * W, outs[k], k)
+        assert [d.tag for d in c.drain()] == list(range(6))
+        for k in range(6):
+            assert_bit_equal(c.to_host(outs[k], (3, H, W)), exp, f"burst, pair {k}")
+        names = cost_kernels(c, mid[0])
+        assert "k_cost_small" not in names, names               # 2 x 125 k pixels per launch, shared: the marching forms
+        for p in [dL, dR] + outs:
+            c.free(p)
+
+
 def test_queue_from_plain_c(lib, tmp_path):
     """ros/queue_example.c: the frame loop of a C host -- ugsm_enqueue_full_managed with three frames in flight, every result equal to the
     blocking ugsm_match_full of the same frame -- compiled with gcc against include/ugsm.h and the built library, run here."""

@@ -29,6 +29,7 @@ UGSM_ERR_NOMEM = 6
 UGSM_ERR_STATE = 7
 UGSM_PENDING = 8   # not an error: not finished yet (ugsm_poll, ugsm_next_done with block = 0)
 UGSM_EMPTY = 9     # not an error: nothing outstanding (ugsm_next_done)
+UGSM_ERR_PEER = 10  # the fovea shard: another rank failed its part of the step, or none answered within the deadline
 UGSM_SHARD_ID_BYTES = 128
 UGSM_MAX_LEVELS = 32
 
@@ -47,7 +48,7 @@ EXPORTS = [
     "ugsm_poll", "ugsm_enqueue_full", "ugsm_enqueue_foveated", "ugsm_enqueue_full_host", "ugsm_enqueue_foveated_host", "ugsm_enqueue_full_managed",
     "ugsm_enqueue_foveated_managed", "ugsm_flush", "ugsm_next_done", "ugsm_queue_depth", "ugsm_queue_plan",
     # ... and RCCL inside the library
-    "ugsm_shard_unique_id", "ugsm_shard_init", "ugsm_shard_init_all", "ugsm_shard_rank", "ugsm_shard_count_ranks", "ugsm_submit_fovea_shard",
+    "ugsm_shard_unique_id", "ugsm_shard_init", "ugsm_shard_init_all", "ugsm_shard_rank", "ugsm_shard_count_ranks", "ugsm_submit_fovea_shard", "ugsm_shard_set_timeout",
     "ugsm_shard_gather", "ugsm_shard_finalize", "ugsm_context_device_bytes",
 ]
 # ... and what include/ugsm_dev.h adds (libugsm_dev.so only)
@@ -55,9 +56,10 @@ DEV_EXPORTS = ["ugsm_stage_poly_probe", "ugsm_stage_div3_probe", "ugsm_stage_div
 
 
 class UgsmError(RuntimeError):
-    def __init__(self, status: int, what: str):
+    def __init__(self, status: int, what: str, tag=None):
         super().__init__(f"ugsm status {status}: {what}")
         self.status = status
+        self.tag = tag   # next_done: the pair whose call failed (the completion HAS been consumed: the caller forgets the tag, then handles the error)
 
 
 class Config(C.Structure):
@@ -255,6 +257,7 @@ def load(dev: bool = False):
     lib.ugsm_shard_rank.argtypes = [vp, ip, ip]
     lib.ugsm_shard_count_ranks.argtypes = [vp, ip]
     lib.ugsm_submit_fovea_shard.argtypes = [vp, i, vp, vp, i, i, i, i, i, vp, i]
+    lib.ugsm_shard_set_timeout.argtypes = [vp, C.c_longlong]
     lib.ugsm_shard_gather.argtypes = [vp, i, vp, C.c_longlong, vp, i]
     lib.ugsm_shard_finalize.argtypes = [vp]
     if bool(lib.ugsm_is_dev_library()) != bool(dev):
@@ -487,14 +490,15 @@ class Context:
 
     def next_done(self, block: bool = True):
         """The oldest pair not yet reported as a Completion, or None (block=False: not finished yet, or nothing outstanding; block=True:
-        nothing outstanding).  A completion whose call failed raises."""
+        nothing outstanding).  A completion whose call failed raises UgsmError with `.tag` set: the pair has been reported -- the library will not
+        name it again -- so whoever keeps per-tag state drops it before handling the error."""
         c = Completion()
         st = self.lib.ugsm_next_done(self._h, C.byref(c), 1 if block else 0)
         if st in (UGSM_PENDING, UGSM_EMPTY):
             return None
         self.check(st)
         if c.status:
-            raise UgsmError(c.status, f"pair {c.tag}: {status_string(c.status)}: {self.lib.ugsm_last_error(self._h).decode()}")
+            raise UgsmError(c.status, f"pair {c.tag}: {status_string(c.status)}: {self.lib.ugsm_last_error(self._h).decode()}", tag=int(c.tag))
         return c
 
     def drain(self):
@@ -532,6 +536,14 @@ class Context:
 
     def submit_fovea_shard(self, slot: int, d_rgbL: int, d_rgbR: int, W: int, H: int, stride: int, off, d_stack: int, src_rank: int = 0):
         self.check(self.lib.ugsm_submit_fovea_shard(self._h, slot, d_rgbL, d_rgbR, W, H, stride, int(off[0]), int(off[1]), d_stack, src_rank))
+
+    def shard_set_timeout(self, milliseconds: int):
+        self.check(self.lib.ugsm_shard_set_timeout(self._h, int(milliseconds)))
+
+    def shard_init_all(self, others=()):
+        """One process, several GPUs: this context and `others` (each on its own device) become ranks 0 .. n-1 of one communicator."""
+        hs = (C.c_void_p * (1 + len(others)))(self._h, *[o._h for o in others])
+        self.check(self.lib.ugsm_shard_init_all(hs, 1 + len(others)))
 
     def shard_gather(self, slot: int, d_stack: int, stack_floats: int, d_all, dst_rank: int = 0):
         self.check(self.lib.ugsm_shard_gather(self._h, slot, d_stack, stack_floats, d_all, dst_rank))

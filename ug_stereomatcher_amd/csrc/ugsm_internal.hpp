@@ -20,6 +20,10 @@ struct CtxHooks {
     bool queue_busy = false;   // pairs are outstanding in the queue: the slots belong to it (slot-level entry points answer UGSM_ERR_STATE)
     bool queue_calling = false;  // ... except while the queue itself is calling them
     bool queue_more = false;     // (while queue_calling) other calls follow the one being sent: it shares the chip (call_alone)
+    // The shard's part in ugsm_wait / ugsm_poll (block = 0) on a slot that holds a shard step: called BEFORE the runtime waits for the slot.
+    // UGSM_OK: go on (wait / query the slot as usual); UGSM_PENDING: (poll) not finished; anything else is returned to the caller once the
+    // slot has drained -- a peer rank failed its part of the step, or the step's deadline passed and the communicator was aborted.
+    int (*shard_wait)(ugsm_ctx *, int slot, int block) = nullptr;
 };
 CtxHooks &ctx_hooks(ugsm_ctx *ctx);
 const ugsm_config &ctx_config(const ugsm_ctx *ctx);
@@ -29,6 +33,8 @@ int ctx_fail(ugsm_ctx *ctx, int status, const char *what);
 void ctx_host_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes);
 // hipPointerGetAttributes says page-locked host memory
 bool host_pinned(const void *p);
+// UGSM_DEV=1 is set: the process asked for the development switches (UGSM_* environment variables); nothing reads one without it
+bool dev_env();
 // the stagger of the queue's first round after idle and the size of every later call (ugsm.h, "the queue")
 int queue_target(int batch, int slots, long long calls_since_idle);
 

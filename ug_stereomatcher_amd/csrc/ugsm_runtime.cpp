@@ -100,6 +100,11 @@ struct Slot {
     float *hpin = nullptr;  // page-locked host staging for host-API outputs that land in pageable caller memory
     size_t hpin_cap = 0;
     hipEvent_t out_ev[12] = {};  // one per piece of the pageable copy-out (copy_out_planes)
+    // out of memory for the configured batch (prepare_slot): the capacity that failed, for which geometry, and the context's release
+    // count then -- the attempt is not repeated until something has been released or a call needs that much
+    int nomem_pairs = 0;
+    size_t nomem_tot = 0;
+    long long nomem_epoch = 0;
     bool have_pyr = false;
     bool have_coarse = false;
     bool range_known = false;
@@ -204,6 +209,7 @@ struct ugsm_ctx {
     CtxHooks hooks;  // the queue (ugsm_queue.cpp) and the RCCL shard (ugsm_shard.cpp): layers over the slot API
     long long dev_bytes = 0;    // device memory held by the slots' growable buffers (grow); ugsm_context_device_bytes
     std::unordered_map<const void *, size_t> dev_allocs;  // ... buffer by buffer, so that every release is accounted whatever path it takes
+    long long release_epoch = 0;  // counts the releases of tracked device buffers (untrack): "memory may have come free since"
     bool counted_live = false;  // this context counts in g_live_contexts (ugsm_create got as far as handing it out)
     long long mem_limit = 0;    // development (UGSM_MEM_LIMIT_MB under UGSM_DEV=1): grow refuses to go past it -- the UGSM_ERR_NOMEM path without exhausting a GPU
 };
@@ -315,6 +321,7 @@ void untrack(ugsm_ctx *ctx, const void *p)
     if (it == ctx->dev_allocs.end()) return;
     ctx->dev_bytes -= (long long)it->second;
     ctx->dev_allocs.erase(it);
+    ctx->release_epoch++;
 }
 
 template <class T>
@@ -431,6 +438,9 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
     // the configured batch cannot be had, size them for this call alone (they grow again when a larger call comes and memory allows)
     int st = UGSM_OK;
     for (int cap_pairs : {want_pairs, nb}) {
+        // (the configured batch did not fit last time, nothing has been released since and this call does not need it: straight to the call's
+        // own size -- no hipFree / failing hipMalloc / hipFree / hipMalloc of gigabytes, each a device-wide synchronisation, per call)
+        if (cap_pairs > nb && s.nomem_pairs > 0 && cap_pairs >= s.nomem_pairs && s.nomem_tot == tot && s.nomem_epoch == ctx->release_epoch) continue;
         st = alloc_slot_buffers(ctx, s, cap_pairs, tot, lvl);
         if (st != UGSM_ERR_NOMEM) break;
         // out of memory: what the attempt (or an earlier, larger call) left in the slot goes back before anything else is tried, so that a
@@ -447,6 +457,9 @@ int prepare_slot(ugsm_ctx *ctx, Slot &s, int W, int H, int nb = 1)
         s.pyr_cap = 0;
         s.lvl_cap = 0;
         ctx->err = why;
+        s.nomem_pairs = cap_pairs;
+        s.nomem_tot = tot;
+        s.nomem_epoch = ctx->release_epoch;  // (after this attempt's own releases)
         if (cap_pairs == nb) break;
     }
     return st;
@@ -1486,6 +1499,7 @@ int copy_out_planes(ugsm_ctx *ctx, Slot &s, const float *d_src, size_t plane_flo
 namespace ugsm {
 void ctx_host_copy(ugsm_ctx *ctx, void *dst, const void *src, size_t bytes) { team_copy(ctx, dst, src, bytes); }
 bool host_pinned(const void *p) { return is_pinned(p); }
+bool dev_env() { return dev_env_on(); }
 }  // namespace ugsm
 
 // =========================================================================================
@@ -1521,6 +1535,7 @@ const char *ugsm_status_string(int st)
     case UGSM_ERR_STATE: return "call sequence error";
     case UGSM_PENDING: return "not finished yet";
     case UGSM_EMPTY: return "nothing outstanding";
+    case UGSM_ERR_PEER: return "a peer rank of the fovea shard failed or did not answer";
     default: return "unknown status";
     }
 }
@@ -1863,11 +1878,13 @@ int ugsm_wait(ugsm_ctx *ctx, int slot)
 {
     Slot *s;
     UCHK(get_slot(ctx, slot, &s, false));
+    // (a slot that holds a step of the fovea shard: the shard layer watches the step's deadline and reads the status word the exchange carried)
+    const int peer = ctx->hooks.shard_wait ? ctx->hooks.shard_wait(ctx, slot, 1) : UGSM_OK;
     if (s->done_recorded) HIPCHK(ctx, hipEventSynchronize(s->ev_done));  // (shared stream: this slot's pair, not the ones queued behind it)
     else HIPCHK(ctx, hipStreamSynchronize(s->st));
     s->busy = false;
     harvest(ctx, *s);
-    return UGSM_OK;
+    return peer;
 }
 
 int ugsm_poll(ugsm_ctx *ctx, int slot)
@@ -1877,9 +1894,10 @@ int ugsm_poll(ugsm_ctx *ctx, int slot)
     const hipError_t e = s->done_recorded ? hipEventQuery(s->ev_done) : hipStreamQuery(s->st);
     if (e == hipErrorNotReady) return UGSM_PENDING;
     HIPCHK(ctx, e);
+    const int peer = ctx->hooks.shard_wait ? ctx->hooks.shard_wait(ctx, slot, 0) : UGSM_OK;  // (the slot is idle: the hook only reads the step's status word)
     s->busy = false;
     harvest(ctx, *s);
-    return UGSM_OK;
+    return peer;
 }
 
 int ugsm_wait_all(ugsm_ctx *ctx)

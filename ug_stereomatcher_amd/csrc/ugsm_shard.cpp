@@ -3,8 +3,16 @@
 // Round 4 left the exchange to a Python caller (torch.distributed on torch's stream, ordered against the slot's stream by two events and
 // a wrapper object); a C++ host -- the node, BASELINE.json: "the ROS host stays C++ and calls HIP through a thin C-ABI layer" -- could not
 // run the shard at all.  Here the collective is one more operation in the slot's stream order:
-//     pyramids -> [src rank: coarse levels top .. F-1] -> ncclBroadcast(state, 3 x fovH x fovW floats) -> fine levels F-2 .. 0 of this rank's window
-// No event, no second stream, nothing waits on the host.  The reference has one centred fovea on one GPU (MatchGPULib.cpp:1173-1176,
+//     pyramids -> [src rank: coarse levels top .. F-1] -> ncclBroadcast(state, 3 x fovH x fovW floats + a status word) -> fine levels F-2 .. 0 of this rank's window
+// No event, no second stream, nothing waits on the host.
+//
+// FAILURE PROTOCOL (round 6): a collective is a promise to the other ranks, so every rank reaches the broadcast whatever
+// happened to it before -- a rank whose pyramids or coarse phase were refused (out of memory, a HIP error) still broadcasts / receives, and
+// the state it sends carries a STATUS WORD behind the 3 x fovH x fovW floats: 0, or the source's failure status.  Every rank copies the word
+// to the host on the same stream; ugsm_wait / ugsm_poll on the slot then answer UGSM_ERR_PEER where the source failed.  A rank that does
+// not reach the collective at all (a crashed process) is what ugsm_shard_set_timeout is for: a step that has not finished by its deadline
+// aborts the communicator (ncclCommAbort: the kernel stuck in the collective exits) and the wait answers UGSM_ERR_PEER; the shard is then
+// dead until ugsm_shard_finalize + ugsm_shard_init.  The reference has one centred fovea on one GPU (MatchGPULib.cpp:1173-1176,
 // seeded from level F-1, :1230-1240,1283-1293); the window offset and the exchange are this build's.
 //
 // RCCL is loaded with dlopen on first use: librccl.so.1 is 570 MB and only a sharding host needs it.  A copy the process has already loaded
@@ -14,6 +22,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+
+#include <time.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +44,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -57,7 +68,8 @@ Rccl *rccl()
                 break;
             }
         }
-        if (!r.handle && getenv("UGSM_RCCL_PATH")) {
+        // (development: another library with RCCL's entry points -- tests/fake_rccl.c; like every UGSM_* variable, read under UGSM_DEV=1 only)
+        if (!r.handle && dev_env() && getenv("UGSM_RCCL_PATH")) {
             if ((r.handle = dlopen(getenv("UGSM_RCCL_PATH"), RTLD_NOW | RTLD_LOCAL))) r.origin = getenv("UGSM_RCCL_PATH");
         }
         for (const char *n : names) {
@@ -78,6 +90,7 @@ Rccl *rccl()
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
@@ -94,13 +107,28 @@ Rccl *rccl()
     return r.handle ? &r : nullptr;
 }
 
+constexpr size_t kStatusWords = 4;  // floats behind the state: [0] = the source's status (bit pattern of an int), the rest padding
+
 struct Shard {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    std::vector<float *> state;       // per slot: level F-1's (dx, dy, conf) -- what is broadcast
-    std::vector<size_t> state_cap;    // floats
+    bool dead = false;                // the communicator was aborted (a step's deadline passed): finalize and init again
+    long long timeout_ms = 0;         // deadline of a step, from its submission (0 = none: ugsm_wait waits as long as it takes)
+    std::vector<float *> state;       // per slot: level F-1's (dx, dy, conf) + kStatusWords -- what is broadcast
+    std::vector<size_t> state_cap;    // floats (without the status words)
     float *count_buf = nullptr;       // two floats for ugsm_shard_count_ranks
+    int *host_word = nullptr;         // page-locked, one int per slot: the status word of the slot's last step, copied on the slot's stream
+    std::vector<char> pending;        // per slot: a step whose status word has not been looked at yet
+    std::vector<int> src;             // ... and its source rank
+    std::vector<long long> deadline;  // ... and its deadline (CLOCK_MONOTONIC ns; 0 = none)
 };
+
+long long mono_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
 
 int nccl_fail(ugsm_ctx *ctx, const char *what, ncclResult_t e)
 {
@@ -124,24 +152,52 @@ void shard_free(ugsm_ctx *ctx, void *p)
     for (float *b : s->state)
         if (b) (void)ugsm_dev_free(ctx, b);
     if (s->count_buf) (void)ugsm_dev_free(ctx, s->count_buf);
+    if (s->host_word) (void)ugsm_host_free(ctx, s->host_word);
     delete s;
 }
 
 Shard *shard_of(ugsm_ctx *ctx) { return static_cast<Shard *>(ctx_hooks(ctx).shard); }
 
+int shard_wait(ugsm_ctx *ctx, int slot, int block);
+
+// The context joins the communicator (on failure nothing is attached and `comm` stays the caller's to destroy).
 int attach(ugsm_ctx *ctx, ncclComm_t comm, int rank, int world)
 {
-    Shard *s = new (std::nothrow) Shard();
-    if (!s) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_shard_init: out of host memory");
-    s->comm = comm;
-    s->rank = rank;
-    s->world = world;
-    s->state.assign((size_t)ctx_config(ctx).slots, nullptr);
-    s->state_cap.assign((size_t)ctx_config(ctx).slots, 0);
+    return no_throw(ctx, "ugsm_shard_init: out of host memory", [&]() -> int {
+        const size_t slots = (size_t)ctx_config(ctx).slots;
+        Shard *s = new Shard();
+        s->rank = rank;
+        s->world = world;
+        s->state.assign(slots, nullptr);
+        s->state_cap.assign(slots, 0);
+        s->pending.assign(slots, 0);
+        s->src.assign(slots, 0);
+        s->deadline.assign(slots, 0);
+        void *p = nullptr;
+        const int st = ugsm_host_alloc(ctx, &p, (long long)(slots * sizeof(int)));
+        if (st != UGSM_OK) {
+            delete s;
+            return st;
+        }
+        s->host_word = static_cast<int *>(p);
+        memset(s->host_word, 0, slots * sizeof(int));
+        s->comm = comm;
+        CtxHooks &h = ctx_hooks(ctx);
+        h.shard = s;
+        h.shard_free = shard_free;
+        h.shard_wait = shard_wait;
+        return UGSM_OK;
+    });
+}
+
+void detach(ugsm_ctx *ctx)
+{
     CtxHooks &h = ctx_hooks(ctx);
-    h.shard = s;
-    h.shard_free = shard_free;
-    return UGSM_OK;
+    if (!h.shard) return;
+    shard_free(ctx, h.shard);
+    h.shard = nullptr;
+    h.shard_free = nullptr;
+    h.shard_wait = nullptr;
 }
 
 int need_shard(ugsm_ctx *ctx, Shard **out, Rccl **lib)
@@ -150,6 +206,8 @@ int need_shard(ugsm_ctx *ctx, Shard **out, Rccl **lib)
     *out = shard_of(ctx);
     *lib = rccl();
     if (!*out || !*lib) return ctx_fail(ctx, UGSM_ERR_STATE, "the context is not part of a shard (ugsm_shard_init first)");
+    if ((*out)->dead)
+        return ctx_fail(ctx, UGSM_ERR_STATE, "the shard's communicator was aborted when a step missed its deadline: ugsm_shard_finalize, then ugsm_shard_init again on every rank");
     if (hipSetDevice(ctx_config(ctx).device) != hipSuccess) return ctx_fail(ctx, UGSM_ERR_DEVICE, "hipSetDevice failed");
     return UGSM_OK;
 }
@@ -160,6 +218,43 @@ int slot_stream(ugsm_ctx *ctx, int slot, hipStream_t *st)
     const int r = ugsm_slot_stream(ctx, slot, &p);
     *st = static_cast<hipStream_t>(p);
     return r;
+}
+
+// ugsm_wait / ugsm_poll on a slot (CtxHooks::shard_wait).  block: wait for the slot's step, at most until its deadline -- a step that is
+// still running then has a rank that never reached the exchange: the communicator is aborted (the kernel stuck in the collective exits; the
+// runtime's own wait behind this hook then returns) and the shard is dead.  Then, the slot being idle, the status word of the step.
+int shard_wait(ugsm_ctx *ctx, int slot, int block)
+{
+    Shard *s = shard_of(ctx);
+    if (!s || slot < 0 || slot >= (int)s->pending.size() || !s->pending[(size_t)slot]) return UGSM_OK;
+    hipStream_t stream;
+    if (slot_stream(ctx, slot, &stream) != UGSM_OK) return UGSM_OK;
+    if (block && s->deadline[(size_t)slot] > 0 && !s->dead) {
+        while (hipStreamQuery(stream) == hipErrorNotReady) {
+            if (mono_ns() > s->deadline[(size_t)slot]) {
+                Rccl *r = rccl();
+                if (r && s->comm) (void)r->CommAbort(s->comm);
+                s->comm = nullptr;
+                s->dead = true;
+                std::fill(s->pending.begin(), s->pending.end(), 0);
+                char b[256];
+                snprintf(b, sizeof b, "the shard step on slot %d did not finish within %lld ms: a rank never reached the exchange; the communicator was aborted", slot,
+                         s->timeout_ms);
+                return ctx_fail(ctx, UGSM_ERR_PEER, b);
+            }
+            timespec ts = {0, 50000};
+            nanosleep(&ts, nullptr);
+        }
+        (void)hipGetLastError();
+    }
+    if (block && hipStreamSynchronize(stream) != hipSuccess) return UGSM_OK;  // (the runtime's own wait reports the HIP error)
+    s->pending[(size_t)slot] = 0;
+    const int word = s->host_word[slot];
+    if (word == UGSM_OK) return UGSM_OK;
+    char b[256];
+    snprintf(b, sizeof b, "rank %d, the source of the shard step on slot %d, failed its pyramids or coarse phase with status %d (%s): this rank's stack is not valid", s->src[(size_t)slot],
+             slot, word, ugsm_status_string(word));
+    return ctx_fail(ctx, UGSM_ERR_PEER, b);
 }
 
 }  // namespace
@@ -213,7 +308,12 @@ int ugsm_shard_init_all(ugsm_ctx *const *ctxs, int n)
     for (int i = 0; i < n; i++) {
         const int st = attach(ctxs[i], comm[i], i, n);
         if (st != UGSM_OK) {
-            for (int j = i; j < n; j++) (void)r->CommDestroy(comm[j]);
+            // all or nothing: the contexts attached so far leave again (their ranks go with them), the other ranks are destroyed
+            for (int j = 0; j < i; j++) detach(ctxs[j]);
+            for (int j = i; j < n; j++) {
+                (void)hipSetDevice(dev[j]);
+                (void)r->CommDestroy(comm[j]);
+            }
             return st;
         }
     }
@@ -256,6 +356,15 @@ int ugsm_shard_count_ranks(ugsm_ctx *ctx, int *ranks)
     return UGSM_OK;
 }
 
+int ugsm_shard_set_timeout(ugsm_ctx *ctx, long long milliseconds)
+{
+    if (!ctx || milliseconds < 0) return UGSM_ERR_BAD_ARG;
+    Shard *s = shard_of(ctx);
+    if (!s) return ctx_fail(ctx, UGSM_ERR_STATE, "the context is not part of a shard (ugsm_shard_init first)");
+    s->timeout_ms = milliseconds;
+    return UGSM_OK;
+}
+
 int ugsm_submit_fovea_shard(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, const uint8_t *d_rgbR, int W, int H, int stride, int off_x, int off_y,
                             float *d_stack, int src_rank)
 {
@@ -263,31 +372,53 @@ int ugsm_submit_fovea_shard(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, cons
     Rccl *r;
     int st = need_shard(ctx, &s, &r);
     if (st != UGSM_OK) return st;
+    // ---- what every rank refuses alike, before anything is enqueued anywhere (the ranks make the same calls with the same geometry) -------
     const ugsm_config &cfg = ctx_config(ctx);
-    if (slot < 0 || slot >= cfg.slots || !d_stack || src_rank < 0 || src_rank >= s->world) return ctx_fail(ctx, UGSM_ERR_BAD_ARG, "ugsm_submit_fovea_shard: bad slot, rank or buffer");
+    if (slot < 0 || slot >= cfg.slots || !d_rgbL || !d_rgbR || !d_stack || src_rank < 0 || src_rank >= s->world)
+        return ctx_fail(ctx, UGSM_ERR_BAD_ARG, "ugsm_submit_fovea_shard: bad slot, rank or buffer");
+    if (cfg.fovea_levels < 2) return ctx_fail(ctx, UGSM_ERR_BAD_ARG, "ugsm_submit_fovea_shard: the context has no fovea levels");
     int fw = 0, fh = 0;
     if ((st = ugsm_fovea_dims(W, H, cfg.levels, cfg.fovea_levels, &fw, &fh)) != UGSM_OK) return st;
-    if (cfg.fovea_levels < 2) return ctx_fail(ctx, UGSM_ERR_BAD_ARG, "ugsm_submit_fovea_shard: the context has no fovea levels");
+    if (stride < 3 * W) return ctx_fail(ctx, UGSM_ERR_SIZE_MISMATCH, "ugsm_submit_fovea_shard: stride < 3 * W");
+    if (ctx_hooks(ctx).queue_busy) return ctx_fail(ctx, UGSM_ERR_STATE, "ugsm_submit_fovea_shard: pairs enqueued with ugsm_enqueue_* are outstanding");
+    hipStream_t stream;
+    if ((st = slot_stream(ctx, slot, &stream)) != UGSM_OK) return st;
+    // ---- the one buffer this rank cannot meet the exchange without: allocated before anything is enqueued.  A rank that cannot have even
+    // this (3 MB) leaves its peers waiting: their ugsm_shard_set_timeout deadline is what ends that. -----------------------------------------
     const size_t n = 3 * (size_t)fw * fh;
     if (s->state_cap[(size_t)slot] < n) {
         // (a reallocation: the slot's earlier work may still read the old buffer)
-        if ((st = ugsm_wait(ctx, slot)) != UGSM_OK) return st;
+        if ((st = ugsm_wait(ctx, slot)) != UGSM_OK && st != UGSM_ERR_PEER) return st;
         if (s->state[(size_t)slot]) (void)ugsm_dev_free(ctx, s->state[(size_t)slot]);
         s->state[(size_t)slot] = nullptr;
         s->state_cap[(size_t)slot] = 0;
         void *p = nullptr;
-        if ((st = ugsm_dev_alloc(ctx, &p, (long long)(n * sizeof(float)))) != UGSM_OK) return st;
+        if ((st = ugsm_dev_alloc(ctx, &p, (long long)((n + kStatusWords) * sizeof(float)))) != UGSM_OK) return st;
         s->state[(size_t)slot] = static_cast<float *>(p);
         s->state_cap[(size_t)slot] = n;
     }
     float *state = s->state[(size_t)slot];
-    hipStream_t stream;
-    if ((st = slot_stream(ctx, slot, &stream)) != UGSM_OK) return st;
-    // Everything below goes onto the slot's stream, in this order.  The state buffer belongs to the slot: a later step's broadcast into
-    // it is ordered, by the stream, after the fine phase of the step before.
-    if ((st = ugsm_submit_pyramids(ctx, slot, d_rgbL, d_rgbR, W, H, stride)) != UGSM_OK) return st;
-    if (s->rank == src_rank && (st = ugsm_submit_fovea_coarse(ctx, slot, state)) != UGSM_OK) return st;
-    NCHK(ctx, r->Broadcast(state, state, n, ncclFloat, src_rank, s->comm, stream));
+    // ---- from here on this rank REACHES THE BROADCAST whatever happens to it.  Everything goes onto the slot's stream, in this order; the
+    // state buffer belongs to the slot: a later step's broadcast into it is ordered, by the stream, after the fine phase of the step before.
+    int mine = ugsm_submit_pyramids(ctx, slot, d_rgbL, d_rgbR, W, H, stride);
+    if (mine == UGSM_OK && s->rank == src_rank) mine = ugsm_submit_fovea_coarse(ctx, slot, state);
+    const std::string why = mine != UGSM_OK ? std::string(ugsm_last_error(ctx)) : std::string();
+    if (s->rank == src_rank) {  // the status word the state carries: what the source made of its part
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + n), mine, 1, stream) != hipSuccess) return ctx_fail(ctx, UGSM_ERR_DEVICE, "ugsm_submit_fovea_shard: status word");
+    }
+    NCHK(ctx, r->Broadcast(state, state, n + kStatusWords, ncclFloat, src_rank, s->comm, stream));
+    if (mine != UGSM_OK) {  // (this rank knows: its submit says so; the peers read the word)
+        s->pending[(size_t)slot] = 0;
+        ctx_fail(ctx, mine, why.c_str());
+        return mine;
+    }
+    if (hipMemcpyAsync(&s->host_word[slot], state + n, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
+        return ctx_fail(ctx, UGSM_ERR_DEVICE, "ugsm_submit_fovea_shard: copy of the status word");
+    s->pending[(size_t)slot] = 1;
+    s->src[(size_t)slot] = src_rank;
+    s->deadline[(size_t)slot] = s->timeout_ms > 0 ? mono_ns() + s->timeout_ms * 1000000LL : 0;
+    // (with a failed source the fine phase below works on a state nobody computed: wasted work on the failure path only, never reported
+    // as a result -- ugsm_wait answers UGSM_ERR_PEER)
     return ugsm_submit_fovea_fine(ctx, slot, state, off_x, off_y, d_stack);
 }
 
@@ -327,9 +458,7 @@ int ugsm_shard_finalize(ugsm_ctx *ctx)
     CtxHooks &h = ctx_hooks(ctx);
     if (!h.shard) return UGSM_OK;
     (void)ugsm_wait_all(ctx);
-    shard_free(ctx, h.shard);
-    h.shard = nullptr;
-    h.shard_free = nullptr;
+    detach(ctx);
     return UGSM_OK;
 }
 

@@ -179,8 +179,14 @@ class MatchGPULib:
 
     def nextDone(self, block: bool = True):
         """The oldest outstanding pair: (tag, result) with result as match / matchStack / matchStackPyramid return it (copies owned by the
-        caller), or None if there is none (block=False: or it has not finished)."""
-        c = self._ctx.next_done(block)
+        caller), or None if there is none (block=False: or it has not finished).  A pair whose call failed raises UgsmError (`.tag` names it);
+        it no longer counts as outstanding."""
+        try:
+            c = self._ctx.next_done(block)
+        except UgsmError as e:
+            if e.tag is not None:
+                self._tags.pop(e.tag, None)
+            raise
         if c is None:
             return None
         kind, rows, cols, want_pyr = self._tags.pop(c.tag)

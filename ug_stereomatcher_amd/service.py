@@ -132,6 +132,7 @@ class GPUMatcher:
         self.frames_in_flight = max(1, int(frames_in_flight))
         self._pending = {}   # tag -> (imL header, imR header, image rows, image cols) of the frames in flight
         self._next_tag = 0
+        self.failed_frames = 0   # frames whose library call failed (pipelined topic path): dropped, the node lives on
         self.cmd_argc, self.cmd_argv = argc, argv
         self.params = params if params is not None else {}
         self.published = {}
@@ -212,7 +213,8 @@ class GPUMatcher:
                 mgpu.enqueueMatch(L, R, tag)
             self.spinOnce()
             while mgpu.outstanding() >= self.frames_in_flight:
-                self._publish_next(True)
+                if not self._publish_next(True):
+                    break   # (nothing more will come out: never spin on a queue that answers "empty")
             return
         if self.foveated == 1:
             mgpu.initStack(L, R)  # :166
@@ -236,7 +238,15 @@ class GPUMatcher:
     # ---- the pipelined topic path (frames_in_flight > 1) ----------------------------------------------------------------------
     def _publish_next(self, block: bool) -> bool:
         mgpu = self._matcher()
-        got = mgpu.nextDone(block)
+        try:
+            got = mgpu.nextDone(block)
+        except UgsmError as e:
+            # the frame's call failed (reference: exit(); here the frame is dropped and the node lives on): it has been reported, forget it
+            if e.tag is None:
+                raise
+            self._pending.pop(e.tag, None)
+            self.failed_frames += 1
+            return True
         if got is None:
             return False
         tag, res = got
