@@ -190,6 +190,28 @@ def test_ros_node_source_compiles_against_declaration_stubs():
     assert r.returncode == 0, r.stderr
 
 
+def test_the_reference_node_compiles_unchanged_against_the_shim(tmp_path):
+    """VERDICT r05 #6 -- INTEGRATION.md's claim that the reference's call sites compile unchanged, checked against the reference's OWN node:
+    /root/reference/src/gpu_matcher/UG_GPU_matcher.cpp is fed to g++ -fsyntax-only ON STDIN (nothing is copied; the build container only:
+    skipped where /root/reference does not exist) with an include directory whose MatchGPULib.h is one line -- #include
+    "MatchGPULib_ugsm.hpp" -- against the declaration stubs of tests/ros_stubs/.  Every use the node makes of the class (ctor(argc, argv),
+    setFoveated, initStack, match, matchStack, matchStackPyramid, getFoveaWidth / Height / Level with cv_bridge::CvImagePtr arguments and
+    float** / float*** results it free()s; UG_GPU_matcher.cpp:160-181, 423, 530-535, 645) is accepted without -fpermissive."""
+    import shutil
+    import subprocess
+    import pytest
+    ref = "/root/reference/src/gpu_matcher/UG_GPU_matcher.cpp"
+    gxx = shutil.which("g++")
+    if not gxx or not os.path.exists(ref):
+        pytest.skip("no g++ or no /root/reference (the GPU box)")
+    (tmp_path / "MatchGPULib.h").write_text('#include "MatchGPULib_ugsm.hpp"\n')
+    with open(ref, "rb") as f:
+        r = subprocess.run([gxx, "-std=c++14", "-fsyntax-only", "-x", "c++", f"-I{tmp_path}", "-Iros", "-Iinclude", "-Itests/ros_stubs", "-"], stdin=f, cwd=ROOT,
+                           capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "error" not in r.stderr, r.stderr[-4000:]
+
+
 def test_torch_hip_runtime_is_shared_only_when_the_abi_matches(lib, tmp_path, monkeypatch):
     """the package preloads PyTorch's bundled libamdhip64 (so that `import torch` after it still sees the GPU) only if that
     file's SONAME is the one libugsm.so was linked against; a mismatch -- mocked here by offering another library, and a file that is no

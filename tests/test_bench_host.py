@@ -66,3 +66,18 @@ def test_the_further_region_of_a_short_run_always_has_a_middle():
                 n = max(steps, 48 * B, 12 * slots * B)
                 win = bench.steady_window(_plan(n, slots, B), slots)
                 assert win is not None and win[1] - win[0] >= 8 * B, (slots, B, steps, win)
+
+
+def test_the_line_compares_like_with_like_and_carries_the_other_configs():
+    """VERDICT r05 #2, pinned on the source (the line itself needs a GPU; tests/test_gpu_queue.py::test_bench_line_keys runs it): `vs_baseline` is the
+    blocking host-memory call over the reference's figure -- the reference's own bracket -- never the device-resident throughput; both ratios
+    and their brackets are named under baseline_comparison; fovea16mp and 1080p ride along under other_workloads."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"vs_baseline": None,' in src and 'result["vs_baseline"] = (same / ref) if same else None' in src
+    assert 'same = result.get("pcie_inclusive", {}).get("pageable_pairs_per_s")' in src
+    assert "value / REFERENCE_PAIRS_PER_S" not in src
+    for key in ('"baseline_comparison"', '"same_bracket"', '"throughput"', '"vs_baseline_is": "same_bracket"', '"other_workloads"', '"blocking_call_ms"',
+                '"vs_reference_same_bracket"', '"on_the_timed_context"'):
+        assert key in src, key
+    assert 'for name in ("fovea16mp", "1080p"):' in src
+    assert bench.REFERENCE_PAIRS_PER_S == {"full16mp": 0.1, "fovea16mp": 1.0 / 3.0} and bench.DEFAULT_BATCH["1080p"] == 16

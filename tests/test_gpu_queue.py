@@ -439,6 +439,39 @@ def test_kernel_choices_follow_what_is_in_flight(lib, orc):
             c.free(p)
 
 
+def test_bench_line_keys(lib):
+    """bench.py end to end on the GPU at a reduced step count (the driver runs the real thing): ONE JSON line on stdout whose `vs_baseline` is the
+    same-bracket ratio, with `other_workloads` for BASELINE configs[3] and configs[1] (VERDICT r05 #2) and the lone-call figure on the timed
+    context within a few per cent of the one-slot context's (VERDICT r05 #1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("UGSM_DEV", None)     # the product as a user runs it
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--repeats", "0", "--profile-pairs", "1",
+                        "--single-pairs", "6", "--other-steps", "32"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "stereo pairs/sec at 16MP full-res pyramid" and d["unit"] == "pairs/s" and d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert d["calls_formed_by_the_library"] == [4, 5, 7, 4]
+    bc = d["baseline_comparison"]
+    assert bc["vs_baseline_is"] == "same_bracket" and d["vs_baseline"] == bc["same_bracket"]["ratio"]
+    assert abs(bc["same_bracket"]["pairs_per_s"] - d["pcie_inclusive"]["pageable_pairs_per_s"]) < 1e-9
+    assert 100 < d["vs_baseline"] < d["baseline_comparison"]["throughput"]["ratio"]           # host memory in and out costs: never the larger figure
+    for name, ref in (("fovea16mp", 1.0 / 3.0), ("1080p", None)):
+        o = d["other_workloads"][name]
+        assert "error" not in o, o
+        assert o["value"] > 100 and o["blocking_call_ms"] > 0 and o["steps"] == 32
+        assert (o["vs_reference_same_bracket"] is None) == (ref is None)
+    sp = d["single_pair_no_events"]
+    assert 0.9 < sp["on_the_timed_context"]["vs_one_slot_context"] < 1.1, sp      # (reported exactly in the line; 11.6 % apart before round 6)
+    assert "roofline" in d and d["roofline"]["kernel"] == "k_cost_march" and 0.1 < d["roofline"]["frac"] < 1.0
+
+
 def test_queue_from_plain_c(lib, tmp_path):
     """ros/queue_example.c: the frame loop of a C host -- ugsm_enqueue_full_managed with three frames in flight, every result equal to the
     blocking ugsm_match_full of the same frame -- compiled with gcc against include/ugsm.h and the built library, run here."""

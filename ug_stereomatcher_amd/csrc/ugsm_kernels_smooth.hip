@@ -393,7 +393,7 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
     const Batch &B = bt ? *bt : one;
     const int pairs = B.n > 1 ? B.n : 1;
     constexpr int LW = STX + 16 + smooth_pad(STX), LH = STY + 14;
-    constexpr size_t max_bytes = 3 * (size_t)LH * LW * sizeof(float);
+    constexpr size_t max_bytes = 3 * (size_t)LH * LW * sizeof(float) + 65536;  // (+ what smooth_lds_extra_bytes may ask for)
     // the attribute is per device: a process may hold contexts on several devices (the launch is made with the context's
     // device current); std::atomic so that contexts driven from different host threads do not race on the mask
     static std::atomic<unsigned long long> attr_mask{0};
@@ -406,7 +406,7 @@ static void launch_smooth_t(hipStream_t st, const float *s3, float *o3, int W, i
         attr_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     if (sty < 1 || sty > STY) sty = STY;
-    const size_t bytes = 3 * (size_t)(sty + 14) * LW * sizeof(float);
+    const size_t bytes = 3 * (size_t)(sty + 14) * LW * sizeof(float) + (size_t)std::min(std::max(smooth_lds_extra_bytes, 0), 65536);
     const int tiles_x = (W + STX - 1) / STX, n_tiles = tiles_x * ((H + sty - 1) / sty);
     if (sty == STY) UGSM_LAUNCH((k_smooth_fused<STX, STY, NT, true>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
     else UGSM_LAUNCH((k_smooth_fused<STX, STY, NT, false>), dim3(n_tiles, pairs), dim3(NT), bytes, st, s3, o3, W, H, passes, do_box, tiles_x, n_tiles, sty, B);
@@ -447,6 +447,9 @@ int smooth_tile_rows(int W, int H, int latency, int pairs)
 // 615 x 407 level (16 MP's level 6, the fovea windows) is 130 tiles of 64 x 32 on 256 CUs, 520 of 32 x 16 -- one pair alone +0.5 %, the
 // foveated stack with four slots +1.5 % (tools/ab.py; 2^19: -0.2 %, 2^16: -0.4 %)
 int smooth_mid_min_pixels = 1 << 18;
+// (development: UGSM_SMOOTH_LDS_EXTRA -- LDS bytes a launch asks for beyond its tile's, i.e. fewer workgroups per CU: 10 000 puts the
+// 112 x 36 tile at one workgroup per CU instead of two; the placement experiment of DESIGN.md section 4.3)
+int smooth_lds_extra_bytes = 0;
 
 void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int tile_rows, const Batch *bt, int tile_class)
 {

@@ -133,6 +133,7 @@ void launch_smooth_fused(hipStream_t st, const float *s3, float *o3, int W, int 
                          int tile_class = 0);
 int smooth_tile_rows(int W, int H, int whole_rounds, int pairs = 1);
 extern int smooth_mid_min_pixels;  // (development: UGSM_SMOOTH_MID_MIN)
+extern int smooth_lds_extra_bytes; // (development: UGSM_SMOOTH_LDS_EXTRA)
 // `passes` (<= 5) Jacobi passes (+ box) for the coarse levels (ugsm_kernels_small.hip): one thread per pixel of an 18 x (rh - 14) tile + halo 7 (rh = 18, 24 or 32)
 void launch_smooth_small(hipStream_t st, const float *s3, float *o3, int W, int H, int passes, int do_box, int rh, const Batch *bt = nullptr);
 

@@ -575,12 +575,14 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     if (const char *e = getenv("UGSM_BATCH_MAX_PIXELS")) k.batch_max_px = atoll(e);
     if (set_globals) {  // the process-wide tuning variables: back to their defaults first, so that a variable a test has removed stops acting
         smooth_mid_min_pixels = 1 << 18;
+        smooth_lds_extra_bytes = 0;
         blur_decimate_streaming = 1;
         pyr_base_streaming = 1;
         blur_decimate_streaming_min = 0;
         march_age_permille[0] = 470;
         march_age_permille[1] = 340;
         geti("UGSM_SMOOTH_MID_MIN", smooth_mid_min_pixels);
+        geti("UGSM_SMOOTH_LDS_EXTRA", smooth_lds_extra_bytes);
         geti("UGSM_PYR_STREAM", blur_decimate_streaming);
         geti("UGSM_PYR_BASE_STREAM", pyr_base_streaming);
         if (const char *e = getenv("UGSM_PYR_STREAM_MIN")) blur_decimate_streaming_min = atoll(e);
