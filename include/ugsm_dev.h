@@ -1,10 +1,9 @@
 /*
  * ugsm_dev.h -- entry points of libugsm_dev.so that libugsm.so does not have.
  *
- * libugsm_dev.so is the same sources built with -DUGSM_DEV_LIB (ug_stereomatcher_amd/csrc/Makefile): everything include/ugsm.h declares,
- * plus what only the tests and the measurement tools need -- kernel_path 1 (one kernel per reference stage: the A/B reference of the
- * fused kernels), ugsm_config.march_smooth (k_smooth_march), the UGSM_ITER_SMALL development switch (k_iter_small), and the probes
- * below.  A maintainer links libugsm.so.
+ * libugsm_dev.so is the product's sources plus ug_stereomatcher_amd/csrc/dev/ (csrc/Makefile): everything include/ugsm.h declares, plus what
+ * only the tests and the measurement tools need -- kernel_path 1 (one kernel per reference stage: the A/B reference of the fused kernels),
+ * ugsm_config.march_min_pixels < 0 (round 1's LDS-tiled K-cost), and the probes below.  A maintainer links libugsm.so.
  */
 #ifndef UGSM_DEV_H
 #define UGSM_DEV_H

@@ -19,7 +19,7 @@ for f in ("bench_default.json", "bench_under_rocprof.json"):
     shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 for f in ("kbench_age_16mp.txt", "kbench_graph.txt", "census_16mp.txt", "kbench_16mp.txt", "kbench_smooth_16mp.txt", "kbench_small.txt", "kbench_aux_16mp.txt", "kbench_strips.txt", "level_breakdown.txt", "valubench.txt", "ldsbench.txt", "service_latency.txt", "bench_slots1.json", "bench_1080p.json",
           "bench_fovea16mp.json", "ab_policies.txt", "ab_batch.txt", "bench_steps20.json", "bench_batch1.json", "kbench_smooth_pipe.txt", "rehearsal_2ranks.txt", "rccl_and_contexts.txt",
-          "kbench_march4.txt", "queue_probe.txt", "ab_queue.txt", "kbench_march_issue_raw.txt"):
+          "kbench_march4.txt", "queue_probe.txt", "ab_queue.txt", "kbench_march_issue_raw.txt", "ab_alone.txt", "kbench_two_streams.txt", "smooth_placement.txt"):
     if os.path.exists(f"{base}/{f}"):
         shutil.copy(f"{base}/{f}", f"{out}/{tag}_{f}")
 
@@ -82,7 +82,7 @@ def _largest(agg, prefix, counter):
     rows = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ugsm::", "")
-        if name.startswith(prefix) and r["Counter_Name"] == counter:
+        if (name.startswith(prefix) if "<" in prefix else name.split("<")[0] == prefix) and r["Counter_Name"] == counter:   # (k_cost_march is not k_cost_march4)
             rows[int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     g = max(rows)
     # (round 3: the marching K-cost launches 3 x 256 workgroups at every level that runs three waves per SIMD, so the largest grid no

@@ -21,7 +21,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ug_stereomatcher_amd", "csrc")
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-x", "hip", "-S",
+FLAGS = ["-O3", "-std=c++17", "-DUGSM_DEV_LIB", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-x", "hip", "-S",
          "--cuda-device-only"]
 
 # valubench kernel -> cost class
@@ -56,7 +56,7 @@ def source_hash():
     """sha256 (first 16 hex digits) over the kernel sources: bench.py reports valu_roofline as stale when the built sources differ"""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)):
+    for f in sorted(os.listdir(CSRC)):   # (the product's kernel sources: csrc/*.hip, *.hpp -- not csrc/dev/)
         if f.endswith((".hip", ".hpp")):
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
@@ -181,12 +181,12 @@ def main():
             "packed": "v_pk_*_f32"}
     for k, v in sorted(costs.items()):
         md.append(f"| {k} | {v:.2f} | {what.get(k, '')} |")
-    jobs = [("ugsm_kernels_march.hip", r"k_cost_marchILi1ELb0", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
-            ("ugsm_kernels_fused.hip", r"k_smooth_fusedILi112ELi36ELi512ELi0ELb1E", "k_smooth_fused", None),
-            ("ugsm_kernels_fused.hip", r"k_cost_splitILi0ELi4", "k_cost_split", None),
-            ("ugsm_kernels_march4.hip", r"k_cost_march4", "k_cost_march4", None)]
+    jobs = [("ugsm_kernels_march.hip", r"k_cost_marchE", "k_cost_march", {"valid_pixels_per_wave_step": 58, "steps_per_trip": 2}),
+            ("ugsm_kernels_smooth.hip", r"k_smooth_fusedILi112ELi36ELi512ELb1E", "k_smooth_fused", None),
+            ("dev/ugsm_dev_cost_tiled.hip", r"k_cost_splitE", "k_cost_split", None),
+            ("ugsm_kernels_march4.hip", r"k_cost_march4E", "k_cost_march4", None)]
     for src, name_re, short, geom in jobs:
-        asm = os.path.join(tmp, src.replace(".hip", ".s"))
+        asm = os.path.join(tmp, os.path.basename(src).replace(".hip", ".s"))
         if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(CSRC, src)):
             subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(CSRC, src), "-o", asm], stderr=subprocess.DEVNULL)
         lp = loops_of(asm, name_re, all_loops=geom is None)

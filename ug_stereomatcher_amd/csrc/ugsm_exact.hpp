@@ -1,4 +1,4 @@
-// ugsm_exact.hpp -- helpers shared by the production kernels (ugsm_kernels_fused.hip, ugsm_kernels_march.hip):
+// ugsm_exact.hpp -- helpers shared by the production kernels (ugsm_kernels_march*.hip, ugsm_kernels_small.hip, ugsm_kernels_smooth.hip):
 // uniform-base global accesses, the XCD-aware tile order, the exact arithmetic shortcuts
 // and the DPP lane-neighbour moves.
 #pragma once

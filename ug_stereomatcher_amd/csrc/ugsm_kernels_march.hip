@@ -31,7 +31,10 @@
 
 namespace ugsm {
 
-constexpr int NP = 1;  // pixels a lane holds (the per-lane values are kept as arrays of NP)
+// Pixels a lane holds.  The per-lane values stay arrays of NP: rewriting them as scalars -- the same operations -- makes the compiler schedule the
+// row step differently and the kernel 2.5-4 % slower (profiles/r06_kbench_march_scalar.txt).  This kernel's code generation follows the shape
+// of its source: tools/isa_dump.py tells whether an edit moved its instruction stream, tools/kbench mode 2 what that costs.
+constexpr int NP = 1;
 
 // value of the lane below / above (lane 0 / lane 63 read 0: those lanes hold strip halo whose results are dropped)
 __device__ __forceinline__ float shr1(float v)  // from lane - 1

@@ -606,6 +606,23 @@ void apply_dev_env(ugsm_config &cfg, DevKnobs &k, bool set_globals)
     if (rh == 18 || rh == 24 || rh == 32) k.small_rh_force = rh;
 }
 
+// The choices of a context that are not in ugsm_config: the development overrides (the defaults are with the policy functions below).
+void set_policy(ugsm_ctx *c, const DevKnobs &k)
+{
+    c->small_mask = k.small_mask;
+    c->fuse_seed = k.fuse_seed;
+    c->small_rh_force = k.small_rh_force;
+    c->smooth_rows = k.smooth_rows;
+    c->smooth_big_min = k.smooth_big_min > 0 ? k.smooth_big_min : 0;
+    // strips by age class, every context: +8 % on a level-0 launch alone on the chip, +1.2 % on a pair alone; with four pairs in
+    // flight it costs 0.4 % (163.2 against 163.7 pairs/s) -- kept on there too, so that a kernel measured alone is the kernel that ran
+    c->march_mode = k.march_mode <= 0 ? k.march_mode : 0;
+    c->march4_lo = k.march4_lo;
+    c->march4_hi = k.march4_hi;
+    c->force_alone = k.force_alone;
+    c->batch_max_px = k.batch_max_px;
+}
+
 // ---- stages ----------------------------------------------------------------------------
 
 // The pairs of one launch: b0 .. b0 + n - 1 of the batch in the slot (n = 1: an ordinary launch of pair b0).
@@ -708,21 +725,20 @@ int build_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *rgb, in
 }
 
 // ---- per-level kernel choices ---------------------------------------------------------------------------------------
-// ONE question decides between the two forms a choice may have: does the call have the chip to itself (Slot::alone, call_alone below)?
-// A call that is alone wants every launch SHORT -- nothing else fills the CUs a launch leaves idle; a call that shares the chip with
-// other calls wants every launch to do LITTLE REDUNDANT WORK -- what it wastes, the others could have used.  Five choices ask it
-// (small_max_px, small_rh, smooth_rows_for, the pyramid's streaming threshold in build_pyramids, the side stream); every other
-// threshold is one number, compared with what the LAUNCH holds: pairs x W x H (pairs = the batch where the level is batched, else 1).
-// Rounds 3-5 also switched between two whole threshold sets by ugsm_config.slots and the frame size ("latency" / "throughput" policy);
-// forced against each other over six frame sizes they differ by 0.35 % where bench.py measures (16 MP, calls of eight) and the
-// "throughput" set loses 2-7 % at 8 MP and 4 MP (profiles/r05_ab_policy_sizes.txt), while a lone 16 MP call on a four-slot context --
-// the node's service call -- lost 11.6 % to it: the second set is gone (profiles/r06_ab_alone.txt).
+// Which kernel runs a level is decided by the level's size -- compared with what the LAUNCH holds: pairs x W x H, pairs = the batch where
+// the level is batched, else 1 -- and by ONE question: does the call have the chip to itself (Slot::alone; call_alone below)?  A call alone
+// wants every launch SHORT: nothing else fills the CUs a launch leaves idle.  A call that shares the chip wants every launch to do LITTLE
+// REDUNDANT WORK: what it wastes, the others could have used.  Five choices ask the question (marked ALONE below, plus the pyramid's
+// streaming threshold in build_pyramids and the side stream); the rest is six numbers.  The A/B behind each: DESIGN.md section 4.
+// (Rounds 3-5 switched between two whole threshold sets by ugsm_config.slots and the frame size; forced against each other they differ by
+// 0.35 % where bench.py measures, and a lone 16 MP call on a four-slot context lost 11.6 % to the wrong one: VERDICT r05 #1.)
+constexpr long long kBatchMaxPixels = 9000000;  // levels up to here go through a batched call as ONE launch for all its pairs (level 0 of a 16 MP pair: pair by pair)
+constexpr int kSmallMaxPixelsAlone = 150000;    // the coarse levels' latency kernels (ugsm_kernels_small.hip) up to here for a call alone ...
+constexpr int kSmallMaxPixelsShared = 50000;    // ... and up to here on a shared chip (above it k_cost_march4 and the tiled K-smooth redo less)
+constexpr int kMarch4MaxPixels = 3000000;       // above them k_cost_march4 (four waves per strip: wins while a launch lasts as long as one strip) up to here
+constexpr int kMarchMinPixels = 400000;         // k_cost_march from here -- asked after k_cost_march4, so in effect above its range
+constexpr int kSmoothBigMinPixels = 1 << 19;    // k_smooth_fused's 112-column tile from here (1.39 x the tile in halo work, against 1.8 x for 64 x 32)
 
-// Levels of at most this many pixels go through a batched call as ONE launch for all its pairs; larger levels are launched pair by
-// pair (one after the other on the slot's stream).  Four slots x four 16 MP pairs, tools/ab.py, same box: 9 Mpx (levels 1-13 batched)
-// +1.9 % against 2.2 Mpx (levels 3-13), 4.5 Mpx +1.2 %, everything +1.5 %; 0.6 Mpx -1 %, 0.15 Mpx -2.8 %.  Level 0 stays per pair: its
-// marching K-cost keeps the strips by age class, which count on one pair's strips filling the chip exactly.
-constexpr long long kBatchMaxPixels = 9000000;
 bool batch_level(const ugsm_ctx *ctx, int W, int H)
 {
     const long long thr = ctx->batch_max_px > 0 ? ctx->batch_max_px : (ctx->batch_max_px < 0 ? 0 : kBatchMaxPixels);
@@ -731,102 +747,56 @@ bool batch_level(const ugsm_ctx *ctx, int W, int H)
 // pairs a launch of a W x H level of the call in `s` holds
 int launch_pairs(const ugsm_ctx *ctx, const Slot &s, int W, int H) { return (s.nb > 1 && batch_level(ctx, W, H)) ? s.nb : 1; }
 
-// Levels of at most this many pixels run the coarse-level latency kernels (ugsm_kernels_small.hip; 0 = none): 0.15 Mpx for a call
-// alone -- above it the other kernels are as fast or faster (tools/kbench modes 7, 14) -- and 50 k pixels when the chip is shared: there
-// the levels of 50-150 k pixels are better off with k_cost_march4 and the tiled K-smooth, which redo less (four slots: the foveated
-// stack +4.5 %, 4 MP frames +2.0 %, 1080p +10-18 %; one pair alone -1.4 %; tools/ab.py).
-constexpr int kSmallMaxPixelsAlone = 150000, kSmallMaxPixelsShared = 50000;
 int small_max_px(const ugsm_config &cfg, bool alone)
 {
     if (cfg.small_max_pixels < 0) return 0;
     return cfg.small_max_pixels > 0 ? cfg.small_max_pixels : (alone ? kSmallMaxPixelsAlone : kSmallMaxPixelsShared);
 }
-
-// K-cost as the channel-parallel marching kernel (ugsm_kernels_march4.hip): a workgroup of four waves per strip, a third of the
-// instructions per row step on any one wave.  It wins where a launch lasts as long as one strip -- levels too small to give every SIMD
-// two or three waves of k_cost_march: up to 3 Mpx (tools/kbench mode 14: 10.9 against 16.4 us at 0.25 Mpx, 24.3 / 29.8 at 1 Mpx,
-// 41.3 / 47.9 at 2 Mpx, 78 / 79 at 4 Mpx).
-constexpr int kMarch4MaxPixels = 3000000;
 bool use_march4(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
-    const ugsm_config &cfg = ctx->cfg;
     const long long px = (long long)W * H * pairs;
-    if (cfg.kernel_path == 1) return false;
-    if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;
-    return px > small_max_px(cfg, alone) && px <= kMarch4MaxPixels;
+    if (ctx->cfg.kernel_path == 1) return false;
+    if (ctx->march4_hi >= 0) return ctx->march4_hi > 0 && px >= ctx->march4_lo && px <= ctx->march4_hi;  // (development override)
+    return px > small_max_px(ctx->cfg, alone) && px <= kMarch4MaxPixels;
 }
-
-// K-cost as the marching kernel (ugsm_kernels_march.hip): a strip is one wave working down >= 6 rows; everything above k_cost_march4's
-// range (the launch path asks use_march4 first).  ugsm_config.march_min_pixels moves the threshold (tests run every level through it).
-constexpr int kMarchMinPixels = 400000;
-bool use_march(const ugsm_ctx *ctx, int W, int H, int pairs = 1)
+bool use_march(const ugsm_ctx *ctx, int W, int H, int pairs = 1)  // (ugsm_config.march_min_pixels moves the threshold: tests run every level through it)
 {
-    const ugsm_config &cfg = ctx->cfg;
-    if (cfg.march_min_pixels < 0) return false;
-    return (long long)W * H * pairs >= (cfg.march_min_pixels > 0 ? cfg.march_min_pixels : kMarchMinPixels);
+    const int thr = ctx->cfg.march_min_pixels;
+    return thr >= 0 && (long long)W * H * pairs >= (thr > 0 ? thr : kMarchMinPixels);
 }
-
 int march_rows_arg(const ugsm_ctx *ctx) { return ctx->cfg.march_rows > 0 ? ctx->cfg.march_rows : ctx->march_mode; }
 
-// The choices of a context that are not in ugsm_config: the development overrides (the defaults are in the functions around here).
-void set_policy(ugsm_ctx *c, const DevKnobs &k)
-{
-    c->small_mask = k.small_mask;
-    c->fuse_seed = k.fuse_seed;
-    c->small_rh_force = k.small_rh_force;
-    c->smooth_rows = k.smooth_rows;
-    c->smooth_big_min = k.smooth_big_min > 0 ? k.smooth_big_min : 0;
-    // strips by age class, every context: +8 % on a level-0 launch alone on the chip, +1.2 % on a pair alone; with four pairs in
-    // flight it costs 0.4 % (163.2 against 163.7 pairs/s) -- kept on there too, so that a kernel measured alone is the kernel that ran
-    c->march_mode = k.march_mode <= 0 ? k.march_mode : 0;
-    c->march4_lo = k.march4_lo;
-    c->march4_hi = k.march4_hi;
-    c->force_alone = k.force_alone;
-    c->batch_max_px = k.batch_max_px;
-}
-
-// K-cost / K-smooth in their latency forms (ugsm_kernels_small.hip): a level of at most small_max_px pixels has fewer tiles than the chip
-// has CUs, and a launch lasts as long as one tile's chain of phases.  Returns the K-smooth region height to use (0 = not a small level).
+// The latency kernels' K-smooth region height (0 = not a level of theirs).  On a shared chip 18 x 18 tiles (3.2 x the tile in halo work; the
+// 18 x 4 / 18 x 10 tiles redo 8 x / 4.6 x: free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight); a call ALONE
+// takes the smallest tile that still gives every workgroup a CU of its own, or nearly.
 int small_rh(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
-    const ugsm_config &cfg = ctx->cfg;
-    if (cfg.small_max_pixels < 0 || cfg.kernel_path == 1) return 0;
     const long long px = (long long)W * H * pairs;
-    if (px > small_max_px(cfg, alone) || use_march(ctx, W, H, pairs)) return 0;
+    if (ctx->cfg.small_max_pixels < 0 || ctx->cfg.kernel_path == 1 || px > small_max_px(ctx->cfg, alone) || use_march(ctx, W, H, pairs)) return 0;
     if (ctx->small_rh_force) return ctx->small_rh_force;
-    // K-smooth tile: 18 x 18 (3.2 x the tile in halo work) when other calls share the chip -- the 18 x 4 / 18 x 10 tiles redo 8 x / 4.6 x
-    // the work, free on an idle chip, 3.6 % / 9.2 % of the throughput with four pairs in flight (tools/ab.py).  A call alone has nothing
-    // to overlap with: the smallest tile that still gives every workgroup a CU of its own, or nearly.
-    if (!alone) return 32;
-    return px <= 36000 ? 18 : (px <= 80000 ? 24 : 32);
+    return !alone ? 32 : (px <= 36000 ? 18 : (px <= 80000 ? 24 : 32));
 }
 
-// Seeding a level (subsampleDisp, MatchGPULib.cpp:1526-1590) can ride on the level's first K-cost launch when that is a marching
-// kernel: the seeded field is then never written (launch_cost_march_seeded, launch_cost_march4).  Not with the early
-// exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
+// Seeding (subsampleDisp, MatchGPULib.cpp:1526-1590) rides on the level's first K-cost launch when that is a marching kernel: the seeded field is
+// never written.  Not with the early exit (the field before the first iteration is compared against), not on the one-stage-per-kernel path.
 bool fuse_seed(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
-    const ugsm_config &cfg = ctx->cfg;
-    return ctx->fuse_seed && cfg.kernel_path != 1 && !(cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, pairs) || use_march4(ctx, W, H, alone, pairs));
+    return ctx->fuse_seed && ctx->cfg.kernel_path != 1 && !(ctx->cfg.early_exit_threshold > 0.0f) && (use_march(ctx, W, H, pairs) || use_march4(ctx, W, H, alone, pairs));
 }
 
-// k_smooth_fused's tile on a W x H level: 0 = the tile class by the level's size (64 x 32 from 0.26 Mpx, else 32 x 16), > 0 = the
-// 112-column tile at this height (smooth_tile_rows, ugsm_kernels_smooth.hip), from 0.5 Mpx per launch: 1.39 x the tile in halo work
-// against 1.8 x for 64 x 32.  A call alone picks the height that fills whole rounds of workgroups.
+// k_smooth_fused's tile: > 0 = the 112-column tile at this height -- a call ALONE picks the height that fills whole rounds of workgroups
+// (smooth_tile_rows), else 36 --; 0 = the tile class by the level's size (64 x 32 from 0.26 Mpx, else 32 x 16)
 int smooth_rows_for(const ugsm_ctx *ctx, int W, int H, bool alone, int pairs = 1)
 {
-    const int big_min = ctx->smooth_big_min > 0 ? ctx->smooth_big_min : (1 << 19);
-    if ((long long)W * H * pairs < big_min) return 0;
+    if ((long long)W * H * pairs < (ctx->smooth_big_min > 0 ? ctx->smooth_big_min : kSmoothBigMinPixels)) return 0;
     if (pairs > 1 && W < 100) return 0;  // (a level narrower than the 112-column tile: the smaller tile classes waste fewer lanes)
     if (ctx->smooth_rows > 0) return std::min(ctx->smooth_rows, kSmoothTileRowsMax);
-    const int rounds_rule = ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (alone ? 1 : 0));
-    return smooth_tile_rows(W, H, rounds_rule, pairs);
+    return smooth_tile_rows(W, H, ctx->smooth_rows == -1 ? 1 : (ctx->smooth_rows == -2 ? 0 : (alone ? 1 : 0)), pairs);
 }
-// ... and the tile class of the smaller levels (launch_smooth_fused's tile_class): by what the launch holds
+// ... and the tile class of the smaller levels of a batched launch: by what the launch holds
 int smooth_class_for(int W, int H, int pairs)
 {
-    if (pairs <= 1) return 0;
-    return ((long long)W * H * pairs >= smooth_mid_min_pixels && W >= 48 && H >= 24) ? 2 : 1;
+    return pairs <= 1 ? 0 : (((long long)W * H * pairs >= smooth_mid_min_pixels && W >= 48 && H >= 24) ? 2 : 1);
 }
 
 // S Jacobi passes + the 3x3 box (MatchGPULib.cpp:2257-2412) for every pair of the call.  On return `a` holds the
