@@ -11,11 +11,11 @@ part=${2:-ACB}   # A: a 16 MP call alone; C: 16 MP calls in flight; B: 1080p and
 export UGSM_DEV=1
 ab() { python tools/ab.py "$@" | grep -v "^round" >> $out || exit 1; }
 if [[ $part == *A* ]]; then
-ab --pairs 32 --rounds 3 "one slot:SLOTS=1" "four slots, one call at a time:SLOTS=4;SERIAL=1" "four slots, one at a time, shared choices forced (rounds 3-5):SLOTS=4;SERIAL=1;UGSM_ALONE=0" "one slot, no side stream:SLOTS=1;UGSM_TWO_STREAMS=0" "one slot, side stream in the slot's own pool:SLOTS=1;UGSM_SIDE_PRIO=h"
+ab --pairs 32 --rounds 3 "one slot:SLOTS=1" "four slots, one call at a time:SLOTS=4;SERIAL=1" "four slots, one at a time, shared choices forced (rounds 3-5):SLOTS=4;SERIAL=1;UGSM_ALONE=0" "one slot, no side stream:SLOTS=1;UGSM_TWO_STREAMS=0" "one slot, side stream in another priority pool:SLOTS=1;UGSM_SIDE_PRIO=l" "four slots, one at a time, no side stream:SLOTS=4;SERIAL=1;UGSM_TWO_STREAMS=0"
 fi
 if [[ $part == *C* ]]; then
 ab --slots 4 --batch 8 --pairs 64 --rounds 2 "four slots, calls of 8 -- library's choice:" "every call taken to share the chip:UGSM_ALONE=0" "every call taken to be alone:UGSM_ALONE=1"
-ab --slots 4 --batch 1 --pairs 64 --rounds 2 "four slots, single-pair calls -- library's choice:" "every call taken to share the chip:UGSM_ALONE=0" "every call taken to be alone:UGSM_ALONE=1"
+ab --slots 4 --batch 1 --pairs 64 --rounds 2 "four slots, single-pair calls -- library's choice:" "every call taken to share the chip:UGSM_ALONE=0" "every call taken to be alone:UGSM_ALONE=1" "idle side streams in another priority pool:UGSM_SIDE_PRIO=l" "no side streams:UGSM_TWO_STREAMS=0"
 fi
 if [[ $part == *B* ]]; then
 ab --size 1920 1080 --pairs 128 --rounds 2 "1080p, one slot:SLOTS=1" "1080p, four slots, one call at a time:SLOTS=4;SERIAL=1" "1080p, four slots, one at a time, shared choices forced:SLOTS=4;SERIAL=1;UGSM_ALONE=0"

@@ -3,6 +3,7 @@
 
     python tools/isa_dump.py ug_stereomatcher_amd/libugsm.so out.json          # one record per device function
     python tools/isa_dump.py --diff before.json after.json                     # added / removed / changed symbols
+    python tools/isa_dump.py --table ug_stereomatcher_amd/libugsm.so           # instructions, registers, LDS, scratch, DPP and MFMA counts per kernel
 
 The gfx950 code objects are cut out of the library's .hip_fatbin section (one clang offload bundle per translation unit), disassembled
 with llvm-objdump, and every function's instructions -- addresses and encodings stripped, so that moving a kernel to another file or
@@ -113,6 +114,18 @@ if __name__ == "__main__":
         for s in ch:
             print(f"changed  {dm[s]}: {a[s]['n']} -> {b[s]['n']} instructions, vgpr {a[s].get('vgpr_count')} -> {b[s].get('vgpr_count')}")
         print(f"{len(set(a) & set(b)) - len(ch)} functions identical, {len(ch)} changed, {len(set(a) - set(b))} removed, {len(set(b) - set(a))} added")
+        sys.exit(0)
+    if sys.argv[1] == "--table":
+        rec = dump(sys.argv[2])
+        dm = demangle(sorted(rec))
+        print(f"# {os.path.basename(sys.argv[2])}: device functions of the gfx950 code objects (llvm-objdump / llvm-readelf --notes; static LDS only: dynamic LDS is the launcher's)")
+        print(f"{'kernel':44s} {'instr':>6s} {'VGPR':>5s} {'SGPR':>5s} {'LDS B':>6s} {'scratch':>7s} {'DPP':>5s} {'v_mfma':>6s}")
+        for s_ in sorted(rec, key=lambda k: -rec[k]["n"]):
+            r = rec[s_]
+            name = dm[s_].split("(")[0].replace("void ", "").replace("ugsm::", "")
+            print(f"{name:44s} {r['n']:6d} {r.get('vgpr_count', 0):5d} {r.get('sgpr_count', 0):5d} {r.get('group_segment_fixed_size', 0):6d} "
+                  f"{r.get('private_segment_fixed_size', 0):7d} {r['dpp']:5d} {r['mfma']:6d}")
+        print(f"{len(rec)} device functions, {sum(r['mfma'] for r in rec.values())} v_mfma")
         sys.exit(0)
     rec = dump(sys.argv[1])
     json.dump(rec, open(sys.argv[2], "w"), indent=0, sort_keys=True)

@@ -53,7 +53,7 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 timeout -k 10 100 ./tools/kbench 4928 3264 10 18 > $O/kbench_two_streams.txt 2>&1; step "kbench (two kernels on two streams)"
 { echo "# two gloo ranks on one MI355X (rehearsal of the N > 1 code path of the replicas: both ranks share the card, each with its own four-slot context and its own queue)"; echo "\$ UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0"; UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo MASTER_PORT=29611 timeout -k 10 200 python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0 2>/dev/null | cut -c1-600; echo "# the fovea shard on ONE rank: torch.distributed (nccl) for the barrier, the library's own RCCL communicator for the exchange (two ranks cannot share a GPU under RCCL: no two-rank rehearsal of this workload on a one-GPU box)"; echo "\$ UGSM_FORCE_DIST=1 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline"; UGSM_FORCE_DIST=1 MASTER_PORT=29612 timeout -k 10 200 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline 2>/dev/null | cut -c1-900; } > $O/rehearsal_2ranks.txt 2>&1; step "two-rank rehearsal over gloo + one-rank fovea shard over RCCL"
 timeout -k 10 300 python -m pytest tests/test_gpu_dist.py tests/test_gpu_batch.py::test_two_contexts_in_one_process_with_stream_priority_pools -m gpu -q -s 2>&1 | grep -v amdgpu.ids | tail -12 > $O/rccl_and_contexts.txt; step "one-rank RCCL shard test (ugsm_shard_*) + two contexts"
-bash tools/ab_alone.sh $O/ab_alone.txt > /dev/null 2>&1; step "same-box A/B: a call alone on one-slot and four-slot contexts; the shared choices forced; side-stream priorities"
+# (tools/ab_alone.sh -- a call alone on one-slot and four-slot contexts, the shared choices forced, side-stream pools -- takes 25 minutes: two gpurun calls of its own, parts A and CB)
 # (7 minutes; the instruction costs do not change with the kernels: only with VALUBENCH=1)
 if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valubench.txt 2>&1; step "valubench"; fi
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"

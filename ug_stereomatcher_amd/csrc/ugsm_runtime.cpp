@@ -72,6 +72,7 @@ struct Slot {
     // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
     // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
     hipStream_t st2 = nullptr;
+    int prio = 0;                  // HIP priority of `st` (the side stream is created in the same pool)
     bool owns_st = true;           // false: `st` is the stream of slot (index % streams): several slots queue their pairs on one stream
     hipEvent_t ev_done = nullptr;  // recorded at the end of every ugsm_submit_*: what ugsm_wait waits for when the stream is shared
     bool done_recorded = false;
@@ -1547,10 +1548,10 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     ctx->cfg = cfg;
     set_policy(ctx, knobs);
     if (dev_env_on() && getenv("UGSM_MEM_LIMIT_MB")) ctx->mem_limit = atoll(getenv("UGSM_MEM_LIMIT_MB")) << 20;
-    // The side stream pays when a pair is alone on the chip (116.7 against 114.0 pairs/s at 16 MP: the right pyramid and the A planes run
-    // beside the left pyramid and the coarse levels; profiles/r06_ab_alone.txt).  With four pairs in flight it LOSES 13 % (136 against
-    // 157 pairs/s): eight streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So every slot
-    // has one, and only a call that is alone on the chip uses it (side_stream_ok).
+    // The side stream pays when a pair is alone on the chip (115.6 against 113.9 pairs/s at 16 MP: the right pyramid and the A planes run
+    // beside the left pyramid and the coarse levels; profiles/r06_ab_alone.txt).  With four pairs in flight USING theirs it loses 13 % (136
+    // against 157 pairs/s): eight streams on the four hardware queues serialise kernels that one stream per pair lets overlap.  So every
+    // slot has one, and only a call that is alone on the chip uses it (side_stream_ok).
     ctx->two_streams = knobs.two_streams >= 0 ? knobs.two_streams : 1;
     ctx->slots.resize(cfg.slots);
     int prio_least = 0, prio_greatest = 0;
@@ -1578,15 +1579,24 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         const int prio = pc == 'h' ? prio_greatest : (pc == 'l' ? prio_least : 0);
         bool ok = (!s.owns_st || hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, prio) == hipSuccess) &&
                   hipMalloc((void **)&s.range_bad, 64) == hipSuccess && hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming) == hipSuccess;
-        // The side stream rides in the OTHER priority pool than the slot's own stream -- least priority beside a greatest-priority slot:
-        // HIP deals the streams of one priority level onto four hardware queues, and a side stream that lands on its own slot's queue
-        // runs strictly after it; across pools the queues are distinct (tools/queue_probe 'hhhhllll': eight queue groups).  The lower
-        // priority costs nothing (116.9 against 116.7 pairs/s; the default pool: -0.5 %; profiles/r06_ab_alone.txt).
-        const int side = knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : (pc == 'l' ? prio_greatest : prio_least)));
-        ok = ok && (!ctx->two_streams || hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, side) == hipSuccess);
+        s.prio = prio;
         for (hipEvent_t *e : {&s.ev_in, &s.ev_L, &s.ev_R}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < cfg.levels; i++) ok = ok && hipEventCreateWithFlags(&s.ev_A[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
+            ugsm_destroy(ctx);
+            return UGSM_ERR_DEVICE;
+        }
+    }
+    // The side streams, after every slot's own stream and in the slots' OWN priority pool.  Two measurements decide this (profiles/r06_ab_alone.txt):
+    // a side stream in ANOTHER pool is as good for the call that uses it (116.9 against 116.7 pairs/s) but its mere existence -- never used --
+    // costs a context with several calls in flight 28-38 % (16 MP single-pair calls 170 -> 123 pairs/s, 1080p calls of eight 1 256 -> 975): more
+    // hardware queues at a second priority level change how the command processor serves the first; in the slots' own pool idle side streams
+    // cost nothing (169.8).  Created for slot 1, 2, ..., 0 in that order: where HIP deals streams onto the pool's four queues in creation
+    // order, no side stream then lands on its own slot's queue (it would run strictly after it and overlap nothing).
+    for (int k = 0; k < cfg.slots && ctx->two_streams; k++) {
+        Slot &s = ctx->slots[(k + 1) % cfg.slots];
+        const int side = knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : s.prio));
+        if (hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, side) != hipSuccess) {
             ugsm_destroy(ctx);
             return UGSM_ERR_DEVICE;
         }
