@@ -1587,7 +1587,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
             return UGSM_ERR_DEVICE;
         }
     }
-    // The side streams, after every slot's own stream and in the slots' OWN priority pool.  Two measurements decide this (profiles/r06_ab_alone.txt):
+    // The side streams, after every slot's own stream and in the slots' OWN priority pool.  Two measurements decide this (profiles/r06_ab_side_streams.txt):
     // a side stream in ANOTHER pool is as good for the call that uses it (116.9 against 116.7 pairs/s) but its mere existence -- never used --
     // costs a context with several calls in flight 28-38 % (16 MP single-pair calls 170 -> 123 pairs/s, 1080p calls of eight 1 256 -> 975): more
     // hardware queues at a second priority level change how the command processor serves the first; in the slots' own pool idle side streams
