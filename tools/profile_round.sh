@@ -7,7 +7,10 @@
 export UGSM_DEV=1  # the UGSM_* kernel-choice overrides below are development switches (ugsm_runtime.cpp, apply_dev_env)
 set -u
 TAG=${1:-r06}
-PART=${2:-AB}   # A: the bench lines, the kernel trace, the counter passes; B: kbench, same-box A/Bs, breakdowns, rehearsals (two gpurun calls: each stays well inside the 20-minute limit)
+PART=${2:-ABC}   # A: the bench lines, the kernel trace, the counter passes; B: kbench, breakdowns, rehearsals, valubench (VALUBENCH=1); C: the same-box A/Bs of
+                 # the batch dimension (gpurun calls of <= 20 minutes: one part per call; tools/ab_alone.sh is two more).  Order for a round's final set: B, A,
+                 # then `python profiles/make_summaries.py gpurun_out/prof_rNN rNN` here, then `python bench.py` once more on the GPU (its valu_roofline then
+                 # prices the kernels as built: stale == false)
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -48,7 +51,6 @@ timeout -k 10 100 ./tools/kbench 4928 3264 20 9 > $O/kbench_aux_16mp.txt 2>&1; s
 { for sz in "54 36" "154 102" "436 289"; do timeout -k 10 60 ./tools/kbench $sz 20 13; done; } > $O/kbench_graph.txt 2>&1; step "kbench (eager launches against a HIP graph, coarse level)"
 { for sz in "436 289" "615 407" "870 576" "1231 815" "1741 1153" "2463 1631"; do echo "== $sz"; timeout -k 10 60 ./tools/kbench $sz 100 14 | grep -v "rows=[1-9]"; done; } > $O/kbench_march4.txt 2>&1; step "kbench (k_cost_march4 against k_cost_march / split / small)"
 { for sz in "3 1" "4 1" "8 1" "4 0" "4 1 hhhh" "8 1 hhhhllll"; do timeout -k 5 60 ./tools/queue_probe $sz; done; } > $O/queue_probe.txt 2>&1; step "queue probe"
-{ timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 4, levels <= 2.2 Mpx batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=2200000" "batches of 4, every level batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=20000000" "batches of 4, tiled pyramid kernel:BATCH=4;UGSM_PYR_STREAM=0" "two slots x 4:SLOTS=2;BATCH=4" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 8:SLOTS=2;BATCH=8" "batches of 8, the choices of a call alone:BATCH=8;UGSM_ALONE=1" "batches of 8, tiled pyramid kernel:BATCH=8;UGSM_PYR_STREAM=0" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --size 1920 1080 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 16:SLOTS=2;BATCH=16" | grep -v "^round"; timeout -k 10 200 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "tiled pyramid kernel:UGSM_PYR_STREAM=0" | grep -v "^round"; } > $O/ab_batch.txt 2>&1; step "same-box A/B: batch sizes, batch threshold, pyramid kernel"
 { timeout -k 10 100 python tools/level_breakdown.py; timeout -k 10 100 python tools/level_breakdown.py --batch 4 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --fovea 7; timeout -k 10 100 python tools/level_breakdown.py --fovea 7 --batch 8 --slots 4; timeout -k 10 100 python tools/level_breakdown.py --size 1920 1080 --batch 8 --slots 4; } 2>&1 | grep -v amdgpu.ids > $O/level_breakdown.txt; step "per-level breakdown: one pair, a batch of 4, the foveated stack alone and as a batch of 8, 1080p as a batch of 8"
 timeout -k 10 100 ./tools/kbench 4928 3264 10 18 > $O/kbench_two_streams.txt 2>&1; step "kbench (two kernels on two streams)"
 { echo "# two gloo ranks on one MI355X (rehearsal of the N > 1 code path of the replicas: both ranks share the card, each with its own four-slot context and its own queue)"; echo "\$ UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0"; UGSM_BENCH_DEVICE=0 UGSM_DIST_BACKEND=gloo MASTER_PORT=29611 timeout -k 10 200 python bench.py --gpus 2 --steps 24 --warmup 4 --workload full16mp --no-cpu-baseline --no-service --profile-pairs 0 --repeats 0 --single-pairs 0 2>/dev/null | cut -c1-600; echo "# the fovea shard on ONE rank: torch.distributed (nccl) for the barrier, the library's own RCCL communicator for the exchange (two ranks cannot share a GPU under RCCL: no two-rank rehearsal of this workload on a one-GPU box)"; echo "\$ UGSM_FORCE_DIST=1 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline"; UGSM_FORCE_DIST=1 MASTER_PORT=29612 timeout -k 10 200 python bench.py --workload fovea-shard --steps 48 --warmup 4 --no-cpu-baseline 2>/dev/null | cut -c1-900; } > $O/rehearsal_2ranks.txt 2>&1; step "two-rank rehearsal over gloo + one-rank fovea shard over RCCL"
@@ -59,5 +61,8 @@ if [ "${VALUBENCH:-0}" = 1 ]; then timeout -k 10 420 ./tools/valubench > $O/valu
 timeout -k 10 200 python tools/service_latency.py > $O/service_latency.txt 2>&1; step "service latency"
 # the default line once more when part A's counter passes have been condensed (profiles/make_summaries.py) into this round's VALU model: `valu_roofline` then prices the kernels as built
 if [ -f profiles/${TAG}_valu_model.json ]; then python bench.py > $O/bench_default.json 2> $O/bench_default.err; step "bench default (with ${TAG}_valu_model.json): $(cut -c1-160 $O/bench_default.json)"; fi
+fi
+if [[ $PART == *C* ]]; then
+{ timeout -k 10 400 python tools/ab.py --slots 4 --pairs 64 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 4, levels <= 2.2 Mpx batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=2200000" "batches of 4, every level batched:BATCH=4;UGSM_BATCH_MAX_PIXELS=20000000" "batches of 4, tiled pyramid kernel:BATCH=4;UGSM_PYR_STREAM=0" "two slots x 4:SLOTS=2;BATCH=4" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --fovea 7 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 2:BATCH=2" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 8:SLOTS=2;BATCH=8" "batches of 8, the choices of a call alone:BATCH=8;UGSM_ALONE=1" "batches of 8, tiled pyramid kernel:BATCH=8;UGSM_PYR_STREAM=0" | grep -v "^round"; timeout -k 10 300 python tools/ab.py --size 1920 1080 --slots 4 --pairs 256 --rounds 2 "single-pair calls:" "batches of 4:BATCH=4" "batches of 8:BATCH=8" "batches of 16:BATCH=16" "two slots x 16:SLOTS=2;BATCH=16" | grep -v "^round"; timeout -k 10 200 python tools/ab.py --slots 1 --pairs 30 --rounds 2 "default:" "no k_cost_march4:UGSM_MARCH4=0,0" "tiled pyramid kernel:UGSM_PYR_STREAM=0" | grep -v "^round"; } > $O/ab_batch.txt 2>&1; step "same-box A/B: batch sizes, batch threshold, pyramid kernel"
 fi
 ls $O
