@@ -238,6 +238,7 @@ int ugsm_submit_foveated_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_
                                     int W, int H, int stride, const int *off_x, const int *off_y, float *const *stackH,
                                     float *const *stackV, float *const *stackC);
 int ugsm_wait(ugsm_ctx *ctx, int slot);
+/* ugsm_wait on every slot, in order; every slot is waited for whatever the ones before it answered, the first failure is the one returned. */
 int ugsm_wait_all(ugsm_ctx *ctx);
 /* The HIP stream `slot` enqueues on (a hipStream_t, returned as a plain pointer): lets a host that owns other streams -- the
  * RCCL collective of the fovea shard -- order them after the slot's work ON THE DEVICE (record an event on this stream, make the

@@ -40,6 +40,8 @@ if args.child:
     args.slots = int(os.environ.get("SLOTS", args.slots))
     args.streams = int(os.environ.get("STREAMS", args.streams))
     serial = int(os.environ.get("SERIAL", args.serial))
+    cap = max(B, int(os.environ.get("CTXBATCH", 0)))   # CTXBATCH=n: the context holds n pairs per slot while the calls carry B
+    slot0 = os.environ.get("SLOT0") == "1"             # SLOT0=1 (with SERIAL=1): every call on slot 0
     class Buf:   # a device buffer with torch's data_ptr() face
         def __init__(self, p):
             self.p = p
@@ -49,7 +51,7 @@ if args.child:
     F = args.fovea
     fw, fh = _lib.fovea_dims(W, H, args.levels, F) if F else (W, H)
     host_pairs = [synth.make_pair(W, H, synth.BASE_SEED + j)[:2] for j in range(max(args.slots, 2))]
-    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams, batch=B) as c:
+    with _lib.Context(levels=args.levels, slots=args.slots, fovea_levels=F, streams=args.streams, batch=cap) as c:
         lib, h = c.lib, c.handle
         if no_torch:
             pairs = [(Buf(c.to_device(L)), Buf(c.to_device(R))) for L, R in host_pairs]
@@ -61,9 +63,9 @@ if args.child:
 
         def run(n):
             for i in range((n + B - 1) // B):          # n pairs, B per call
-                s = i % args.slots
+                s = 0 if (serial and slot0) else i % args.slots
                 if serial and i > 0:
-                    c.check(lib.ugsm_wait(h, (i - 1) % args.slots))   # the call before has finished: this one has the chip to itself
+                    c.check(lib.ugsm_wait(h, 0 if slot0 else (i - 1) % args.slots))   # the call before has finished: this one has the chip to itself
                 elif i >= args.slots:
                     c.check(lib.ugsm_wait(h, s))
                 if B > 1:

@@ -54,13 +54,18 @@ struct Call {
     int slot = 0, status = UGSM_OK;
     long long index = 0;
     std::vector<Item> items;
+    size_t reported = 0;  // pairs already moved to the done list (retire_front can be resumed after an allocation failure)
+};
+
+struct Done {
+    ugsm_completion c;
+    int managed;  // the managed buffer the completion lends, or -1
 };
 
 struct Queue {
     std::deque<Item> waiting;
     std::deque<Call> flight;             // in dispatch order; retired from the front
-    std::deque<ugsm_completion> done;    // retired, not yet fetched
-    std::vector<int> done_managed;       // (parallel to `done`: the managed buffer a completion lends, or -1)
+    std::deque<Done> done;               // retired, not yet fetched
     std::vector<Managed> pool;
     std::vector<int> lent;               // managed buffers the last ugsm_next_done lent to the host
     unsigned long long seq = 0, flush_upto = 0;
@@ -71,7 +76,7 @@ struct Queue {
     int outstanding() const
     {
         size_t n = waiting.size() + done.size();
-        for (const Call &c : flight) n += c.items.size();
+        for (const Call &c : flight) n += c.items.size() - c.reported;
         return (int)n;
     }
 };
@@ -115,7 +120,8 @@ void retire_front(ugsm_ctx *ctx, Queue *q)
 {
     Call &c = q->flight.front();
     const long long t = now_ns();
-    for (const Item &it : c.items) {
+    for (; c.reported < c.items.size(); c.reported++) {  // (push_back may throw: what has been reported is not reported again)
+        const Item &it = c.items[c.reported];
         ugsm_completion d{};
         d.tag = it.tag;
         d.status = c.status;
@@ -125,8 +131,7 @@ void retire_front(ugsm_ctx *ctx, Queue *q)
         d.done_ns = t;
         if (it.mem == MEM_MANAGED)
             for (int k = 0; k < 5; k++) d.result[k] = it.out[k];
-        q->done.push_back(d);
-        q->done_managed.push_back(it.managed);
+        q->done.push_back(Done{d, it.managed});
     }
     q->slot_busy[(size_t)c.slot] = 0;
     q->flight.pop_front();
@@ -175,10 +180,18 @@ int free_slot(const Queue *q)
 // other slots are doing at this instant (call_alone, ugsm_runtime.cpp).
 void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot, bool more)
 {
-    Call c;
+    // the call's place in the flight list first: everything that can run out of host memory happens before anything reaches the GPU,
+    // and a call that has reached the GPU is always on the list
+    q->flight.emplace_back();
+    Call &c = q->flight.back();
+    try {
+        c.items.assign(q->waiting.begin(), q->waiting.begin() + n);
+    } catch (...) {
+        q->flight.pop_back();
+        throw;  // (to the entry point's no_throw; the pairs still wait)
+    }
     c.slot = slot;
     c.index = q->calls++;
-    c.items.assign(q->waiting.begin(), q->waiting.begin() + n);
     q->waiting.erase(q->waiting.begin(), q->waiting.begin() + n);
     const Item &f = c.items[0];
     const uint8_t *L[UGSM_MAX_BATCH], *R[UGSM_MAX_BATCH];
@@ -222,7 +235,6 @@ void dispatch(ugsm_ctx *ctx, Queue *q, int n, int slot, bool more)
     q->slot_busy[(size_t)slot] = 1;
     q->next_slot = (slot + 1) % (int)q->slot_busy.size();
     q->calls_since_idle++;
-    q->flight.push_back(std::move(c));
 }
 
 // Forms and sends calls from the backlog.  may_block: a call that is full may wait for the slot of the oldest call in flight
@@ -303,11 +315,18 @@ int enqueue(ugsm_ctx *ctx, Item it)
         if (!q) return ctx_fail(ctx, UGSM_ERR_NOMEM, "ugsm_enqueue_*: out of host memory");
         const int r = room(ctx, q);
         if (r != UGSM_OK) return r;
-        it.seq = ++q->seq;
+        it.seq = q->seq + 1;
         q->waiting.push_back(it);
+        q->seq = it.seq;
         ctx_hooks(ctx).queue_busy = true;
-        pump(ctx, q, true);
-        return UGSM_OK;  // the pair is accepted; whatever happens to its call comes out of ugsm_next_done
+        // the pair is accepted; whatever happens to its call comes out of ugsm_next_done -- and a pump that ran out of host memory leaves
+        // the pairs waiting for the next entry point's pump: that is not a rejection either
+        (void)no_throw(ctx, "ugsm_enqueue_*: out of host memory", [&]() -> int {
+            pump(ctx, q, true);
+            return UGSM_OK;
+        });
+        update_busy(ctx, q);
+        return UGSM_OK;
     });
 }
 
@@ -403,7 +422,9 @@ int enqueue_managed(ugsm_ctx *ctx, int mode, const uint8_t *rgbL, const uint8_t 
     it.out[4] = (mode == M_FOVEA && want_pyr) ? m.out + 6 * plane : nullptr;
     it.tag = tag;
     it.managed = idx;
-    return enqueue(ctx, it);
+    const int st = enqueue(ctx, it);
+    if (st != UGSM_OK) q->pool[(size_t)idx].busy = false;  // (rejected: the staging buffer is free again)
+    return st;
 }
 
 int next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
@@ -435,11 +456,10 @@ int next_done(ugsm_ctx *ctx, ugsm_completion *out, int block)
         }
         wait_front(ctx, q);
     }
-    *out = q->done.front();
+    const int m = q->done.front().managed;
+    if (m >= 0) q->lent.push_back(m);  // (before the completion leaves the list: a push_back that throws loses nothing)
+    *out = q->done.front().c;
     q->done.pop_front();
-    const int m = q->done_managed.front();
-    q->done_managed.erase(q->done_managed.begin());
-    if (m >= 0) q->lent.push_back(m);
     // (pairs that waited for room may go out now; the slot-level entry points open up again once nothing is outstanding)
     pump(ctx, q, false);
     return UGSM_OK;

@@ -71,8 +71,17 @@ struct Slot {
     // (MatchGPULib.cpp:1866-1875, once per level), run there beside the left pyramid and the coarse levels' iterations -- launches
     // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
     // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
+    // WHICH stream that is (round 6): a call uses a side stream only when it has the chip to itself (`alone`), i.e. when every other slot
+    // is idle -- so with two or more streams in the context the side stream of a slot is the NEXT SLOT'S OWN STREAM, borrowed for the call:
+    // a context holds no stream that calls in flight leave idle, and a lone call's two streams sit on two hardware queues whatever way HIP
+    // deals streams onto queues.  A context with one stream gets one stream more (owns_st2).
     hipStream_t st2 = nullptr;
-    int prio = 0;                  // HIP priority of `st` (the side stream is created in the same pool)
+    bool owns_st2 = false;
+    // set where a call puts work on st2, cleared where a ugsm_submit_* returns success (every piece of that work has then been joined by
+    // the main stream).  Still set at ugsm_wait / ugsm_poll = the submit failed part-way: the side stream is waited for as well, so that a
+    // reported call never leaves work behind that reads the caller's images.
+    bool forked = false;
+    int prio = 0;                  // HIP priority of `st` (a side stream of the slot's own is created in the same pool)
     bool owns_st = true;           // false: `st` is the stream of slot (index % streams): several slots queue their pairs on one stream
     hipEvent_t ev_done = nullptr;  // recorded at the end of every ugsm_submit_*: what ugsm_wait waits for when the stream is shared
     bool done_recorded = false;
@@ -535,7 +544,7 @@ struct DevKnobs {
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int force_alone = -1;    // UGSM_ALONE=1 / 0: the kernel choices of a call that has the chip to itself / that shares it, whatever is in flight
     int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
-    char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l: priority of the side streams (default: the slot's own)
+    char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l|s: a side stream of its own for every slot, at that priority (s: the slot's); default: borrowed (ugsm_create)
     char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
     int march_mode = 0;      // UGSM_MARCH_MODE=0,-1,-2,-3: launch_cost_march's strip-height / age-class mode (default 0: latency heights, strips by age class)
     long long batch_max_px = 0;  // UGSM_BATCH_MAX_PIXELS: levels up to this many pixels are ONE launch for all pairs of a batched call (default kBatchMaxPixels; < 0: none)
@@ -993,6 +1002,7 @@ int enqueue_side_A(ugsm_ctx *ctx, Slot &s, int a_from)
     size_t tot = s.off[s.levels - 1] + 3 * (size_t)s.w[s.levels - 1] * s.h[s.levels - 1];
     UCHK(grow(ctx, s.Apyr, s.apyr_cap, tot));
     HIPCHK(ctx, hipEventRecord(s.ev_L, s.st));  // (the left pyramid is complete on the main stream)
+    s.forked = true;
     HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_L, 0));
     for (int i = s.levels - 1; i >= a_from; i--) {  // coarsest first: that is the order the levels need them in
         launch_sqblur_clamp(s.st2, level_view(s, s.pyrL, i, 0, 0), s.w[i], s.h[i], s.Apyr + s.off[i]);
@@ -1028,6 +1038,7 @@ int enqueue_pyramids(ugsm_ctx *ctx, Slot &s, int si, const uint8_t *const *d_rgb
     }
     // the side stream starts after everything enqueued on this slot so far (the previous pair still reads pyrR and Apyr)
     HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
+    s.forked = true;
     HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
     UCHK(build_pyramids(ctx, s, si, d_rgbR, stride, s.pyrR, s.st2, win));
     HIPCHK(ctx, hipEventRecord(s.ev_R, s.st2));
@@ -1330,6 +1341,7 @@ int get_slot(ugsm_ctx *ctx, int slot, Slot **out, bool enqueues = true)
 // this event, not for the pairs other slots have queued behind it on the same stream.
 int mark_done(ugsm_ctx *ctx, Slot &s)
 {
+    s.forked = false;  // (the call was enqueued whole: the main stream waits for everything it put on the side stream)
     if (ctx->streams >= (int)ctx->slots.size()) return UGSM_OK;
     HIPCHK(ctx, hipEventRecord(s.ev_done, s.st));
     s.done_recorded = true;
@@ -1351,6 +1363,7 @@ int stage_in(ugsm_ctx *ctx, Slot &s, const uint8_t *rgbL, const uint8_t *rgbR, i
     // left pyramid instead of in front of it.  The side stream first waits for what the slot did before.
     if (s.alone && s.st2 && ctx->cfg.kernel_path != 1 && ctx->cfg.profile_events == 0 && ctx->two_streams) {  // (single pairs: as side_stream_ok)
         HIPCHK(ctx, hipEventRecord(s.ev_in, s.st));
+        s.forked = true;
         HIPCHK(ctx, hipStreamWaitEvent(s.st2, s.ev_in, 0));
         HIPCHK(ctx, hipMemcpyAsync(s.rgbR, rgbR, bytes, hipMemcpyHostToDevice, s.st2));
     } else {
@@ -1587,19 +1600,33 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
             return UGSM_ERR_DEVICE;
         }
     }
-    // The side streams, after every slot's own stream and in the slots' OWN priority pool.  Two measurements decide this (profiles/r06_ab_side_streams.txt):
-    // a side stream in ANOTHER pool is as good for the call that uses it (116.9 against 116.7 pairs/s) but its mere existence -- never used --
-    // costs a context with several calls in flight 28-38 % (16 MP single-pair calls 170 -> 123 pairs/s, 1080p calls of eight 1 256 -> 975): more
-    // hardware queues at a second priority level change how the command processor serves the first; in the slots' own pool idle side streams
-    // cost nothing (169.8).  Created for slot 1, 2, ..., 0 in that order: where HIP deals streams onto the pool's four queues in creation
-    // order, no side stream then lands on its own slot's queue (it would run strictly after it and overlap nothing).
+    // The side streams.  A call forks onto one only when it is alone on the chip -- every other slot idle -- so a slot BORROWS the stream of
+    // the next slot: no stream is created that calls in flight would leave idle.  What decided this (profiles/r06_ab_side_streams.txt,
+    // r06_ab_lone_call.txt): side streams of the slots' own in ANOTHER priority pool cost a context with several calls in flight 28-38 %
+    // though never used; in the slots' own pool they cost such a context nothing, but eight streams on the pool's four hardware queues left
+    // a lone call on a four-slot context 2-3 % behind the same call on a one-slot context (one of a slot's two streams shares a queue with a
+    // neighbour's).  Borrowed, a lone call's two streams are two slots' streams: two hardware queues wherever the slots' streams have one each.
+    // One stream in the whole context (one slot, or ugsm_config.streams = 1): one more stream, created here, serves every slot.
+    // UGSM_SIDE_PRIO (development) asks for the streams of rounds 3-6a: one per slot, created for slot 1, 2, ..., 0, in the pool named.
     for (int k = 0; k < cfg.slots && ctx->two_streams; k++) {
-        Slot &s = ctx->slots[(k + 1) % cfg.slots];
+        if (!knobs.side_prio) {
+            Slot &s = ctx->slots[k];
+            if (ctx->streams >= 2) {
+                s.st2 = ctx->slots[(k % ctx->streams + 1) % ctx->streams].st;
+                continue;
+            }
+            if (k > 0) {
+                s.st2 = ctx->slots[0].st2;
+                continue;
+            }
+        }
+        Slot &s = ctx->slots[knobs.side_prio ? (k + 1) % cfg.slots : k];
         const int side = knobs.side_prio == 'h' ? prio_greatest : (knobs.side_prio == 'l' ? prio_least : (knobs.side_prio == 'n' ? 0 : s.prio));
         if (hipStreamCreateWithPriority(&s.st2, hipStreamNonBlocking, side) != hipSuccess) {
             ugsm_destroy(ctx);
             return UGSM_ERR_DEVICE;
         }
+        s.owns_st2 = true;
     }
     {
         std::lock_guard<std::mutex> lk(g_globals_mutex);
@@ -1644,7 +1671,7 @@ void ugsm_destroy(ugsm_ctx *ctx)
         if (s.Apyr) (void)hipFree(s.Apyr);
         if (s.lr) (void)hipFree(s.lr);
         if (s.lr_host) (void)hipHostFree(s.lr_host);
-        if (s.st2) (void)hipStreamDestroy(s.st2);
+        if (s.st2 && s.owns_st2) (void)hipStreamDestroy(s.st2);
         if (s.st && s.owns_st) (void)hipStreamDestroy(s.st);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
@@ -1864,6 +1891,8 @@ int ugsm_wait(ugsm_ctx *ctx, int slot)
     const int peer = ctx->hooks.shard_wait ? ctx->hooks.shard_wait(ctx, slot, 1) : UGSM_OK;
     if (s->done_recorded) HIPCHK(ctx, hipEventSynchronize(s->ev_done));  // (shared stream: this slot's pair, not the ones queued behind it)
     else HIPCHK(ctx, hipStreamSynchronize(s->st));
+    if (s->forked && s->st2) HIPCHK(ctx, hipStreamSynchronize(s->st2));  // (a submit that failed after its fork: Slot::forked)
+    s->forked = false;
     s->busy = false;
     harvest(ctx, *s);
     return peer;
@@ -1876,6 +1905,12 @@ int ugsm_poll(ugsm_ctx *ctx, int slot)
     const hipError_t e = s->done_recorded ? hipEventQuery(s->ev_done) : hipStreamQuery(s->st);
     if (e == hipErrorNotReady) return UGSM_PENDING;
     HIPCHK(ctx, e);
+    if (s->forked && s->st2) {  // (a submit that failed after its fork: Slot::forked)
+        const hipError_t e2 = hipStreamQuery(s->st2);
+        if (e2 == hipErrorNotReady) return UGSM_PENDING;
+        HIPCHK(ctx, e2);
+    }
+    s->forked = false;
     const int peer = ctx->hooks.shard_wait ? ctx->hooks.shard_wait(ctx, slot, 0) : UGSM_OK;  // (the slot is idle: the hook only reads the step's status word)
     s->busy = false;
     harvest(ctx, *s);
@@ -1885,8 +1920,19 @@ int ugsm_poll(ugsm_ctx *ctx, int slot)
 int ugsm_wait_all(ugsm_ctx *ctx)
 {
     if (!ctx) return UGSM_ERR_BAD_ARG;
-    for (int i = 0; i < (int)ctx->slots.size(); i++) UCHK(ugsm_wait(ctx, i));
-    return UGSM_OK;
+    // every slot is waited for whatever the ones before it answer (ugsm_shard_finalize frees the slots' exchange buffers behind this call); the
+    // first failure is the one reported
+    int first = UGSM_OK;
+    std::string why;
+    for (int i = 0; i < (int)ctx->slots.size(); i++) {
+        const int st = ugsm_wait(ctx, i);
+        if (st != UGSM_OK && first == UGSM_OK) {
+            first = st;
+            why = ctx->err;
+        }
+    }
+    if (first != UGSM_OK) ctx->err = why;
+    return first;
 }
 
 // The service call on a slot: upload, pyramids, match, results into caller memory.  `sync` = the reference's call (returns when the
@@ -1910,6 +1956,7 @@ static int match_full_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, cons
     float *const dst[3] = {dispH, dispV, dispC};
     if (sync) prefault_planes(ctx, dst, n);  // the GPU is busy for the next ~10 ms: touch the caller's result pages meanwhile
     UCHK(copy_out_planes(ctx, *s, s->hout, n, dst));
+    if (sync) s->forked = false;  // (enqueued whole, as mark_done)
     return sync ? ugsm_wait(ctx, slot) : mark_done(ctx, *s);
 }
 
@@ -1963,6 +2010,7 @@ static int match_foveated_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, 
     HIPCHK(ctx, hipMemcpyAsync(stackC, d_stack + 2 * stackn, stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrL) HIPCHK(ctx, hipMemcpyAsync(pyrL, d_pl, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
     if (pyrR) HIPCHK(ctx, hipMemcpyAsync(pyrR, d_pr, 3 * stackn * sizeof(float), hipMemcpyDeviceToHost, s->st));
+    if (sync) s->forked = false;  // (enqueued whole, as mark_done)
     return sync ? ugsm_wait(ctx, slot) : mark_done(ctx, *s);
 }
 

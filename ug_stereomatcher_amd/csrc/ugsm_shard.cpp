@@ -402,14 +402,19 @@ int ugsm_submit_fovea_shard(ugsm_ctx *ctx, int slot, const uint8_t *d_rgbL, cons
     // state buffer belongs to the slot: a later step's broadcast into it is ordered, by the stream, after the fine phase of the step before.
     int mine = ugsm_submit_pyramids(ctx, slot, d_rgbL, d_rgbR, W, H, stride);
     if (mine == UGSM_OK && s->rank == src_rank) mine = ugsm_submit_fovea_coarse(ctx, slot, state);
-    const std::string why = mine != UGSM_OK ? std::string(ugsm_last_error(ctx)) : std::string();
+    char why[512] = "";  // (the message of this rank's own failure, kept past the calls below; no allocation on this path)
+    if (mine != UGSM_OK) snprintf(why, sizeof why, "%s", ugsm_last_error(ctx));
     if (s->rank == src_rank) {  // the status word the state carries: what the source made of its part
-        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + n), mine, 1, stream) != hipSuccess) return ctx_fail(ctx, UGSM_ERR_DEVICE, "ugsm_submit_fovea_shard: status word");
+        // (a stream that refuses even this is broken and the broadcast below will say so too; the promise is kept regardless: no return here)
+        if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(state + n), mine, 1, stream) != hipSuccess && mine == UGSM_OK) {
+            mine = UGSM_ERR_DEVICE;
+            snprintf(why, sizeof why, "ugsm_submit_fovea_shard: the status word could not be written");
+        }
     }
     NCHK(ctx, r->Broadcast(state, state, n + kStatusWords, ncclFloat, src_rank, s->comm, stream));
     if (mine != UGSM_OK) {  // (this rank knows: its submit says so; the peers read the word)
         s->pending[(size_t)slot] = 0;
-        ctx_fail(ctx, mine, why.c_str());
+        ctx_fail(ctx, mine, why);
         return mine;
     }
     if (hipMemcpyAsync(&s->host_word[slot], state + n, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess)
