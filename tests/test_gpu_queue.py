@@ -439,6 +439,51 @@ def test_kernel_choices_follow_what_is_in_flight(lib, orc):
             c.free(p)
 
 
+def test_a_lone_call_borrows_the_next_slots_stream(lib, orc, monkeypatch):
+    """Round 6: a slot's side stream is the NEXT slot's own stream, borrowed by a call that has the chip to itself (ugsm_create).  What must
+    hold whatever the neighbour is doing: (a) lone calls in turn on every slot of a four-slot, a three-slot and a shared-stream context; (b) a
+    call submitted on the neighbour while the lone call is still in flight queues behind the borrowed work; (c) with UGSM_ALONE=1 EVERY call
+    forks, four in flight, each onto a stream that is busy with its neighbour's call -- stream order and the events keep all of it correct.
+    Results: the oracle's, bit for bit, full and foveated."""
+    from ug_stereomatcher_amd import synth
+    W, H, lv, F = 640, 480, 9, 4
+    L, R, _, _ = synth.make_pair(W, H, synth.BASE_SEED + 771)
+    exp = orc.match_full(L, R, lv)
+    expf = orc.match_foveated(L, R, lv, F)[0]
+    fw, fh = lib.fovea_dims(W, H, lv, F)
+
+    def burst(c, slots, wait_each):
+        dL, dR = c.to_device(L), c.to_device(R)
+        outs = [c.alloc(3 * W * H * 4) for _ in range(slots)]
+        stks = [c.alloc(3 * F * fw * fh * 4) for _ in range(slots)]
+        for rnd in range(2):
+            for k in range(slots):
+                c.check(c.lib.ugsm_submit_full(c.handle, k, dL, dR, W, H, 3 * W, outs[k]))
+                if wait_each:
+                    c.check(c.lib.ugsm_wait(c.handle, k))
+            c.check(c.lib.ugsm_wait_all(c.handle))
+            for k in range(slots):
+                assert_bit_equal(c.to_host(outs[k], (3, H, W)), exp, f"full, slot {k}, round {rnd}")
+            for k in range(slots):
+                c.check(c.lib.ugsm_submit_foveated(c.handle, k, dL, dR, W, H, 3 * W, 0, 0, stks[k], None, None))
+                if wait_each:
+                    c.check(c.lib.ugsm_wait(c.handle, k))
+            c.check(c.lib.ugsm_wait_all(c.handle))
+            for k in range(slots):
+                assert_bit_equal(c.to_host(stks[k], (3, F, fh, fw)), expf, f"foveated, slot {k}, round {rnd}")
+        for p in [dL, dR] + outs + stks:
+            c.free(p)
+
+    for kw in ({"slots": 4}, {"slots": 3}, {"slots": 4, "streams": 2}, {"slots": 2, "streams": 1}, {"slots": 1}):
+        with lib.Context(levels=lv, fovea_levels=F, **kw) as c:
+            burst(c, kw["slots"], wait_each=True)      # (a): every call alone, forking onto the next slot's (idle) stream
+            burst(c, kw["slots"], wait_each=False)     # (b): the first call of a round is alone and borrows; the others queue behind it
+    monkeypatch.setenv("UGSM_DEV", "1")
+    monkeypatch.setenv("UGSM_ALONE", "1")
+    with lib.Context(levels=lv, fovea_levels=F, slots=4) as c:
+        burst(c, 4, wait_each=False)                   # (c)
+
+
 def test_bench_line_keys(lib):
     """bench.py end to end on the GPU at a reduced step count (the driver runs the real thing): ONE JSON line on stdout whose `vs_baseline` is the
     same-bracket ratio, with `other_workloads` for BASELINE configs[3] and configs[1] and the lone-call figure on the timed

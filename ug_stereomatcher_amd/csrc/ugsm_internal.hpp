@@ -27,6 +27,9 @@ struct CtxHooks {
 };
 CtxHooks &ctx_hooks(ugsm_ctx *ctx);
 const ugsm_config &ctx_config(const ugsm_ctx *ctx);
+// the HIP stream of a slot (a hipStream_t), nullptr for a slot the context does not have; unlike ugsm_slot_stream it leaves the slot's
+// bookkeeping alone (the public call takes it that the host is about to enqueue work of its own there: the slot becomes busy)
+void *ctx_slot_stream(ugsm_ctx *ctx, int slot);
 // sets ugsm_last_error and returns `status`
 int ctx_fail(ugsm_ctx *ctx, int status, const char *what);
 // memcpy by the context's host team (large copies; falls back to the calling thread)

@@ -227,6 +227,7 @@ struct ugsm_ctx {
 namespace ugsm {
 CtxHooks &ctx_hooks(ugsm_ctx *ctx) { return ctx->hooks; }
 const ugsm_config &ctx_config(const ugsm_ctx *ctx) { return ctx->cfg; }
+void *ctx_slot_stream(ugsm_ctx *ctx, int slot) { return (ctx && slot >= 0 && slot < (int)ctx->slots.size()) ? (void *)ctx->slots[(size_t)slot].st : nullptr; }
 int ctx_fail(ugsm_ctx *ctx, int status, const char *what)
 {
     if (ctx && what) ctx->err = what;
@@ -2375,7 +2376,7 @@ int ugsm_stage_lr_check(ugsm_ctx *ctx, float *d_left3, const float *d_right3, in
 long long ugsm_last_lr_marked(ugsm_ctx *ctx, int slot)
 {
     Slot *s;
-    if (get_slot(ctx, slot, &s) != UGSM_OK) return -1;
+    if (get_slot(ctx, slot, &s, false) != UGSM_OK) return -1;
     return (s->lr_ran && s->lr_host) ? (long long)*s->lr_host : -1;
 }
 
@@ -2391,7 +2392,7 @@ int ugsm_slot_stream(ugsm_ctx *ctx, int slot, void **hip_stream)
 int ugsm_last_iterations(ugsm_ctx *ctx, int slot, int *per_level)
 {
     Slot *s;
-    UCHK(get_slot(ctx, slot, &s));
+    UCHK(get_slot(ctx, slot, &s, false));  // (reads host state only: the slot does not become busy)
     if (!per_level) return UGSM_ERR_BAD_ARG;
     for (int i = 0; i < UGSM_MAX_LEVELS; i++) per_level[i] = s->iters_run[i];
     return UGSM_OK;

@@ -214,10 +214,8 @@ int need_shard(ugsm_ctx *ctx, Shard **out, Rccl **lib)
 
 int slot_stream(ugsm_ctx *ctx, int slot, hipStream_t *st)
 {
-    void *p = nullptr;
-    const int r = ugsm_slot_stream(ctx, slot, &p);
-    *st = static_cast<hipStream_t>(p);
-    return r;
+    *st = static_cast<hipStream_t>(ctx_slot_stream(ctx, slot));
+    return *st ? UGSM_OK : ctx_fail(ctx, UGSM_ERR_BAD_ARG, "slot out of range");
 }
 
 // ugsm_wait / ugsm_poll on a slot (CtxHooks::shard_wait).  block: wait for the slot's step, at most until its deadline -- a step that is
