@@ -1603,8 +1603,9 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
     }
     // The side streams.  A call forks onto one only when it is alone on the chip -- every other slot idle -- so a slot BORROWS the stream of
     // the next slot: no stream is created that calls in flight would leave idle.  What decided this (profiles/r06_ab_side_streams.txt,
-    // r06_ab_lone_call.txt): side streams of the slots' own in ANOTHER priority pool cost a context with several calls in flight 28-38 %
-    // though never used; in the slots' own pool they cost such a context nothing, but eight streams on the pool's four hardware queues left
+    // r06_ab_lone_call.txt): side streams of the slots' own, created between the slots' streams in another priority pool, cost a context with
+    // several calls in flight 28-38 % though never used (which queues the slots' streams land on depends on what is created around them);
+    // created after them they cost such a context nothing in either pool, but eight streams on the pool's four hardware queues left
     // a lone call on a four-slot context 2-3 % behind the same call on a one-slot context (one of a slot's two streams shares a queue with a
     // neighbour's).  Borrowed, a lone call's two streams are two slots' streams: two hardware queues wherever the slots' streams have one each.
     // One stream in the whole context (one slot, or ugsm_config.streams = 1): one more stream, created here, serves every slot.
