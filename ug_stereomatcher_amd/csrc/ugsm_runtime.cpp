@@ -208,7 +208,7 @@ struct ugsm_ctx {
     std::string err;
     StatCell cells[KC_COUNT][UGSM_MAX_LEVELS + 1];
     int fuse_seed = 1, small_mask = 3, small_rh_force = 0;  // development overrides (apply_dev_env); the defaults are the product
-    int two_streams = 0;  // side streams in use (one-slot contexts; UGSM_TWO_STREAMS under UGSM_DEV=1 overrides)
+    int two_streams = 0;  // a call alone forks onto a side stream (every context; UGSM_TWO_STREAMS=0 under UGSM_DEV=1: never)
     int march4_lo = -1, march4_hi = -1;  // development override of k_cost_march4's pixel range (use_march4; -1 = by the mode; 0, 0 = never)
     int force_alone = -1;  // development override of call_alone(): 1 = every call is taken to be alone on the chip, 0 = none is
     int streams = 1;      // streams the slots' work is dealt onto: slot i enqueues on the stream of slot i % streams (ugsm_config.streams)
@@ -544,7 +544,7 @@ struct DevKnobs {
     int small_mask = 3;      // UGSM_SMALL_MASK: bit 0 = k_cost_small, bit 1 = k_smooth_small
     int small_rh_force = 0;  // UGSM_SMALL_RH: region height of k_smooth_small whatever the level size (18, 24 or 32)
     int force_alone = -1;    // UGSM_ALONE=1 / 0: the kernel choices of a call that has the chip to itself / that shares it, whatever is in flight
-    int two_streams = -1;    // UGSM_TWO_STREAMS=0 / 1: never / always use the slots' side streams (default: one-slot contexts only)
+    int two_streams = -1;    // UGSM_TWO_STREAMS=0: no call forks onto a side stream (default 1: a call that is alone does)
     char side_prio = 0;         // UGSM_SIDE_PRIO=h|n|l|s: a side stream of its own for every slot, at that priority (s: the slot's); default: borrowed (ugsm_create)
     char stream_prio[65] = "";  // UGSM_STREAM_PRIO: one letter per slot, h / n / l = greatest / default / least stream priority (slot_stream_priority)
     int march_mode = 0;      // UGSM_MARCH_MODE=0,-1,-2,-3: launch_cost_march's strip-height / age-class mode (default 0: latency heights, strips by age class)
