@@ -1602,7 +1602,7 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         }
     }
     // The side streams.  A call forks onto one only when it is alone on the chip -- every other slot idle -- so a slot BORROWS the stream of
-    // the next slot: no stream is created that calls in flight would leave idle.  What decided this (profiles/r06_ab_side_streams.txt,
+    // a neighbour: no stream is created that calls in flight would leave idle.  What decided this (profiles/r06_ab_side_streams.txt,
     // r06_ab_lone_call.txt): side streams of the slots' own, created between the slots' streams in another priority pool, cost a context with
     // several calls in flight 28-38 % though never used (which queues the slots' streams land on depends on what is created around them);
     // created after them they cost such a context nothing in either pool, but eight streams on the pool's four hardware queues left
@@ -1614,7 +1614,9 @@ int ugsm_create(const ugsm_config *cfg_in, ugsm_ctx **out)
         if (!knobs.side_prio) {
             Slot &s = ctx->slots[k];
             if (ctx->streams >= 2) {
-                s.st2 = ctx->slots[(k % ctx->streams + 1) % ctx->streams].st;
+                // (the slot BEFORE it in the rotation: a burst's first call is alone and forks -- the burst's second call then goes to the
+                // next slot, whose stream holds no borrowed work in front of it)
+                s.st2 = ctx->slots[(k % ctx->streams + ctx->streams - 1) % ctx->streams].st;
                 continue;
             }
             if (k > 0) {
