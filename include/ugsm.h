@@ -154,7 +154,7 @@ long long ugsm_pixel_iterations(int W, int H, int levels, int fovea_levels);
  * pairs waiting behind it in the queue -- so the blocking entry points (ugsm_match_*: the node's service call and its one-at-a-time
  * topic path) are alone whatever cfg->slots says, and the calls of a burst are not.  A call alone gets every launch as SHORT as possible
  * (nothing else fills the CUs a launch leaves idle: the coarse-level latency kernels up to 0.15 Mpx on their smallest tiles, K-smooth tile
- * heights that fill whole rounds of workgroups, the right pyramid and the A planes on a side stream -- the idle next slot's stream,
+ * heights that fill whole rounds of workgroups, the right pyramid and the A planes on a side stream -- an idle neighbour slot's stream,
  * borrowed for the call; a one-stream context has one stream more for it); a call that shares the
  * chip gets every launch doing little redundant work (latency kernels up to 50 k pixels only, on 18 x 18 tiles; one stream).
  * cost_kernel / smooth_kernel: 0 = LDS-tiled (k_smooth_fused; as a cost kernel: k_cost_split, libugsm_dev.so only), 1 = marching

@@ -439,8 +439,8 @@ def test_kernel_choices_follow_what_is_in_flight(lib, orc):
             c.free(p)
 
 
-def test_a_lone_call_borrows_the_next_slots_stream(lib, orc, monkeypatch):
-    """Round 6: a slot's side stream is the NEXT slot's own stream, borrowed by a call that has the chip to itself (ugsm_create).  What must
+def test_a_lone_call_borrows_a_neighbour_slots_stream(lib, orc, monkeypatch):
+    """Round 6: a slot's side stream is a NEIGHBOUR slot's own stream (the one before it in the rotation), borrowed by a call that has the chip to itself (ugsm_create).  What must
     hold whatever the neighbour is doing: (a) lone calls in turn on every slot of a four-slot, a three-slot and a shared-stream context; (b) a
     call submitted on the neighbour while the lone call is still in flight queues behind the borrowed work; (c) with UGSM_ALONE=1 EVERY call
     forks, four in flight, each onto a stream that is busy with its neighbour's call -- stream order and the events keep all of it correct.
@@ -476,7 +476,7 @@ def test_a_lone_call_borrows_the_next_slots_stream(lib, orc, monkeypatch):
 
     for kw in ({"slots": 4}, {"slots": 3}, {"slots": 4, "streams": 2}, {"slots": 2, "streams": 1}, {"slots": 1}):
         with lib.Context(levels=lv, fovea_levels=F, **kw) as c:
-            burst(c, kw["slots"], wait_each=True)      # (a): every call alone, forking onto the next slot's (idle) stream
+            burst(c, kw["slots"], wait_each=True)      # (a): every call alone, forking onto a neighbour's (idle) stream
             burst(c, kw["slots"], wait_each=False)     # (b): the first call of a round is alone and borrows; the others queue behind it
     monkeypatch.setenv("UGSM_DEV", "1")
     monkeypatch.setenv("UGSM_ALONE", "1")

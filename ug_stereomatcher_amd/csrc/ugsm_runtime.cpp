@@ -72,7 +72,7 @@ struct Slot {
     // that last microseconds and depend on nothing but the left pyramid.  The main stream joins it through events: ev_R before the
     // first level, ev_A[i] before level i's first K-cost launch, so a wait on the main stream still covers everything.
     // WHICH stream that is (round 6): a call uses a side stream only when it has the chip to itself (`alone`), i.e. when every other slot
-    // is idle -- so with two or more streams in the context the side stream of a slot is the NEXT SLOT'S OWN STREAM, borrowed for the call:
+    // is idle -- so with two or more streams in the context the side stream of a slot is A NEIGHBOUR SLOT'S OWN STREAM, borrowed for the call:
     // a context holds no stream that calls in flight leave idle, and a lone call's two streams sit on two hardware queues whatever way HIP
     // deals streams onto queues.  A context with one stream gets one stream more (owns_st2).
     hipStream_t st2 = nullptr;
