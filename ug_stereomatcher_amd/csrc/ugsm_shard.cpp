@@ -55,53 +55,62 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+void load_rccl(Rccl &r)
+{
+    // a copy that is already in the process first (RTLD_NOLOAD), then the system's
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) {
+        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) {
+            r.origin = std::string(n) + " (already loaded)";
+            break;
+        }
+    }
+    // (development: another library with RCCL's entry points -- tests/fake_rccl.c; like every UGSM_* variable, read under UGSM_DEV=1 only)
+    if (!r.handle && dev_env() && getenv("UGSM_RCCL_PATH")) {
+        if ((r.handle = dlopen(getenv("UGSM_RCCL_PATH"), RTLD_NOW | RTLD_LOCAL))) r.origin = getenv("UGSM_RCCL_PATH");
+    }
+    for (const char *n : names) {
+        if (r.handle) break;
+        if ((r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) r.origin = n;
+    }
+    if (!r.handle) {
+        if ((r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL))) r.origin = "/opt/rocm/lib/librccl.so.1";
+    }
+    if (!r.handle) return;
+    bool ok = true;
+    auto sym = [&](const char *name) {
+        void *p = dlsym(r.handle, name);
+        ok = ok && p != nullptr;
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) {
+        r.handle = nullptr;  // (left loaded: a library that lacks these symbols is not RCCL)
+        r.origin.clear();
+    }
+}
+
 Rccl *rccl()
 {
     static Rccl r;
     static std::once_flag once;
-    std::call_once(once, [] {
-        // a copy that is already in the process first (RTLD_NOLOAD), then the system's
-        const char *names[] = {"librccl.so.1", "librccl.so"};
-        for (const char *n : names) {
-            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) {
-                r.origin = std::string(n) + " (already loaded)";
-                break;
-            }
-        }
-        // (development: another library with RCCL's entry points -- tests/fake_rccl.c; like every UGSM_* variable, read under UGSM_DEV=1 only)
-        if (!r.handle && dev_env() && getenv("UGSM_RCCL_PATH")) {
-            if ((r.handle = dlopen(getenv("UGSM_RCCL_PATH"), RTLD_NOW | RTLD_LOCAL))) r.origin = getenv("UGSM_RCCL_PATH");
-        }
-        for (const char *n : names) {
-            if (r.handle) break;
-            if ((r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) r.origin = n;
-        }
-        if (!r.handle) {
-            if ((r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL))) r.origin = "/opt/rocm/lib/librccl.so.1";
-        }
-        if (!r.handle) return;
-        bool ok = true;
-        auto sym = [&](const char *name) {
-            void *p = dlsym(r.handle, name);
-            ok = ok && p != nullptr;
-            return p;
-        };
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
-        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
-        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
-        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
-        r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-        r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-        if (!ok) {
-            r.handle = nullptr;  // (left loaded: a library that lacks these symbols is not RCCL)
-            r.origin.clear();
+    std::call_once(once, []() noexcept {
+        try {
+            load_rccl(r);
+        } catch (...) {  // (out of host memory for the origin strings: no RCCL then, not an exception across the C-ABI)
+            r.handle = nullptr;
         }
     });
     return r.handle ? &r : nullptr;
