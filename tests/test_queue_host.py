@@ -32,7 +32,7 @@ class Completion(C.Structure):
 @pytest.fixture(scope="module")
 def fq(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("fakeq") / "libugsm_queue_fake.so")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fvisibility=hidden", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fvisibility=hidden",
            os.path.join(ROOT, "tests", "fake_runtime.cpp"), os.path.join(ROOT, "ug_stereomatcher_amd", "csrc", "ugsm_queue.cpp"),
            "-Wl,--version-script=" + os.path.join(ROOT, "ug_stereomatcher_amd", "csrc", "ugsm.map"), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)

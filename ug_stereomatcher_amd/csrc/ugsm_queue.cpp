@@ -7,8 +7,7 @@
 // ros::spin, :749-752) gets the same pipeline from three calls.  Written against the public slot-level entry points only.
 #include "ugsm_internal.hpp"
 
-#include <hip/hip_runtime.h>
-#include <time.h>
+#include <time.h>  // (no HIP header: the queue makes no HIP call -- tests/test_queue_host.py builds this file with g++ against a fake runtime)
 
 #include <algorithm>
 #include <cstring>
