@@ -10,4 +10,5 @@ hipcc -O2 --offload-arch=gfx950 tools/queue_probe.hip -o tools/queue_probe
 [ -f tools/valubench.hip ] && hipcc -O2 -std=c++17 --offload-arch=gfx950 tools/valubench.hip -o tools/valubench
 [ -f tools/ldsbench.hip ] && hipcc -O2 --offload-arch=gfx950 tools/ldsbench.hip -o tools/ldsbench
 hipcc -O3 --offload-arch=gfx950 tools/gridbar.hip -o tools/gridbar
+hipcc -O3 --offload-arch=gfx950 tools/pcie_probe.hip -o tools/pcie_probe
 echo "tools built"
