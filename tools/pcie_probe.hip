@@ -65,7 +65,7 @@ int main()
     report("down: six half-plane copies on three streams", down, time_ms([&] {
                for (int k = 0; k < 6; k++) CHK(hipMemcpyAsync(h + k * plane / 2, d + k * plane / 2, plane / 2, hipMemcpyDeviceToHost, st[k % 3]));
            }));
-    for (int blocks : {64, 256, 1024, 4096})
+    for (int blocks : {2, 4, 8, 16, 32, 64, 256, 1024, 4096})
         for (int threads : {256, 1024}) {
             char name[128];
             snprintf(name, sizeof name, "down: a kernel storing into the mapped host buffer, %d x %d threads", blocks, threads);
@@ -83,6 +83,24 @@ int main()
            time_ms([&] { hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st[0], (const float4 *)hd, (float4 *)d, up / 16); }));
     report("both ways at once: 193 MB down on one stream, 96 MB up on another", down + up, time_ms([&] {
                CHK(hipMemcpyAsync(h, d, down, hipMemcpyDeviceToHost, st[0]));
+               CHK(hipMemcpyAsync(d2, h2, up, hipMemcpyHostToDevice, st[1]));
+           }));
+    char *hd2 = nullptr;
+    CHK(hipHostGetDevicePointer((void **)&hd2, h2, 0));
+    report("both ways at once: hipMemcpyAsync down, a KERNEL loading the images up", down + up, time_ms([&] {
+               CHK(hipMemcpyAsync(h, d, down, hipMemcpyDeviceToHost, st[0]));
+               hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st[1], (const float4 *)hd2, (float4 *)d2, up / 16);
+           }));
+    report("both ways at once: a KERNEL storing the planes down, hipMemcpyAsync up", down + up, time_ms([&] {
+               hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st[0], (const float4 *)d, (float4 *)hd, down / 16);
+               CHK(hipMemcpyAsync(d2, h2, up, hipMemcpyHostToDevice, st[1]));
+           }));
+    report("both ways at once: kernels both ways", down + up, time_ms([&] {
+               hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st[0], (const float4 *)d, (float4 *)hd, down / 16);
+               hipLaunchKernelGGL(k_copy16, dim3(1024), dim3(256), 0, st[1], (const float4 *)hd2, (float4 *)d2, up / 16);
+           }));
+    report("both ways at once, equal sizes: 96 MB down and 96 MB up, hipMemcpyAsync both", 2 * up, time_ms([&] {
+               CHK(hipMemcpyAsync(h, d, up, hipMemcpyDeviceToHost, st[0]));
                CHK(hipMemcpyAsync(d2, h2, up, hipMemcpyHostToDevice, st[1]));
            }));
     return 0;
