@@ -1939,6 +1939,18 @@ int ugsm_wait_all(ugsm_ctx *ctx)
     return first;
 }
 
+// A blocking entry point that failed part-way: whatever it did enqueue -- uploads that read the caller's images, on the slot's stream or on
+// the side stream -- has drained before the caller hears of the failure.  "When the call returns the buffers are the caller's again"
+// holds for a failed call too (the reference exit()s instead, MatchGPULib.cpp passim).
+static int drained(ugsm_ctx *ctx, int slot, int st)
+{
+    if (st == UGSM_OK || !ctx || slot < 0 || slot >= (int)ctx->slots.size()) return st;
+    const std::string why = ctx->err;
+    (void)ugsm_wait(ctx, slot);
+    ctx->err = why;
+    return st;
+}
+
 // The service call on a slot: upload, pyramids, match, results into caller memory.  `sync` = the reference's call (returns when the
 // planes are in place; pageable or page-locked memory); otherwise everything is only enqueued and every buffer must be page-locked.
 static int match_full_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
@@ -1967,7 +1979,7 @@ static int match_full_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, cons
 int ugsm_match_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
                     float *dispV, float *dispC)
 {
-    return match_full_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, dispH, dispV, dispC, true);
+    return drained(ctx, 0, match_full_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, dispH, dispV, dispC, true));
 }
 
 int ugsm_submit_full_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, float *dispH,
@@ -2021,7 +2033,7 @@ static int match_foveated_on_slot(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, 
 int ugsm_match_foveated(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
                         int off_y, float *stackH, float *stackV, float *stackC, float *pyrL, float *pyrR)
 {
-    return match_foveated_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, off_x, off_y, stackH, stackV, stackC, pyrL, pyrR, true);
+    return drained(ctx, 0, match_foveated_on_slot(ctx, 0, rgbL, rgbR, W, H, stride, off_x, off_y, stackH, stackV, stackC, pyrL, pyrR, true));
 }
 
 int ugsm_submit_foveated_host(ugsm_ctx *ctx, int slot, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x,
@@ -2137,8 +2149,8 @@ int ugsm_submit_foveated_batch_host(ugsm_ctx *ctx, int slot, int n, const uint8_
 }
 
 // match(L, R, fov == 1), MatchGPULib.cpp:354-360: foveated matching, then hierarchicalDisparity on the stacks
-int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
-                             float *outH, float *outV, float *outC)
+static int match_foveated_full_on_slot0(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                                        float *outH, float *outV, float *outC)
 {
     Slot *s;
     UCHK(get_slot(ctx, 0, &s));
@@ -2161,7 +2173,13 @@ int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *
     float *const dst[3] = {outH, outV, outC};
     prefault_planes(ctx, dst, n);
     UCHK(copy_out_planes(ctx, *s, d_full, n, dst));
+    s->forked = false;  // (enqueued whole, as mark_done)
     return ugsm_wait(ctx, 0);
+}
+int ugsm_match_foveated_full(ugsm_ctx *ctx, const uint8_t *rgbL, const uint8_t *rgbR, int W, int H, int stride, int off_x, int off_y,
+                             float *outH, float *outV, float *outC)
+{
+    return drained(ctx, 0, match_foveated_full_on_slot0(ctx, rgbL, rgbR, W, H, stride, off_x, off_y, outH, outV, outC));
 }
 
 // ---- stage-level ------------------------------------------------------------------------
