@@ -174,7 +174,10 @@ class Host:
 
 def plan(lib, slots, batch, n):
     """ugsm_queue_plan: what the header says a burst of n pairs becomes."""
-    from ug_stereomatcher_amd._lib import Config
+    class Config(C.Structure):   # ugsm_config (include/ugsm.h; the layout is pinned against the header by tests/test_abi_host.py through _lib.Config)
+        _fields_ = [(n, C.c_float if n in ("early_exit_threshold", "lr_check_threshold") else C.c_int) for n in (
+            "device", "levels", "fovea_levels", "slots", "kernel_path", "profile_events", "march_min_pixels", "march_np", "march_rows", "march_smooth",
+            "early_exit_threshold", "small_max_pixels", "lr_check_threshold", "streams", "batch", "stream_priority")]
     cfg = Config()
     cfg.slots, cfg.batch, cfg.levels, cfg.fovea_levels = slots, batch, 8, 4
     sizes = (C.c_int * 64)()
